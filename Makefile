@@ -1,0 +1,41 @@
+# Top-level build: the gfx950 engine (libm3hip.so), the synthetic-MC generator
+# (libm3synth.so) and the test-only CPU oracle (oracle/).  No cmake needed.
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+LIBDIR = mach3_amd/lib
+CSRC = mach3_amd/csrc
+
+# -ffp-contract=off : only the explicit fmaf() calls fuse (bit-parity with the reference order)
+# -munsafe-fp-atomics: hardware f64 atomic add (global_atomic_add_f64 / ds_add_f64), no CAS loop
+HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -munsafe-fp-atomics \
+           -Wall -Wextra -Wno-unused-parameter -Iinclude
+
+all: $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so oracle
+
+$(LIBDIR)/libm3hip.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp \
+                       $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+
+$(LIBDIR)/libm3synth.so: mach3_amd/synth/m3synth.c mach3_amd/synth/m3synth.h
+	@mkdir -p $(LIBDIR)
+	$(CC) -O3 -fPIC -shared -fopenmp -ffp-contract=off -Wall -Wextra -o $@ mach3_amd/synth/m3synth.c -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+isa: $(CSRC)/m3hip_kernels.hip
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage \
+	    -o build/m3hip_kernels.o $(CSRC)/m3hip_kernels.hip
+
+clean:
+	rm -f $(LIBDIR)/*.so build/*
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean isa
+
+examples:
+	@true
+.PHONY: examples

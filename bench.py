@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC-step (LLH evaluation) throughput of the MI355X likelihood engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic MC:
+    new parameter vector -> SampleHandlerFD::Reweight() -> GetLikelihood() -> LLH on the host
+(the pair MR2T2::ProposeStep runs per proposal, ref: Fitters/MR2T2.cpp:66-76), timed
+DragRace-style (ref: Fitters/FitterBase.cpp:461-489).
+
+Workload: BASELINE.json configs[1] ("c2": 1e6 events, 128 TSpline3 systematics x 7 knots,
+single-sample Poisson LLH) PER GPU; with N > 1 every rank holds its own 1e6-event shard of an
+N x 1e6-event sample and each step ends in ONE RCCL all-reduce of the bin-rate vector (weak
+scaling).  value = N * K / t: LLH evaluations of a 1e6-event shard per second, which at
+N = 1 is exactly MCMC steps/s on configs[1].
+
+Prints ONE JSON line on rank 0 (contract in the task description), carrying `roofline`
+(fused reweight kernel: algorithmic bytes / hipEvent-measured launch time vs 8 TB/s) and,
+at N = 1, `cpu_baseline` (the OpenMP oracle port timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(spec, budget_s=12.0, sample_events=100_000):
+    """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events`
+    events of the same workload; steps/s scaled to the full event count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from mach3_amd import synth
+
+    n = min(sample_events, spec.n_events)
+    threads = min(os.cpu_count() or 1, 16)  # the reference caps at 16 threads (Manager/Monitor.cpp:122-138)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp")
+    lib = ob.load("omp")
+    threads = lib.m3o_max_threads()
+    samp.reweight()
+    samp.add_data(samp.mc)
+    laps, t_spl, t_fill = 0, 0.0, 0.0
+    for lap in range(1, 4):  # warm-up
+        par[:] = synth.params(spec, lap)
+        samp.reweight()
+        samp.get_likelihood()
+    t0 = time.perf_counter()
+    while True:
+        par[:] = synth.params(spec, 100 + laps)
+        samp.reweight()
+        samp.get_likelihood()
+        a, b = samp.last_timing()
+        t_spl += a
+        t_fill += b
+        laps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or laps >= 200:
+            break
+    sps_sample = laps / el
+    samp.close()
+    mono.close()
+    return {
+        "value": sps_sample * n / spec.n_events,
+        "unit": "steps/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"first {n} of {spec.n_events} events, {laps} laps in {el:.1f} s "
+                  f"({1e3 * el / laps:.2f} ms/lap: spline eval {1e3 * t_spl / laps:.2f} ms, fill {1e3 * t_fill / laps:.2f} ms); "
+                  f"steps/s scaled by {n}/{spec.n_events}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--events", type=int, default=0, help="override events per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=131072)
+    args = ap.parse_args()
+
+    import torch  # device sync + torch.distributed (RCCL) plumbing only
+
+    from mach3_amd import synth
+    from mach3_amd.engine import build_from_synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    base = synth.CONFIGS[args.config]
+    per_gpu = args.events or base.n_events
+    spec = base.scaled(per_gpu * n_gpus)
+    e0, e1 = rank * per_gpu, (rank + 1) * per_gpu
+
+    t_setup = time.perf_counter()
+    eng, mono, sh, par = build_from_synth(spec, device_id=local_rank, chunk_events=args.chunk, event_range=(e0, e1))
+    info = eng.info()
+    if rank == 0:
+        log(f"[bench] {spec.name}: {per_gpu} events/GPU x {n_gpus} GPU, P={spec.n_params}, S={info.n_splines}, "
+            f"T={info.n_tf1}, coeff store {info.coeff_bytes / 1e9:.2f} GB, tiles {info.n_tiles_uniform}u/"
+            f"{info.n_tiles_brick}b, setup {time.perf_counter() - t_setup:.1f} s")
+
+    comm_mode = "none"
+    if world > 1:
+        # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], rank, world)
+        comm_mode = "rccl-allreduce(f64[n_bins]) in-library"
+
+    # Asimov data at nominal (ref: Fitters/MaCh3Factory.h:142-153); freezes W2 as the reference does
+    par[:] = synth.params(spec, 0)
+    sh.Reweight()
+    sh.AddData(sh.GetMCArray())
+    assert abs(sh.GetLikelihood()) < 1e-9
+
+    laps = [synth.params(spec, 1 + i) for i in range(64)]
+
+    def step(i):
+        par[:] = laps[i % len(laps)]
+        return sh.Step()
+
+    for i in range(args.warmup):
+        step(i)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    llh = 0.0
+    for i in range(args.steps):
+        llh = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    k_ms, k_n = eng.timing_read(0)
+    eng.timing_enable(False)
+
+    if rank == 0:
+        out = {
+            "metric": "LLH evaluations/sec (MCMC steps/sec)",
+            "value": n_gpus * args.steps / el,
+            "unit": "steps/s" if n_gpus == 1 else "steps/s x shards (one 1e6-event shard per GPU)",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1] ({base.name}): {per_gpu} events/GPU, {spec.n_params} TSpline3 systematics x "
+                            f"{spec.n_knots} knots (occupancy {spec.occupancy:g}), {spec.n_norm} norm systematics, pre-staged osc table, "
+                            f"{spec.total_bins} bins, Poisson LLH",
+                "events_per_gpu": per_gpu,
+                "total_events": per_gpu * n_gpus,
+                "spline_responses_per_gpu": int(info.n_splines),
+                "comm": comm_mode,
+                "steps_per_s": args.steps / el,
+                "last_llh": llh,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_reweight_uniform<fill> (spline eval + weight product + bin fill, fused)",
+                "achieved": info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
+                "traffic": None,
+                "alg_bytes_per_launch": int(info.alg_bytes_fused),
+                "avg_kernel_ms": k_ms,
+                "launches_timed": int(k_n),
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(base.scaled(per_gpu))
+            except Exception as e:  # the GPU number stands on its own
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,232 @@
+/*
+ * m3hip.h -- C ABI of the MI355X (gfx950) per-step likelihood engine for MaCh3.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each
+ * entry point names the reference interface it replaces (file:line under the MaCh3
+ * v2.4.2 tree).  The C++ facade in include/mach3_amd/ re-exposes the reference's class
+ * names (SMonolithGPU, SMonolith, SampleHandlerFD) on top of exactly these calls.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative M3HIP_E* code otherwise;
+ *     m3hip_last_error() gives the message (the reference logs + throws
+ *     MaCh3Exception, Manager/MaCh3Exception.h:29-38; the facade rethrows).
+ *   - host arrays are copied during the call; the caller keeps ownership.
+ *   - one handle <-> one device <-> one HIP stream; calls on a handle must come from
+ *     one host thread at a time (the reference's step loop is single threaded).
+ *   - there is NO CPU fallback: without a usable HIP device m3hip_create fails.
+ */
+#ifndef M3HIP_H
+#define M3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3HIP_OK 0
+#define M3HIP_EINVAL (-1)  /* bad argument / inconsistent input arrays */
+#define M3HIP_EHIP (-2)    /* HIP runtime error */
+#define M3HIP_ESTATE (-3)  /* call out of order */
+#define M3HIP_ENOMEM (-4)
+#define M3HIP_ECOMM (-5)   /* RCCL error */
+
+/* Samples/SampleStructs.h:105-112 -- same numeric values as enum TestStatistic */
+#define M3HIP_kPoisson 0
+#define M3HIP_kBarlowBeeston 1
+#define M3HIP_kIceCube 2
+#define M3HIP_kPearson 3
+#define M3HIP_kDembinskiAbdelmotteleb 4
+
+/* Manager/Core.h:80-91 */
+#define M3HIP_LARGE_LOGL 1234567890.0
+#define M3HIP_LOW_MC_BOUND 0.00001
+#define M3HIP_UNDER_OVERFLOW_BIN (-1)
+
+typedef struct m3hip_ctx* m3hip_handle;
+
+/* ------------------------------------------------------------------------------------
+ * Lifetime.  Replaces: SMonolithGPU::SMonolithGPU / ~SMonolithGPU
+ * (Splines/gpuSplineUtils.cu:77-110), SetDevice/ResetDevice (Manager/gpuUtils.cu:85-111).
+ * ---------------------------------------------------------------------------------- */
+int m3hip_create(int device_id, m3hip_handle* out);
+int m3hip_destroy(m3hip_handle h);
+/* message of the last failure on h (h == NULL: last failure of m3hip_create) */
+const char* m3hip_last_error(m3hip_handle h);
+/* run on a caller-owned hipStream_t instead of the handle's own stream (NULL restores it) */
+int m3hip_set_stream(m3hip_handle h, void* hip_stream);
+/* device memory in use / total, bytes.  Replaces checkGpuMem (Manager/gpuUtils.cu:40-56) */
+int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes);
+
+/* ------------------------------------------------------------------------------------
+ * Seam 2: the spline-monolith backend (class SMonolithGPU, Splines/gpuSplineUtils.cuh:63-218)
+ * ---------------------------------------------------------------------------------- */
+
+/* Pinned host buffers.  Replaces InitGPU_Segments / InitGPU_Vals and the pinned
+ * cpu_total_weights of InitGPU_SplineMonolith (gpuSplineUtils.cu:116-171), and
+ * CleanupGPU_Segments / the cudaFreeHost in CleanupGPU_SplineMonolith (:519-570). */
+int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes);
+int m3hip_free_pinned(m3hip_handle h, void* ptr);
+
+/*
+ * One-time upload of the flattened monolith.  Replaces InitGPU_SplineMonolith +
+ * CopyToGPU_SplineMonolith (gpuSplineUtils.cu:116-333).  Input is the reference's flat
+ * layout as built by SMonolith::PrepareForGPU (Splines/SplineMonolith.cpp:53-250):
+ *   coeff_x[n_params*max_knots]      knot x per parameter (SplineCommon.h:36)
+ *   npts[n_params]                   FastSplineInfo.nPts per parameter (SplineStructs.h:37);
+ *                                    <= 1 for parameters without a TSpline3 (TF1 / unused)
+ *   coeff_many[4*total_nknots]       AoS {y,b,c,d} per knot (SplineCommon.h:39)
+ *   nknots_arr[n_splines]            first knot of each spline (SplineCommon.h:42)
+ *   param_no[n_splines]              parameter of each spline (SplineCommon.h:45)
+ *   coeff_tf1[2*n_tf1], param_no_tf1[n_tf1]   (SplineMonolith.h:130-137, _nTF1Coeff_ = 2)
+ *   n_param_per_event[2*n_events]    {count,start} (SplineMonolith.h:124)
+ *   n_param_per_event_tf1[2*n_events]{count,start} (SplineMonolith.h:127)
+ * Unlike the reference, n_params is a run-time value (the reference needs a recompile,
+ * gpuSplineUtils.cu:211-216) and the data are re-laid-out on upload.
+ *
+ * Large monoliths (> 2^32 coefficients, which the reference's unsigned offsets cannot
+ * address) are streamed in event-ordered chunks: begin / append / end.  Offsets inside a
+ * chunk are chunk-local.  Every chunk but the last must hold a multiple of 1024 events.
+ */
+int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x,
+                         const int16_t* npts);
+int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many,
+                          uint64_t total_nknots, const unsigned int* nknots_arr,
+                          const int16_t* param_no, uint64_t n_splines, const float* coeff_tf1,
+                          const int16_t* param_no_tf1, uint64_t n_tf1,
+                          const unsigned int* n_param_per_event,
+                          const unsigned int* n_param_per_event_tf1);
+int m3hip_monolith_end(m3hip_handle h);
+/* begin + one append + end */
+int m3hip_upload_monolith(m3hip_handle h, uint64_t n_events, int n_params, int max_knots,
+                          const float* coeff_x, const int16_t* npts, const float* coeff_many,
+                          uint64_t total_nknots, const unsigned int* nknots_arr,
+                          const int16_t* param_no, uint64_t n_splines, const float* coeff_tf1,
+                          const int16_t* param_no_tf1, uint64_t n_tf1,
+                          const unsigned int* n_param_per_event,
+                          const unsigned int* n_param_per_event_tf1);
+
+/*
+ * Per step.  Replaces RunGPU_SplineMonolith(cpu_total_weights, vals, segment, n_splines,
+ * n_tf1) (gpuSplineUtils.cu:444-512): evaluates every TSpline3 / TF1 response and the
+ * per-event product (EvalOnGPU_Splines + EvalOnGPU_TF1 + EvalOnGPU_TotWeight, :337-438) in
+ * ONE kernel and, if cpu_total_weights != NULL, starts the async device-to-host copy of
+ * the n_events total weights.  vals / segment are what SplineBase::FindSplineSegment
+ * (Splines/SplineBase.cpp:44-109) produced on the host.  Asynchronous.
+ */
+int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment,
+                       float* cpu_total_weights);
+/* Replaces SynchroniseSplines (gpuSplineUtils.cu:71-73) */
+int m3hip_sync(m3hip_handle h);
+
+/* ------------------------------------------------------------------------------------
+ * Seam 3: the sample operator (SampleHandlerBase::Reweight / GetLikelihood,
+ * Samples/SampleHandlerBase.h:40-49, as implemented by SampleHandlerFD.cpp:316-463,
+ * 568-594, 1262-1300).  Spline evaluation, weight product, bin fill and bin LLH all stay
+ * on the device; per step only the parameter vector goes in and the LLH comes out.
+ * ---------------------------------------------------------------------------------- */
+
+/* Which entry of the global parameter vector drives spline parameter i.
+ * Replaces SMonolith::setSplinePointers (Splines/SplineMonolith.h:44-46), whose
+ * `const double*` are addresses inside ParameterHandlerBase::_fPropVal. */
+int m3hip_set_spline_param_map(m3hip_handle h, const int32_t* global_index, int n_params);
+
+/* Global binning: sample s owns global bins [sample_bin_offset[s], sample_bin_offset[s+1])
+ * (BinningHandler::SetGlobalBinNumbers, Samples/BinningHandler.cpp:341-355). */
+int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_offset);
+
+/*
+ * Per-event sample-side data for events [event_offset, event_offset+n), any chunking:
+ *   bin_idx   global bin of the event (FindGlobalBin result, BinningHandler.cpp:257-291);
+ *             -1 = under/overflow.  Static kinematics (no functional shifts).
+ *   osc_idx   index into the oscillation-weight table, -1 = no oscillation pointer
+ *             (SampleHandlerFD.cpp:1108-1133: NC / unity weights are not pushed)
+ *   norm_off[n+1], norm_idx[]   CSR of global parameter indices whose values are the
+ *             event's norm_pointers (FarDetectorCoreInfoStruct.h:109), chunk-local offsets
+ * Must be called after m3hip_monolith_end.
+ */
+int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n,
+                        const int32_t* bin_idx, const int32_t* osc_idx,
+                        const uint64_t* norm_off, const int16_t* norm_idx);
+
+/* Pre-staged oscillation weights (what OscillationHandler::Evaluate leaves behind the
+ * event pointers, Samples/OscillationHandler.cpp:81-119).  May be re-uploaded per step. */
+int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n);
+
+/* SampleHandlerFD::AddData for all global bins (SampleHandlerFD.cpp:1027-1044) */
+int m3hip_set_data(m3hip_handle h, const double* data, int n_bins);
+/* SampleHandlerBase::SetTestStatistic (SampleHandlerBase.h:185) + LikelihoodOptions:UpdateW2
+ * (SampleHandlerFD.cpp:62-65) */
+int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2);
+
+/* SampleHandlerFD::Reweight() (SampleHandlerFD.cpp:316-343) for parameter vector
+ * params[n_par] (the proposed values, ParameterHandlerBase.h:205).  Asynchronous. */
+int m3hip_reweight(m3hip_handle h, const double* params, int n_par);
+/* SampleHandlerFD::GetLikelihood() (+ GetSampleLikelihood(i) into per_sample[n_samples],
+ * may be NULL).  Runs the bin-LLH kernel, copies the result back and synchronises. */
+int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample);
+/* reweight + get_likelihood: one MCMC step's `samples[i]->Reweight(); llh +=
+ * samples[i]->GetLikelihood()` pair (Fitters/MR2T2.cpp:66-76) */
+int m3hip_step(m3hip_handle h, const double* params, int n_par, double* llh_total,
+               double* per_sample);
+
+/* GetMCArray / GetW2Array (SampleHandlerFD.h:162-187).  Synchronises. */
+int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins);
+/* Device-side results for parity checks: the monolith's per-event total weight
+ * (SMonolith::cpu_total_weights) and the full CalcWeightTotal weight.  Synchronises. */
+int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n);
+/* enable = 1: subsequent m3hip_reweight calls also store both per-event weights (off by
+ * default: the fused step writes nothing per event) */
+int m3hip_record_event_weights(m3hip_handle h, int enable);
+int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n);
+/* state written by the device-side FindSplineSegment of the last reweight */
+int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_params);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU (new; the reference is single device, Manager/gpuUtils.cu:71).  Events are
+ * sharded over ranks; m3hip_reweight then ends with ONE in-place ncclAllReduce(sum) of the
+ * per-bin rate vector (and of w2 while it is being updated) before the LLH kernel.
+ * ---------------------------------------------------------------------------------- */
+#define M3HIP_UNIQUE_ID_BYTES 128
+int m3hip_comm_get_unique_id(void* out_id /*128 bytes*/);
+int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks);
+int m3hip_comm_destroy(m3hip_handle h);
+
+/* ------------------------------------------------------------------------------------
+ * Introspection / measurement
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t n_events, n_splines, n_tf1;
+  uint64_t n_tiles_uniform, n_tiles_brick;
+  uint64_t coeff_bytes;     /* device bytes of the re-laid-out coefficient store */
+  uint64_t alg_bytes_eval;  /* 16*S + 8*T + 4*E : algorithmic bytes of one spline-eval launch */
+  uint64_t alg_bytes_fused; /* 16*S + 8*T + 8*E : ... of one fused reweight launch */
+  int n_params, max_knots, n_bins, n_samples;
+} m3hip_info;
+int m3hip_get_info(m3hip_handle h, m3hip_info* out);
+/* Average duration (ms) of the dominant kernel over the launches since the last reset,
+ * measured with hipEvents on the stream the kernel runs on.  which: 0 = fused reweight
+ * kernel, 1 = spline-eval kernel. */
+int m3hip_timing_enable(m3hip_handle h, int enable);
+int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches);
+int m3hip_timing_reset(m3hip_handle h);
+
+/* Host-only probe of the upload re-layout (no device needed): sizes[4] = {n_tiles,
+ * spline store in float4, TF1 store in float2, slot-meta in int32}; with non-NULL output
+ * buffers of those sizes it also fills them and tile_desc[n_tiles][8] = {spl_off, tf1_off,
+ * meta_off, n_spl_slots, n_tf1_slots, n_events, kind, n_planes}.  Used by the CPU tests. */
+int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_t n_events,
+                       const float* coeff_many, uint64_t total_nknots,
+                       const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
+                       const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
+                       const unsigned int* n_param_per_event,
+                       const unsigned int* n_param_per_event_tf1, uint64_t* sizes, float* spl,
+                       float* tf1, int32_t* meta, uint64_t* tile_desc);
+
+const char* m3hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

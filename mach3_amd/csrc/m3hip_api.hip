@@ -1,0 +1,891 @@
+// m3hip_api.hip -- implementation of the C ABI declared in include/m3hip.h.
+// Host orchestration only: device memory, the per-step launch sequence, RCCL, timing.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/m3hip.h"
+#include "m3hip_kernels.h"
+#include "m3hip_layout.h"
+
+using namespace m3hip;
+
+namespace {
+
+constexpr int kRing = 4;  // parameter staging slots in flight
+
+struct m3hip_unique_id_t {  // same size/layout as ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+  char internal[M3HIP_UNIQUE_ID_BYTES];
+};
+
+struct Chunk {
+  void* d_spl = nullptr;
+  void* d_tf1 = nullptr;
+  int32_t* d_meta = nullptr;
+};
+
+// RCCL is loaded on demand so that single-GPU users never touch it.
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, m3hip_unique_id_t, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load(std::string* err) {
+    if (lib) return true;
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { *err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *err = "librccl lacks nccl* symbols"; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
+std::string g_create_err;
+
+}  // namespace
+
+struct m3hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+
+  // monolith
+  int P = 0, K = 0;
+  std::vector<int16_t> h_npts;
+  float* d_coeff_x = nullptr;
+  int16_t* d_npts = nullptr;
+  bool mono_open = false, mono_done = false;
+  uint64_t E = 0, S = 0, T = 0, coeff_bytes = 0, E_pad = 0;
+  uint64_t n_uniform = 0, n_brick = 0;
+  std::vector<Chunk> chunks;
+  std::vector<TileDev> h_tiles;
+  TileDev* d_tiles = nullptr;
+
+  // per-step parameter state
+  PTab* d_ptab = nullptr;
+  float* d_pval = nullptr;
+  int16_t* d_seg = nullptr;
+  int16_t* d_currseg = nullptr;
+  int32_t* d_parmap = nullptr;
+  bool parmap_set = false;
+  double* h_params[kRing] = {nullptr, nullptr, nullptr, nullptr};  // pinned, device-mapped
+  double* d_params_src[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  bool ring_used[kRing] = {false, false, false, false};
+  int ring_pos = 0;
+  int par_cap = 0;
+  double* d_params = nullptr;  // [par_cap + 1]
+  float* h_vals = nullptr;     // pinned staging for the vals/segments path
+  int16_t* h_segs = nullptr;
+  float* d_vals_in = nullptr;
+  int16_t* d_segs_in = nullptr;
+
+  // events
+  int32_t* d_bin = nullptr;
+  int32_t* d_osc = nullptr;
+  int16_t* d_nidx = nullptr;
+  uint32_t M = 0;
+  float* d_spline_w = nullptr;
+  float* d_event_w = nullptr;
+  float* d_osc_table = nullptr;
+  uint64_t n_osc = 0;
+
+  // bins
+  int n_bins = 0, n_samples = 0;
+  int32_t* d_sample_off = nullptr;
+  double* d_data = nullptr;
+  double* d_hist = nullptr;
+  int teststat = M3HIP_kPoisson;
+  bool update_w2 = false, first_w2 = true;
+  double* h_out = nullptr;  // pinned, device-mapped: [1 + n_samples]
+  double* d_out = nullptr;
+  bool want_event_w = false;
+
+  // comm
+  void* comm = nullptr;
+  int rank = 0, n_ranks = 1;
+
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int pending = -1;
+  double acc_ms[2] = {0, 0};
+  uint64_t cnt[2] = {0, 0};
+};
+
+namespace {
+
+int fail(m3hip_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_err = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return fail(h, e_ == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP,                          \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                \
+  } while (0)
+
+template <class T>
+int dev_alloc(m3hip_handle h, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+  return M3HIP_OK;
+}
+
+void dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+void collect_timing(m3hip_handle h) {
+  if (h->pending >= 0) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
+      h->acc_ms[h->pending] += ms;
+      h->cnt[h->pending]++;
+    }
+    h->pending = -1;
+  }
+}
+
+int ensure_param_capacity(m3hip_handle h, int n_par) {
+  if (n_par <= h->par_cap) return M3HIP_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < kRing; ++i) {
+    if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
+    HIPCHK(h, hipHostMalloc((void**)&h->h_params[i], sizeof(double) * n_par, hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_params_src[i], h->h_params[i], 0));
+    h->ring_used[i] = false;
+  }
+  dev_free(h->d_params);
+  int rc = dev_alloc(h, &h->d_params, size_t(n_par) + 1);
+  if (rc) return rc;
+  h->par_cap = n_par;
+  return M3HIP_OK;
+}
+
+void free_monolith(m3hip_handle h) {
+  for (auto& c : h->chunks) {
+    dev_free(c.d_spl);
+    dev_free(c.d_tf1);
+    dev_free(c.d_meta);
+  }
+  h->chunks.clear();
+  h->h_tiles.clear();
+  dev_free(h->d_tiles); h->d_tiles = nullptr;
+  dev_free(h->d_coeff_x); h->d_coeff_x = nullptr;
+  dev_free(h->d_npts); h->d_npts = nullptr;
+  dev_free(h->d_ptab); h->d_ptab = nullptr;
+  dev_free(h->d_pval); h->d_pval = nullptr;
+  dev_free(h->d_seg); h->d_seg = nullptr;
+  dev_free(h->d_currseg); h->d_currseg = nullptr;
+  dev_free(h->d_parmap); h->d_parmap = nullptr;
+  dev_free(h->d_vals_in); h->d_vals_in = nullptr;
+  dev_free(h->d_segs_in); h->d_segs_in = nullptr;
+  dev_free(h->d_bin); h->d_bin = nullptr;
+  dev_free(h->d_osc); h->d_osc = nullptr;
+  dev_free(h->d_nidx); h->d_nidx = nullptr;
+  dev_free(h->d_spline_w); h->d_spline_w = nullptr;
+  dev_free(h->d_event_w); h->d_event_w = nullptr;
+  if (h->h_vals) { (void)hipHostFree(h->h_vals); h->h_vals = nullptr; }
+  if (h->h_segs) { (void)hipHostFree(h->h_segs); h->h_segs = nullptr; }
+  h->M = 0;
+  h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
+  h->n_uniform = h->n_brick = 0;
+  h->mono_open = h->mono_done = false;
+  h->parmap_set = false;
+}
+
+ReweightArgs make_rw_args(m3hip_handle h) {
+  ReweightArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tiles = h->d_tiles;
+  a.ptab = h->d_ptab;
+  a.pval = h->d_pval;
+  a.spline_w = h->d_spline_w;
+  a.event_w = h->d_event_w;
+  a.bin = h->d_bin;
+  a.osc = h->d_osc;
+  a.nidx = h->d_nidx;
+  a.params = h->d_params;
+  a.osc_table = h->d_osc_table;
+  a.hist = h->d_hist;
+  a.e_pad = h->E_pad;
+  a.n_norm_slots = h->M;
+  a.n_bins = h->n_bins;
+  a.fill_w2 = h->first_w2 ? 1 : 0;
+  a.tile_base = 0;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* m3hip_version(void) { return "mach3_amd/m3hip 0.1 (gfx950)"; }
+
+const char* m3hip_last_error(m3hip_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int m3hip_create(int device_id, m3hip_handle* out) {
+  if (!out) return fail(nullptr, M3HIP_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, M3HIP_EHIP, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                         "); this engine has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, M3HIP_EINVAL, "device_id out of range");
+  m3hip_ctx* h = new m3hip_ctx();
+  h->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+    std::string m = hipGetErrorString(e);
+    delete h;
+    return fail(nullptr, M3HIP_EHIP, "device initialisation failed: " + m);
+  }
+  for (int i = 0; i < kRing; ++i) (void)hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming);
+  h->stream = h->own_stream;
+  *out = h;
+  return M3HIP_OK;
+}
+
+int m3hip_destroy(m3hip_handle h) {
+  if (!h) return M3HIP_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  m3hip_comm_destroy(h);
+  free_monolith(h);
+  for (int i = 0; i < kRing; ++i) {
+    if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
+    if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+  }
+  dev_free(h->d_params);
+  dev_free(h->d_osc_table);
+  dev_free(h->d_sample_off);
+  dev_free(h->d_data);
+  dev_free(h->d_hist);
+  if (h->h_out) (void)hipHostFree(h->h_out);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return M3HIP_OK;
+}
+
+int m3hip_set_stream(m3hip_handle h, void* hip_stream) {
+  if (!h) return M3HIP_EINVAL;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return M3HIP_OK;
+}
+
+int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes) {
+  if (!h) return M3HIP_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemGetInfo(free_bytes, total_bytes));
+  return M3HIP_OK;
+}
+
+int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes) {
+  if (!h || !ptr) return M3HIP_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return M3HIP_OK;
+}
+
+int m3hip_free_pinned(m3hip_handle h, void* ptr) {
+  if (!h) return M3HIP_EINVAL;
+  if (ptr) HIPCHK(h, hipHostFree(ptr));
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- monolith upload */
+
+int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x, const int16_t* npts) {
+  if (!h) return M3HIP_EINVAL;
+  if (n_params <= 0 || n_params > 32767 || max_knots < 1 || !coeff_x || !npts)
+    return fail(h, M3HIP_EINVAL, "monolith_begin: bad n_params / max_knots / NULL arrays");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_monolith(h);
+  h->P = n_params;
+  h->K = max_knots;
+  h->h_npts.assign(npts, npts + n_params);
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_coeff_x, size_t(n_params) * max_knots))) return rc;
+  if ((rc = dev_alloc(h, &h->d_npts, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_ptab, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_pval, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_seg, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_currseg, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_parmap, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_vals_in, size_t(n_params)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_segs_in, size_t(n_params)))) return rc;
+  HIPCHK(h, hipHostMalloc((void**)&h->h_vals, sizeof(float) * n_params, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_segs, sizeof(int16_t) * n_params, hipHostMallocDefault));
+  HIPCHK(h, hipMemcpy(h->d_coeff_x, coeff_x, sizeof(float) * n_params * max_knots, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_npts, npts, sizeof(int16_t) * n_params, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(h->d_currseg, 0, sizeof(int16_t) * n_params));  // FastSplineInfo(): CurrSegment = 0
+  HIPCHK(h, hipMemset(h->d_seg, 0, sizeof(int16_t) * n_params));      // SplineMonolith.cpp:91
+  std::vector<int32_t> ident(n_params);
+  for (int i = 0; i < n_params; ++i) ident[i] = i;
+  HIPCHK(h, hipMemcpy(h->d_parmap, ident.data(), sizeof(int32_t) * n_params, hipMemcpyHostToDevice));
+  h->mono_open = true;
+  return M3HIP_OK;
+}
+
+int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
+                          const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
+                          const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
+                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_append before monolith_begin");
+  if (h->E % M3_GROUP != 0) return fail(h, M3HIP_EINVAL, "only the last chunk may hold a non-multiple of 1024 events");
+  if (n_events == 0) return M3HIP_OK;
+  if ((n_splines && (!coeff_many || !nknots_arr || !param_no)) || (n_tf1 && (!coeff_tf1 || !param_no_tf1)))
+    return fail(h, M3HIP_EINVAL, "monolith_append: NULL coefficient arrays");
+  HIPCHK(h, hipSetDevice(h->device));
+  ChunkInput in;
+  in.n_events = n_events;
+  in.coeff_many = coeff_many;
+  in.total_nknots = total_nknots;
+  in.nknots_arr = nknots_arr;
+  in.param_no = param_no;
+  in.n_splines = n_splines;
+  in.coeff_tf1 = coeff_tf1;
+  in.param_no_tf1 = param_no_tf1;
+  in.n_tf1 = n_tf1;
+  in.npe = n_param_per_event;
+  in.npe_tf1 = n_param_per_event_tf1;
+  ChunkPlan plan;
+  std::string err;
+  if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
+
+  // host staging (pinned) -> device
+  float *s_spl = nullptr, *s_tf1 = nullptr;
+  int32_t* s_meta = nullptr;
+  const size_t b_spl = size_t(plan.spl_float4) * 16, b_tf1 = size_t(plan.tf1_float2) * 8, b_meta = size_t(plan.meta_int32) * 4;
+  HIPCHK(h, hipHostMalloc((void**)&s_spl, b_spl ? b_spl : 16, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&s_tf1, b_tf1 ? b_tf1 : 16, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&s_meta, b_meta ? b_meta : 16, hipHostMallocDefault));
+  fill_chunk(h->P, h->h_npts.data(), in, plan, s_spl, s_tf1, s_meta);
+
+  Chunk c;
+  hipError_t e = hipMalloc(&c.d_spl, b_spl ? b_spl : 16);
+  if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 ? b_tf1 : 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&c.d_meta, b_meta ? b_meta : 16);
+  if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
+  if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
+  if (e == hipSuccess && b_meta) e = hipMemcpy(c.d_meta, s_meta, b_meta, hipMemcpyHostToDevice);
+  (void)hipHostFree(s_spl);
+  (void)hipHostFree(s_tf1);
+  (void)hipHostFree(s_meta);
+  if (e != hipSuccess) {
+    dev_free(c.d_spl); dev_free(c.d_tf1); dev_free(c.d_meta);
+    return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("monolith_append upload: ") + hipGetErrorString(e));
+  }
+  h->chunks.push_back(c);
+  for (const TileHost& th : plan.tiles) {
+    TileDev td;
+    td.spl = reinterpret_cast<const float4*>(c.d_spl) + th.spl_off;
+    td.tf1 = reinterpret_cast<const float2*>(c.d_tf1) + th.tf1_off;
+    td.meta = c.d_meta + th.meta_off;
+    td.n_spl_slots = th.n_spl_slots;
+    td.n_tf1_slots = th.n_tf1_slots;
+    td.n_events = th.n_events;
+    td.first_event = 0;
+    h->h_tiles.push_back(td);
+  }
+  h->n_uniform += plan.n_uniform;
+  h->n_brick += plan.n_brick;
+  h->E += n_events;
+  h->S += n_splines;
+  h->T += n_tf1;
+  h->coeff_bytes += b_spl + b_tf1;
+  return M3HIP_OK;
+}
+
+int m3hip_monolith_end(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_end before monolith_begin");
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint64_t n_tiles = h->h_tiles.size();
+  h->E_pad = ((n_tiles * M3_TE + M3_GROUP - 1) / M3_GROUP) * M3_GROUP;
+  if (h->E_pad == 0) h->E_pad = M3_GROUP;
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_tiles, size_t(n_tiles)))) return rc;
+  if (n_tiles) HIPCHK(h, hipMemcpy(h->d_tiles, h->h_tiles.data(), sizeof(TileDev) * n_tiles, hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(h, &h->d_spline_w, size_t(h->E_pad)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_bin, size_t(h->E_pad)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_osc, size_t(h->E_pad)))) return rc;
+  HIPCHK(h, hipMemset(h->d_bin, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: under/overflow
+  HIPCHK(h, hipMemset(h->d_osc, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: no oscillation pointer
+  HIPCHK(h, hipMemset(h->d_spline_w, 0, sizeof(float) * h->E_pad));
+  h->mono_open = false;
+  h->mono_done = true;
+  return M3HIP_OK;
+}
+
+int m3hip_upload_monolith(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* coeff_x,
+                          const int16_t* npts, const float* coeff_many, uint64_t total_nknots,
+                          const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
+                          const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
+                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) {
+  int rc = m3hip_monolith_begin(h, n_params, max_knots, coeff_x, npts);
+  if (rc) return rc;
+  rc = m3hip_monolith_append(h, n_events, coeff_many, total_nknots, nknots_arr, param_no, n_splines, coeff_tf1,
+                             param_no_tf1, n_tf1, n_param_per_event, n_param_per_event_tf1);
+  if (rc) return rc;
+  return m3hip_monolith_end(h);
+}
+
+/* ---------------------------------------------------------------- seam 2 per step */
+
+int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment, float* cpu_total_weights) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_done) return fail(h, M3HIP_ESTATE, "eval_splines before the monolith was uploaded");
+  if (!vals || !segment) return fail(h, M3HIP_EINVAL, "eval_splines: NULL vals / segment");
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int i = 0; i < h->P; ++i) {
+    const int np = h->h_npts[i];
+    if (np > 1 && (segment[i] < 0 || segment[i] > np - 2))
+      return fail(h, M3HIP_EINVAL, "eval_splines: segment out of range for parameter " + std::to_string(i));
+  }
+  // Both staging buffers are reused every call: the previous copies must have drained.
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  memcpy(h->h_vals, vals, sizeof(float) * h->P);
+  memcpy(h->h_segs, segment, sizeof(int16_t) * h->P);
+  HIPCHK(h, hipMemcpyAsync(h->d_vals_in, h->h_vals, sizeof(float) * h->P, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_segs_in, h->h_segs, sizeof(int16_t) * h->P, hipMemcpyHostToDevice, h->stream));
+  PrepArgs p;
+  memset(&p, 0, sizeof(p));
+  p.coeff_x = h->d_coeff_x;
+  p.npts = h->d_npts;
+  p.curr_seg = h->d_currseg;
+  p.n_params = h->P;
+  p.max_knots = h->K;
+  p.ptab = h->d_ptab;
+  p.pval = h->d_pval;
+  p.seg_out = h->d_seg;
+  p.vals_in = h->d_vals_in;
+  p.seg_in = h->d_segs_in;
+  launch_prep(p, h->stream);
+  ReweightArgs a = make_rw_args(h);
+  if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), kModeEval, h->stream);
+  if (h->timing) {
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->pending = 1;
+  }
+  HIPCHK(h, hipGetLastError());
+  if (cpu_total_weights)  // gpuSplineUtils.cu:505 cudaMemcpyAsync(cpu_total_weights, gpu_total_weights, ...)
+    HIPCHK(h, hipMemcpyAsync(cpu_total_weights, h->d_spline_w, sizeof(float) * h->E, hipMemcpyDeviceToHost, h->stream));
+  return M3HIP_OK;
+}
+
+int m3hip_sync(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- seam 3 setup */
+
+int m3hip_set_spline_param_map(m3hip_handle h, const int32_t* global_index, int n_params) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_open && !h->mono_done) return fail(h, M3HIP_ESTATE, "set_spline_param_map before monolith_begin");
+  if (!global_index || n_params != h->P) return fail(h, M3HIP_EINVAL, "set_spline_param_map: n_params mismatch");
+  for (int i = 0; i < n_params; ++i)
+    if (global_index[i] < 0) return fail(h, M3HIP_EINVAL, "set_spline_param_map: negative index");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_parmap, global_index, sizeof(int32_t) * n_params, hipMemcpyHostToDevice));
+  h->parmap_set = true;
+  return M3HIP_OK;
+}
+
+int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_offset) {
+  if (!h) return M3HIP_EINVAL;
+  if (n_samples <= 0 || !sample_bin_offset || sample_bin_offset[0] != 0) return fail(h, M3HIP_EINVAL, "set_binning: bad offsets");
+  for (int s = 0; s < n_samples; ++s)
+    if (sample_bin_offset[s + 1] < sample_bin_offset[s]) return fail(h, M3HIP_EINVAL, "set_binning: offsets must not decrease");
+  const int nb = sample_bin_offset[n_samples];
+  if (nb <= 0) return fail(h, M3HIP_EINVAL, "set_binning: no bins");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist);
+  if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
+  if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2))) return rc;
+  HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
+  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (1 + n_samples), hipHostMallocMapped));
+  HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_out, h->h_out, 0));
+  h->n_bins = nb;
+  h->n_samples = n_samples;
+  h->first_w2 = true;
+  return M3HIP_OK;
+}
+
+int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* bin_idx,
+                        const int32_t* osc_idx, const uint64_t* norm_off, const int16_t* norm_idx) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_done) return fail(h, M3HIP_ESTATE, "upload_events before monolith_end");
+  if (event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "upload_events: range exceeds the monolith's events");
+  if (n == 0) return M3HIP_OK;
+  if (!bin_idx) return fail(h, M3HIP_EINVAL, "upload_events: bin_idx is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->n_bins > 0)
+    for (uint64_t i = 0; i < n; ++i)
+      if (bin_idx[i] < -1 || bin_idx[i] >= h->n_bins) return fail(h, M3HIP_EINVAL, "upload_events: bin index out of range");
+  HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (osc_idx) HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (norm_off) {
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t c = norm_off[i + 1] - norm_off[i];
+      if (c > 4096) return fail(h, M3HIP_EINVAL, "upload_events: implausible norm list length");
+      if (c > mx) mx = uint32_t(c);
+    }
+    if (mx > h->M) {  // grow the ELL planes, keep what is there
+      int16_t* nn = nullptr;
+      int rc = dev_alloc(h, &nn, size_t(mx) * h->E_pad);
+      if (rc) return rc;
+      HIPCHK(h, hipMemset(nn, 0xFF, sizeof(int16_t) * size_t(mx) * h->E_pad));  // -1: empty slot
+      if (h->M) HIPCHK(h, hipMemcpy(nn, h->d_nidx, sizeof(int16_t) * size_t(h->M) * h->E_pad, hipMemcpyDeviceToDevice));
+      dev_free(h->d_nidx);
+      h->d_nidx = nn;
+      h->M = mx;
+    }
+    if (h->M) {
+      std::vector<int16_t> plane(n);
+      for (uint32_t m = 0; m < h->M; ++m) {
+        for (uint64_t i = 0; i < n; ++i) {
+          const uint64_t c = norm_off[i + 1] - norm_off[i];
+          plane[i] = (m < c) ? norm_idx[norm_off[i] + m] : int16_t(-1);
+          if (m < c && plane[i] < 0) return fail(h, M3HIP_EINVAL, "upload_events: negative norm parameter index");
+        }
+        HIPCHK(h, hipMemcpy(h->d_nidx + size_t(m) * h->E_pad + event_offset, plane.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  return M3HIP_OK;
+}
+
+int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
+  if (!h) return M3HIP_EINVAL;
+  if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table: empty table");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (n != h->n_osc) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    dev_free(h->d_osc_table);
+    int rc = dev_alloc(h, &h->d_osc_table, size_t(n));
+    if (rc) return rc;
+    h->n_osc = n;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_osc_table, table, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return M3HIP_OK;
+}
+
+int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "set_data before set_binning");
+  if (!data || n_bins != h->n_bins) return fail(h, M3HIP_EINVAL, "set_data: n_bins mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_data, data, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+  return M3HIP_OK;
+}
+
+int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2) {
+  if (!h) return M3HIP_EINVAL;
+  if (kind < 0 || kind > 4) return fail(h, M3HIP_EINVAL, "set_test_statistic: unknown kind");
+  h->teststat = kind;
+  h->update_w2 = update_w2 != 0;
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- seam 3 per step */
+
+int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_done) return fail(h, M3HIP_ESTATE, "reweight before the monolith was uploaded");
+  if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "reweight before set_binning");
+  if (!params || n_par <= 0) return fail(h, M3HIP_EINVAL, "reweight: empty parameter vector");
+  if (!h->parmap_set && n_par < h->P) return fail(h, M3HIP_EINVAL, "reweight: parameter vector shorter than the spline parameters");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_param_capacity(h, n_par);
+  if (rc) return rc;
+  collect_timing(h);
+  // stage the proposed values; the slot is free once the k_prep that read it has run
+  const int slot = h->ring_pos;
+  h->ring_pos = (h->ring_pos + 1) % kRing;
+  if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
+  memcpy(h->h_params[slot], params, sizeof(double) * n_par);
+
+  PrepArgs p;
+  memset(&p, 0, sizeof(p));
+  p.params_src = h->d_params_src[slot];
+  p.params_dev = h->d_params;
+  p.n_par = n_par;
+  p.par_map = h->d_parmap;
+  p.coeff_x = h->d_coeff_x;
+  p.npts = h->d_npts;
+  p.curr_seg = h->d_currseg;
+  p.n_params = h->P;
+  p.max_knots = h->K;
+  p.ptab = h->d_ptab;
+  p.pval = h->d_pval;
+  p.seg_out = h->d_seg;
+  p.hist = h->d_hist;
+  p.n_bins = h->n_bins;
+  p.reset_hist = 1;
+  p.reset_w2 = h->first_w2 ? 1 : 0;
+  launch_prep(p, h->stream);
+  HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
+  h->ring_used[slot] = true;
+
+  ReweightArgs a = make_rw_args(h);
+  int mode = kModeFill;
+  if (h->want_event_w) {
+    if (!h->d_event_w) {
+      if ((rc = dev_alloc(h, &h->d_event_w, size_t(h->E_pad)))) return rc;
+      a.event_w = h->d_event_w;
+    }
+    mode |= kModeEventW | kModeEval;
+  }
+  if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->stream);
+  if (h->timing) {
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    h->pending = 0;
+  }
+  HIPCHK(h, hipGetLastError());
+  if (h->comm && h->n_ranks > 1) {
+    const size_t count = size_t(h->n_bins) * (h->first_w2 ? 2 : 1);
+    int r = g_rccl.AllReduce(h->d_hist, h->d_hist, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+  }
+  if (!h->update_w2) h->first_w2 = false;  // SampleHandlerFD.cpp:342
+  return M3HIP_OK;
+}
+
+int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "get_likelihood before set_binning");
+  HIPCHK(h, hipSetDevice(h->device));
+  LlhArgs l;
+  l.data = h->d_data;
+  l.hist = h->d_hist;
+  l.n_bins = h->n_bins;
+  l.n_samples = h->n_samples;
+  l.sample_off = h->d_sample_off;
+  l.kind = h->teststat;
+  l.out = h->d_out;
+  launch_llh(l, h->stream);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  if (llh_total) *llh_total = h->h_out[0];
+  if (per_sample)
+    for (int s = 0; s < h->n_samples; ++s) per_sample[s] = h->h_out[1 + s];
+  return M3HIP_OK;
+}
+
+int m3hip_step(m3hip_handle h, const double* params, int n_par, double* llh_total, double* per_sample) {
+  int rc = m3hip_reweight(h, params, n_par);
+  if (rc) return rc;
+  return m3hip_get_likelihood(h, llh_total, per_sample);
+}
+
+int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->n_bins == 0 || n_bins != h->n_bins) return fail(h, M3HIP_EINVAL, "get_bins: n_bins mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  if (mc) HIPCHK(h, hipMemcpy(mc, h->d_hist, sizeof(double) * n_bins, hipMemcpyDeviceToHost));
+  if (w2) HIPCHK(h, hipMemcpy(w2, h->d_hist + n_bins, sizeof(double) * n_bins, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
+int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_spline_weights: bad range");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  HIPCHK(h, hipMemcpy(out, h->d_spline_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
+int m3hip_record_event_weights(m3hip_handle h, int enable) {
+  if (!h) return M3HIP_EINVAL;
+  h->want_event_w = enable != 0;
+  return M3HIP_OK;
+}
+
+int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_weights: bad range");
+  if (!h->d_event_w) return fail(h, M3HIP_ESTATE, "get_event_weights: call m3hip_record_event_weights(h, 1) before the reweight");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  HIPCHK(h, hipMemcpy(out, h->d_event_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
+int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_params) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_done || n_params != h->P) return fail(h, M3HIP_EINVAL, "get_segments: n_params mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (segments) HIPCHK(h, hipMemcpy(segments, h->d_seg, sizeof(int16_t) * n_params, hipMemcpyDeviceToHost));
+  if (vals) HIPCHK(h, hipMemcpy(vals, h->d_pval, sizeof(float) * n_params, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- multi-GPU */
+
+int m3hip_comm_get_unique_id(void* out_id) {
+  if (!out_id) return M3HIP_EINVAL;
+  std::string err;
+  if (!g_rccl.load(&err)) return fail(nullptr, M3HIP_ECOMM, err);
+  int r = g_rccl.GetUniqueId(out_id);
+  if (r != 0) return fail(nullptr, M3HIP_ECOMM, "ncclGetUniqueId failed");
+  return M3HIP_OK;
+}
+
+int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks) {
+  if (!h || !unique_id) return M3HIP_EINVAL;
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, M3HIP_EINVAL, "comm_init: bad rank / n_ranks");
+  std::string err;
+  if (!g_rccl.load(&err)) return fail(h, M3HIP_ECOMM, err);
+  HIPCHK(h, hipSetDevice(h->device));
+  m3hip_comm_destroy(h);
+  m3hip_unique_id_t id;
+  memcpy(id.internal, unique_id, M3HIP_UNIQUE_ID_BYTES);
+  void* comm = nullptr;
+  int r = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
+  if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+  h->comm = comm;
+  h->rank = rank;
+  h->n_ranks = n_ranks;
+  return M3HIP_OK;
+}
+
+int m3hip_comm_destroy(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->comm) {
+    (void)hipStreamSynchronize(h->stream);
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  h->rank = 0;
+  h->n_ranks = 1;
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- host-only layout probe */
+
+int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_t n_events, const float* coeff_many,
+                       uint64_t total_nknots, const unsigned int* nknots_arr, const int16_t* param_no,
+                       uint64_t n_splines, const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
+                       const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1,
+                       uint64_t* sizes, float* spl, float* tf1, int32_t* meta, uint64_t* tile_desc) {
+  if (!npts || !sizes) return fail(nullptr, M3HIP_EINVAL, "debug_layout: NULL arguments");
+  ChunkInput in;
+  in.n_events = n_events;
+  in.coeff_many = coeff_many;
+  in.total_nknots = total_nknots;
+  in.nknots_arr = nknots_arr;
+  in.param_no = param_no;
+  in.n_splines = n_splines;
+  in.coeff_tf1 = coeff_tf1;
+  in.param_no_tf1 = param_no_tf1;
+  in.n_tf1 = n_tf1;
+  in.npe = n_param_per_event;
+  in.npe_tf1 = n_param_per_event_tf1;
+  ChunkPlan plan;
+  std::string err;
+  if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err)) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
+  sizes[0] = plan.tiles.size();
+  sizes[1] = plan.spl_float4;
+  sizes[2] = plan.tf1_float2;
+  sizes[3] = plan.meta_int32;
+  if (!spl || !tf1 || !meta || !tile_desc) return M3HIP_OK;  // plan only
+  fill_chunk(n_params, npts, in, plan, spl, tf1, meta);
+  for (size_t t = 0; t < plan.tiles.size(); ++t) {
+    const TileHost& th = plan.tiles[t];
+    uint64_t* d = tile_desc + 8 * t;
+    d[0] = th.spl_off; d[1] = th.tf1_off; d[2] = th.meta_off; d[3] = th.n_spl_slots;
+    d[4] = th.n_tf1_slots; d[5] = th.n_events; d[6] = th.kind; d[7] = th.n_planes;
+  }
+  return M3HIP_OK;
+}
+
+/* ---------------------------------------------------------------- introspection */
+
+int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
+  if (!h || !out) return M3HIP_EINVAL;
+  memset(out, 0, sizeof(*out));
+  out->n_events = h->E;
+  out->n_splines = h->S;
+  out->n_tf1 = h->T;
+  out->n_tiles_uniform = h->n_uniform;
+  out->n_tiles_brick = h->n_brick;
+  out->coeff_bytes = h->coeff_bytes;
+  out->alg_bytes_eval = 16 * h->S + 8 * h->T + 4 * h->E;
+  out->alg_bytes_fused = 16 * h->S + 8 * h->T + 8 * h->E;
+  out->n_params = h->P;
+  out->max_knots = h->K;
+  out->n_bins = h->n_bins;
+  out->n_samples = h->n_samples;
+  return M3HIP_OK;
+}
+
+int m3hip_timing_enable(m3hip_handle h, int enable) {
+  if (!h) return M3HIP_EINVAL;
+  h->timing = enable != 0;
+  return M3HIP_OK;
+}
+
+int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches) {
+  if (!h || which < 0 || which > 1) return M3HIP_EINVAL;
+  if (avg_ms) *avg_ms = h->cnt[which] ? h->acc_ms[which] / double(h->cnt[which]) : 0.0;
+  if (n_launches) *n_launches = h->cnt[which];
+  return M3HIP_OK;
+}
+
+int m3hip_timing_reset(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  h->acc_ms[0] = h->acc_ms[1] = 0;
+  h->cnt[0] = h->cnt[1] = 0;
+  return M3HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// m3hip_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the per-step likelihood path.
+//
+//   k_prep              a1  SplineBase::FindSplineSegment (Splines/SplineBase.cpp:44-109)
+//                       a6  SampleHandlerFD::ResetHistograms (Samples/SampleHandlerFD.cpp:454-463)
+//   k_reweight_uniform  a2  SMonolith::CalcSplineWeights   (Splines/SplineMonolith.cpp:727-788)
+//                       a3  SMonolith::CalcTotalEventWeight (:792-830)
+//                       a7  SampleHandlerFD::CalcWeightTotal (Samples/SampleHandlerFD.cpp:568-594)
+//                       a8  SampleHandlerFD::FillArray      (:352-383)
+//   k_llh               a10-a12 GetLikelihood / GetTestStatLLH (Samples/SampleHandlerFD.cpp:1284-1300,
+//                       Samples/SampleHandlerBase.cpp:17-192)
+//
+// Floating point: compiled with -ffp-contract=off; the only fused operations are the
+// explicit fmaf() calls the reference itself makes, so per-event float weights are
+// bit-identical to a serial CPU evaluation in the reference's operation order.
+#include "m3hip_kernels.h"
+
+namespace m3hip {
+
+// ------------------------------------------------------------------------------------
+// k_prep: one workgroup.  Parameter-only work of a step.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+  const int tid = threadIdx.x;
+  // ResetHistograms: mc always, w2 only while FirstTimeW2 (SampleHandlerFD.cpp:454-463)
+  if (a.reset_hist) {
+    for (int b = tid; b < a.n_bins; b += 256) {
+      a.hist[b] = 0.0;
+      if (a.reset_w2) a.hist[a.n_bins + b] = 0.0;
+    }
+  }
+  if (a.params_src) {
+    for (int i = tid; i < a.n_par; i += 256) a.params_dev[i] = a.params_src[i];
+    if (tid == 0) a.params_dev[a.n_par] = 1.0;
+    __syncthreads();  // from here on read the device copy, not host memory over PCIe
+  }
+  const int K = a.max_knots;
+  for (int i = tid; i < a.n_params; i += 256) {
+    float xvar;
+    int segment = 0;
+    const int nPoints = a.npts[i];
+    const float* xArray = a.coeff_x + (size_t)i * K;
+    if (a.vals_in) {
+      // host already ran FindSplineSegment (RunGPU_SplineMonolith inputs, gpuSplineUtils.cu:444-465)
+      xvar = a.vals_in[i];
+      segment = a.seg_in[i];
+    } else {
+      xvar = float(a.params_dev[a.par_map[i]]);  // SplineBase.cpp:54 (double -> float)
+      if (nPoints > 0) {                         // :60 parameters without knots are skipped
+        int kHigh = nPoints - 1;
+        const int PreviousSegment = a.curr_seg[i];
+        if (xvar <= xArray[0]) {
+          segment = 0;
+        } else if (xvar >= xArray[nPoints - 1]) {
+          segment = kHigh;
+        } else if (xArray[PreviousSegment + 1] > xvar && xvar >= xArray[PreviousSegment]) {  // :76
+          segment = PreviousSegment;
+        } else {
+          while (kHigh - segment > 1) {  // :84-94
+            const int kHalf = (segment + kHigh) / 2;
+            if (xvar > xArray[kHalf]) segment = kHalf;
+            else kHigh = kHalf;
+          }
+        }
+        if (segment >= nPoints - 1 && nPoints > 1) segment = nPoints - 2;  // :97
+        a.curr_seg[i] = (int16_t)segment;
+      } else {
+        segment = a.curr_seg[i];  // untouched, as in the reference (SplineSegments keeps its value)
+      }
+    }
+    a.pval[i] = xvar;
+    a.seg_out[i] = (int16_t)segment;
+    PTab t;
+    t.seg = segment;
+    // SplineMonolith.cpp:747,759: dx = ParamValues[Param] - coeff_x[Param*_max_knots + segment]
+    t.dx = (nPoints > 0) ? (xvar - xArray[segment]) : 0.f;
+    a.ptab[i] = t;
+  }
+}
+
+void launch_prep(const PrepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, a); }
+
+// ------------------------------------------------------------------------------------
+// k_reweight_uniform: one workgroup (256 lanes = 256 events) per uniform tile.
+//
+// HBM traffic per event: one float4 per spline slot (the active segment's plane), one
+// float2 per TF1 slot, + 8 B of bin/osc indices and 2 B per norm slot when fused.
+// Every vector load is lane-contiguous (64 x 16 B = 1 KiB per wave instruction); all
+// parameter-dependent state (segment, dx, value) is wave-uniform and travels in SGPRs.
+// ------------------------------------------------------------------------------------
+constexpr int kUnroll = 8;
+
+__device__ __forceinline__ float spline_poly(float dx, const float4 c) {
+  // SplineMonolith.cpp:762  fmaf(dx, fmaf(dx, fmaf(dx, fD, fC), fB), fY); c = {y,b,c,d}
+  return fmaf(dx, fmaf(dx, fmaf(dx, c.w, c.z), c.y), c.x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
+  extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 (kModeFill only)
+  const uint32_t tile = a.tile_base + blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const TileDev td = a.tiles[tile];
+
+  if (MODE & kModeFill) {
+    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+    for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
+  }
+
+  // ---- kernel (i): TSpline3 responses, then TF1 responses, product in the reference's order
+  float w = 1.0f;  // SplineMonolith.cpp:798
+  {
+    const float4* __restrict__ sp = td.spl + lane;
+    const int2* __restrict__ meta = reinterpret_cast<const int2*>(td.meta);
+    const uint32_t J = td.n_spl_slots;
+    uint32_t j = 0;
+    for (; j + kUnroll <= J; j += kUnroll) {
+      float4 c[kUnroll];
+      float dx[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int2 m = meta[j + u];
+        const PTab pt = a.ptab[m.x];
+        c[u] = sp[(size_t)(uint32_t)(m.y + pt.seg) * M3_TE];
+        dx[u] = pt.dx;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) w *= spline_poly(dx[u], c[u]);
+    }
+    for (; j < J; ++j) {
+      const int2 m = meta[j];
+      const PTab pt = a.ptab[m.x];
+      w *= spline_poly(pt.dx, sp[(size_t)(uint32_t)(m.y + pt.seg) * M3_TE]);
+    }
+  }
+  {
+    const float2* __restrict__ tp = td.tf1 + lane;
+    const int32_t* __restrict__ tmeta = td.meta + 2 * td.n_spl_slots;
+    const uint32_t J = td.n_tf1_slots;
+    uint32_t j = 0;
+    for (; j + kUnroll <= J; j += kUnroll) {
+      float2 c[kUnroll];
+      float x[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        x[u] = a.pval[tmeta[j + u]];
+        c[u] = tp[(size_t)(j + u) * M3_TE];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) w *= fmaf(c[u].x, x[u], c[u].y);  // SplineMonolith.cpp:779
+    }
+    for (; j < J; ++j) {
+      const float x = a.pval[tmeta[j]];
+      const float2 c = tp[(size_t)j * M3_TE];
+      w *= fmaf(c.x, x, c.y);
+    }
+  }
+
+  const uint64_t ev = (uint64_t)tile * M3_TE + lane;
+  if (MODE & kModeEval) a.spline_w[ev] = w;  // cpu_total_weights[EventNum] (SplineMonolith.cpp:828)
+
+  if (MODE & (kModeFill | kModeEventW)) {
+    // ---- kernel (ii): CalcWeightTotal (SampleHandlerFD.cpp:568-594): norm pointers first
+    // (double -> float cast each), then total_weight_pointers = {osc, spline total weight}.
+    float tw = 1.0f;
+    for (uint32_t m = 0; m < a.n_norm_slots; ++m) {
+      const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
+      if (idx >= 0) tw *= static_cast<float>(a.params[idx]);  // -1: empty ELL slot
+    }
+    const int oi = a.osc[ev];
+    if (oi >= 0) tw *= a.osc_table[oi];
+    tw *= w;
+    if (MODE & kModeEventW) a.event_w[ev] = tw;
+    if (MODE & kModeFill) {
+      __syncthreads();
+      const int b = a.bin[ev];
+      // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`
+      if (lane < td.n_events && tw > 0.f && b >= 0) {
+        atomicAdd(&lds_hist[b], (double)tw);
+        if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // float square, then widened (:445)
+      }
+      __syncthreads();
+      const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+      for (int i = lane; i < nb; i += 256) {
+        const double v = lds_hist[i];
+        if (v != 0.0) atomicAdd(&a.hist[i], v);
+      }
+    }
+  }
+}
+
+void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s) {
+  if (n_tiles == 0) return;
+  const size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  const dim3 g(n_tiles), b(256);
+  switch (mode) {
+    case kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeEval>, g, b, 0, s, a); break;
+    case kModeFill: hipLaunchKernelGGL(k_reweight_uniform<kModeFill>, g, b, lds, s, a); break;
+    case kModeFill | kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEval>, g, b, lds, s, a); break;
+    case kModeFill | kModeEventW: hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEventW>, g, b, lds, s, a); break;
+    case kModeFill | kModeEval | kModeEventW:
+      hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEval | kModeEventW>, g, b, lds, s, a);
+      break;
+    case kModeEventW | kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeEventW | kModeEval>, g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_reweight_uniform<kModeEventW>, g, b, 0, s, a); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// k_llh: kernel (iii).  One workgroup; per-bin test statistic in fp64, wavefront shuffle
+// reduction followed by an LDS tree across the four waves.  Fixed summation tree, so the
+// result is run-to-run reproducible for a given bin vector.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_poisson_llh(double data, double mc) {
+  // Samples/SampleHandlerBase.cpp:17-31
+  if (data == 0) return mc;
+  if (mc < M3HIP_LOW_MC_BOUND_D) {
+    if (data > M3HIP_LOW_MC_BOUND_D) return (M3HIP_LOW_MC_BOUND_D - data + data * log(data / M3HIP_LOW_MC_BOUND_D));
+    else if (data >= mc) return 0.;
+  }
+  return (mc - data + data * log(data / mc));
+}
+
+__device__ double d_test_stat_llh(int kind, double data, double mc, double w2) {
+  const double low = M3HIP_LOW_MC_BOUND_D;
+  switch (kind) {
+    case 1: {  // kBarlowBeeston, SampleHandlerBase.cpp:46-87
+      double newmc = mc;
+      if (mc < low) {
+        if (data > low) newmc = low;
+        else if (data >= mc) return 0.;
+      }
+      const double fractional = sqrt(w2) / newmc;
+      const double fractional2 = fractional * fractional;
+      const double temp = newmc * fractional2 - 1;
+      const double temp2 = temp * temp + 4 * data * fractional2;
+      if (temp2 < 0) return __builtin_nan("");  // the reference throws here
+      const double beta = (-1 * temp + sqrt(temp2)) / 2.;
+      double stat = mc * beta;
+      if (data > 0) {
+        newmc *= beta;
+        stat = newmc - data + data * log(data / newmc);
+      }
+      double penalty = 0;
+      if (fractional > 0) penalty = (beta - 1) * (beta - 1) / (2 * fractional2);
+      return stat + penalty;
+    }
+    case 4: {  // kDembinskiAbdelmotteleb, :90-125
+      if (w2 == 0) return d_poisson_llh(data, mc);
+      double newmc = mc;
+      if (mc < low) {
+        if (data > low) newmc = low;
+        else if (data >= mc) return 0.;
+      }
+      const double k = newmc * newmc / w2;
+      const double beta = (data + k) / (newmc + k);
+      newmc *= beta;
+      const double penalty = k * beta - k + k * log(k / (k * beta));
+      double stat = newmc;
+      if (data > 0) stat = newmc - data + data * log(data / newmc);
+      return stat + penalty;
+    }
+    case 2: {  // kIceCube, :133-159.  The reference evaluates this in x87 long double with
+               // lgammal; the device has no 80-bit type, so this is fp64 (tolerance in tests).
+      if (w2 == 0) return d_poisson_llh(data, mc);
+      const double b = mc / w2;
+      const double a = mc * b + 1;
+      const double stat = -1 * (a * log(b) + lgamma(data + a) - lgamma(data + 1) - ((data + a) * log1p(b)) - lgamma(a));
+      if (mc <= data) {
+        if (data <= low) return 0.;
+        const double poisson = d_poisson_llh(data, low);
+        if (stat > poisson) return poisson;
+      }
+      return stat;
+    }
+    case 3: {  // kPearson, :162-176
+      if (data == 0) return mc / 2.;
+      if (mc < low) {
+        if (data > low) return (data - low) * (data - low) / (2. * low);
+        else if (data >= mc) return 0.;
+      }
+      return (data - mc) * (data - mc) / (2 * mc);
+    }
+    case 0:  // kPoisson, :178-183
+      return d_poisson_llh(data, mc);
+    default:
+      return __builtin_nan("");
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ double block_sum_256(double v, double* scratch /*[4]*/) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+__global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
+  __shared__ double scratch[4];
+  const double* mc = a.hist;
+  const double* w2 = a.hist + a.n_bins;
+  // GetLikelihood(): all global bins (SampleHandlerFD.cpp:1284-1300)
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < a.n_bins; i += 256) acc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
+  const double total = block_sum_256(acc, scratch);
+  if (threadIdx.x == 0) a.out[0] = total;
+  // GetSampleLikelihood(s): bins [start, end) of each sample (:1262-1281)
+  for (int s = 0; s < a.n_samples; ++s) {
+    const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
+    double sacc = 0.0;
+    for (int i = b0 + threadIdx.x; i < b1; i += 256) sacc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
+    const double st = block_sum_256(sacc, scratch);
+    if (threadIdx.x == 0) a.out[1 + s] = st;
+  }
+}
+
+void launch_llh(const LlhArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_llh, dim3(1), dim3(256), 0, s, a); }
+
+}  // namespace m3hip

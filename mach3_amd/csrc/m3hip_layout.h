@@ -1,0 +1,75 @@
+// m3hip_layout.h -- host-side re-layout of a reference-format monolith chunk into the
+// engine's tile store.  Pure C++ (no HIP): the engine calls it from m3hip_monolith_append,
+// and tests inspect its output directly through the m3hip_layout_* debug exports.
+//
+// Reference layout in (Splines/SplineMonolith.cpp:53-250): event-major CSR, one
+// 16*nKnots-byte AoS record {y,b,c,d}[knot] per spline, of which a step reads ONE quad.
+//
+// Engine layout out ("segment-major tiles"):
+//   events are cut into tiles of M3_TE = 256 consecutive events.
+//   UNIFORM tile  (every event of the tile has the same ordered parameter list):
+//       slot j of the tile <-> parameter plist[j]; the tile stores, per slot and per
+//       spline SEGMENT k (npts-1 of them), one plane of M3_TE float4 {y,b,c,d}:
+//           spl[(plane0[j] + k) * M3_TE + lane]
+//       so the quads a step needs for (slot j, segment seg[p]) are 4 KB contiguous and a
+//       wavefront's 64 loads are one 1 KB line-aligned burst.  TF1: tf1[j * M3_TE + lane]
+//       float2 {a,b}.  Lane = event inside the tile; the per-event product runs over j in
+//       the reference's order (splines in event order, then TF1s).
+//   BRICK tile (ragged parameter lists): see m3hip_layout.cpp.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace m3hip {
+
+constexpr int M3_TE = 256;       // events per tile (= workgroup size of the reweight kernels)
+constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
+
+enum TileKind : uint32_t { kTileUniform = 0, kTileBrick = 1 };
+
+// Host-side tile descriptor: offsets into the chunk's stores.
+struct TileHost {
+  uint64_t spl_off = 0;   // float4 index of the tile's first plane
+  uint64_t tf1_off = 0;   // float2 index
+  uint64_t meta_off = 0;  // int32 index: [2*n_spl_slots] {param, plane0}, then [n_tf1_slots] {param}
+  uint32_t n_spl_slots = 0;
+  uint32_t n_tf1_slots = 0;
+  uint32_t n_events = 0;  // valid lanes (<= M3_TE)
+  uint32_t kind = kTileUniform;
+  uint64_t n_planes = 0;  // spline planes in the tile (sum of segments over slots)
+};
+
+struct ChunkInput {
+  uint64_t n_events = 0;
+  const float* coeff_many = nullptr;
+  uint64_t total_nknots = 0;
+  const unsigned int* nknots_arr = nullptr;
+  const int16_t* param_no = nullptr;
+  uint64_t n_splines = 0;
+  const float* coeff_tf1 = nullptr;
+  const int16_t* param_no_tf1 = nullptr;
+  uint64_t n_tf1 = 0;
+  const unsigned int* npe = nullptr;
+  const unsigned int* npe_tf1 = nullptr;
+};
+
+struct ChunkPlan {
+  std::vector<TileHost> tiles;
+  uint64_t spl_float4 = 0;  // size of the spline store, float4 units
+  uint64_t tf1_float2 = 0;  // size of the TF1 store, float2 units
+  uint64_t meta_int32 = 0;  // size of the slot-meta store
+  uint64_t n_uniform = 0, n_brick = 0;
+};
+
+// Validates the chunk against (n_params, npts) and sizes the tile store.
+// Returns false and sets err on inconsistent input.
+bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
+                std::string* err);
+
+// Fills caller-provided stores (sizes from the plan).  Multi-threaded.
+void fill_chunk(int n_params, const int16_t* npts, const ChunkInput& in, const ChunkPlan& plan, float* spl /*float4*/,
+                float* tf1 /*float2*/, int32_t* meta);
+
+}  // namespace m3hip

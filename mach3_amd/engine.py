@@ -1,0 +1,304 @@
+"""Python mirror of the reference's operator interface for the per-step path, on top of the
+C ABI (include/m3hip.h).  Same names and argument meaning as the reference:
+
+  SMonolith          Splines/SplineMonolith.h:11-149   Evaluate / SynchroniseMemTransfer /
+                                                       setSplinePointers / cpu_total_weights
+  SampleHandlerFD    Samples/SampleHandlerFD.h:21-413  Reweight / GetLikelihood /
+                                                       GetSampleLikelihood / GetMCArray / ...
+
+This is the test and benchmark harness; the production host side is the C++ facade in
+include/mach3_amd/.  Nothing here computes on the CPU: if libm3hip.so or a HIP device is
+missing, construction raises M3HipError."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import M3HipError, _ptr
+
+
+class Engine:
+    """Owns one m3hip handle (one device, one stream)."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = capi.load_m3hip()
+        h = C.c_void_p()
+        rc = self.lib.m3hip_create(device_id, C.byref(h))
+        if rc != 0:
+            raise M3HipError(rc, self.lib.m3hip_last_error(None).decode())
+        self.h = h
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise M3HipError(rc, self.lib.m3hip_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.m3hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- monolith upload (CopyToGPU_SplineMonolith) ----
+    def monolith_begin(self, n_params, max_knots, coeff_x, npts):
+        self._chk(self.lib.m3hip_monolith_begin(self.h, n_params, max_knots, _ptr(coeff_x, np.float32), _ptr(npts, np.int16)))
+
+    def monolith_append(self, ch: dict):
+        self._chk(self.lib.m3hip_monolith_append(
+            self.h, ch["n_events"], _ptr(ch["coeff_many"], np.float32), ch["total_nknots"],
+            _ptr(ch["nknots_arr"], np.uint32), _ptr(ch["param_no"], np.int16), ch["n_splines"],
+            _ptr(ch["coeff_tf1"], np.float32), _ptr(ch["param_no_tf1"], np.int16), ch["n_tf1"],
+            _ptr(ch["npe"], np.uint32), _ptr(ch["npe_tf1"], np.uint32)))
+
+    def monolith_end(self):
+        self._chk(self.lib.m3hip_monolith_end(self.h))
+
+    def info(self) -> capi.Info:
+        out = capi.Info()
+        self._chk(self.lib.m3hip_get_info(self.h, C.byref(out)))
+        return out
+
+    def mem_info(self):
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.lib.m3hip_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def sync(self):
+        self._chk(self.lib.m3hip_sync(self.h))
+
+    # ---- timing of the dominant kernel (hipEvents on the engine's stream) ----
+    def timing_enable(self, on=True):
+        self._chk(self.lib.m3hip_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._chk(self.lib.m3hip_timing_reset(self.h))
+
+    def timing_read(self, which=0):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._chk(self.lib.m3hip_timing_read(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- multi-GPU ----
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+        rc = self.lib.m3hip_comm_get_unique_id(buf)
+        if rc != 0:
+            raise M3HipError(rc, self.lib.m3hip_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        assert len(unique_id) == capi.UNIQUE_ID_BYTES
+        self._chk(self.lib.m3hip_comm_init(self.h, C.c_char_p(unique_id), rank, n_ranks))
+
+
+class SMonolith:
+    """Event-by-event spline monolith evaluated on the GPU.
+
+    Mirrors SMonolith (ref: Splines/SplineMonolith.h:11-149): `setSplinePointers`,
+    `Evaluate`, `SynchroniseMemTransfer`, `cpu_total_weights`, `GetNParams`.  The
+    constructor takes the flattened arrays PrepareForGPU would have produced (one dict per
+    event chunk, see synth.monolith_chunk) instead of a MasterSpline of ROOT objects."""
+
+    def __init__(self, engine: Engine, n_params, max_knots, coeff_x, npts, chunks):
+        self.eng = engine
+        self.nParams = int(n_params)
+        self._max_knots = int(max_knots)
+        self.coeff_x = np.ascontiguousarray(coeff_x, np.float32)
+        self.npts = np.ascontiguousarray(npts, np.int16)
+        engine.monolith_begin(n_params, max_knots, self.coeff_x, self.npts)
+        for ch in chunks:
+            engine.monolith_append(ch)
+        engine.monolith_end()
+        self.NEvents = int(engine.info().n_events)
+        # FastSplineInfo state (ref: Splines/SplineStructs.h:21-44)
+        self.CurrSegment = np.zeros(n_params, np.int16)
+        self.SplineSegments = np.zeros(n_params, np.int16)          # SplineMonolith.cpp:91
+        self.ParamValues = np.full(n_params, -999.0, np.float32)    # SplineMonolith.cpp:92
+        self.cpu_total_weights = np.zeros(self.NEvents, np.float32)
+        self._par = None
+        self._idx = np.arange(n_params)
+
+    def GetName(self):
+        return "SplineMonolith"
+
+    def GetNParams(self):
+        return self.nParams
+
+    def setSplinePointers(self, par_vector: np.ndarray, index=None):
+        """`par_vector` plays ParameterHandlerBase::_fPropVal; `index[i]` says which entry
+        drives spline parameter i.  Values are read at Evaluate() time, as through the
+        reference's stored `const double*`."""
+        self._par = par_vector
+        self._idx = np.arange(self.nParams) if index is None else np.asarray(index, np.int64)
+        gi = np.ascontiguousarray(self._idx, np.int32)
+        self.eng._chk(self.eng.lib.m3hip_set_spline_param_map(self.eng.h, _ptr(gi, np.int32), self.nParams))
+
+    def FindSplineSegment(self):
+        """Host half of Evaluate(): SplineBase::FindSplineSegment (ref: Splines/SplineBase.cpp:44-109).
+        O(P) work; stays on the host exactly as in the reference's GPU build."""
+        x = self.coeff_x.reshape(self.nParams, self._max_knots)
+        for i in range(self.nParams):
+            n = int(self.npts[i])
+            xvar = np.float32(self._par[self._idx[i]])
+            self.ParamValues[i] = xvar
+            if n <= 0:
+                continue
+            xa = x[i]
+            prev = int(self.CurrSegment[i])
+            seg, khigh = 0, n - 1
+            if xvar <= xa[0]:
+                seg = 0
+            elif xvar >= xa[n - 1]:
+                seg = khigh
+            elif xa[prev + 1] > xvar and xvar >= xa[prev]:
+                seg = prev
+            else:
+                while khigh - seg > 1:
+                    khalf = (seg + khigh) // 2
+                    if xvar > xa[khalf]:
+                        seg = khalf
+                    else:
+                        khigh = khalf
+            if seg >= n - 1 and n > 1:
+                seg = n - 2
+            self.CurrSegment[i] = seg
+            self.SplineSegments[i] = seg
+
+    def Evaluate(self):
+        """ref: Splines/SplineMonolith.cpp:695-708 (GPU branch): segments on the host, then
+        RunGPU_SplineMonolith (asynchronous)."""
+        self.FindSplineSegment()
+        self.eng._chk(self.eng.lib.m3hip_eval_splines(self.eng.h, _ptr(self.ParamValues, np.float32),
+                                                      _ptr(self.SplineSegments, np.int16),
+                                                      _ptr(self.cpu_total_weights, np.float32)))
+
+    def SynchroniseMemTransfer(self):
+        self.eng.sync()
+
+    def retPointer(self, event: int):
+        return self.cpu_total_weights[event:event + 1]
+
+
+class SampleHandlerFD:
+    """The fused sample operator: SampleHandlerBase::Reweight / GetLikelihood on the GPU
+    (ref: Samples/SampleHandlerFD.cpp:316-463, 1262-1300).  Built from flat per-event
+    arrays instead of YAML + ROOT files."""
+
+    def __init__(self, engine: Engine, n_samples: int, sample_bin_offset, par_vector: np.ndarray,
+                 test_statistic=capi.kPoisson, update_w2=False):
+        self.eng = engine
+        self.nSamples = int(n_samples)
+        off = np.ascontiguousarray(sample_bin_offset, np.int32)
+        self.sample_bin_offset = off
+        self.nBins = int(off[-1])
+        engine._chk(engine.lib.m3hip_set_binning(engine.h, n_samples, _ptr(off, np.int32)))
+        self.par = par_vector  # plays _fPropVal; read at Reweight() time
+        self.SetTestStatistic(test_statistic, update_w2)
+
+    def GetName(self):
+        return "SampleHandlerFD"
+
+    def GetNsamples(self):
+        return self.nSamples
+
+    def SetTestStatistic(self, kind, update_w2=False):
+        self.eng._chk(self.eng.lib.m3hip_set_test_statistic(self.eng.h, int(kind), int(update_w2)))
+
+    def SetupEvents(self, event_offset, bin_idx, osc_idx, norm_off, norm_idx):
+        n = len(bin_idx)
+        self.eng._chk(self.eng.lib.m3hip_upload_events(
+            self.eng.h, event_offset, n, _ptr(np.ascontiguousarray(bin_idx, np.int32), np.int32),
+            _ptr(np.ascontiguousarray(osc_idx, np.int32), np.int32) if osc_idx is not None else None,
+            _ptr(np.ascontiguousarray(norm_off, np.uint64), np.uint64) if norm_off is not None else None,
+            _ptr(np.ascontiguousarray(norm_idx, np.int16), np.int16) if norm_off is not None else None))
+
+    def SetOscillationWeights(self, table):
+        t = np.ascontiguousarray(table, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_set_osc_table(self.eng.h, _ptr(t, np.float32), len(t)))
+
+    def AddData(self, data):
+        d = np.ascontiguousarray(data, np.float64)
+        self.eng._chk(self.eng.lib.m3hip_set_data(self.eng.h, _ptr(d, np.float64), len(d)))
+
+    def Reweight(self):
+        p = np.ascontiguousarray(self.par, np.float64)
+        self.eng._chk(self.eng.lib.m3hip_reweight(self.eng.h, _ptr(p, np.float64), len(p)))
+
+    def GetLikelihood(self) -> float:
+        tot = C.c_double(0)
+        self._per_sample = np.zeros(self.nSamples, np.float64)
+        self.eng._chk(self.eng.lib.m3hip_get_likelihood(self.eng.h, C.byref(tot), _ptr(self._per_sample, np.float64)))
+        return tot.value
+
+    def GetSampleLikelihood(self, isample: int) -> float:
+        self.GetLikelihood()
+        return float(self._per_sample[isample])
+
+    def Step(self) -> float:
+        """Reweight() + GetLikelihood(): one proposal's sample part (ref: Fitters/MR2T2.cpp:66-76)."""
+        p = np.ascontiguousarray(self.par, np.float64)
+        tot = C.c_double(0)
+        self.eng._chk(self.eng.lib.m3hip_step(self.eng.h, _ptr(p, np.float64), len(p), C.byref(tot), None))
+        return tot.value
+
+    def _bins(self):
+        mc = np.empty(self.nBins, np.float64)
+        w2 = np.empty(self.nBins, np.float64)
+        self.eng._chk(self.eng.lib.m3hip_get_bins(self.eng.h, _ptr(mc, np.float64), _ptr(w2, np.float64), self.nBins))
+        return mc, w2
+
+    def GetMCArray(self):
+        return self._bins()[0]
+
+    def GetW2Array(self):
+        return self._bins()[1]
+
+    # ---- parity helpers ----
+    def RecordEventWeights(self, on=True):
+        self.eng._chk(self.eng.lib.m3hip_record_event_weights(self.eng.h, int(on)))
+
+    def GetEventWeights(self, off, n):
+        out = np.empty(n, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_get_event_weights(self.eng.h, _ptr(out, np.float32), off, n))
+        return out
+
+    def GetSplineWeights(self, off, n):
+        out = np.empty(n, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_get_spline_weights(self.eng.h, _ptr(out, np.float32), off, n))
+        return out
+
+    def GetSegments(self, n_params):
+        seg = np.empty(n_params, np.int16)
+        val = np.empty(n_params, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_get_segments(self.eng.h, _ptr(seg, np.int16), _ptr(val, np.float32), n_params))
+        return seg, val
+
+
+def build_from_synth(spec, device_id=0, chunk_events=131072, event_range=None, engine=None):
+    """Generate `spec` (events [e0,e1) of it) and upload it through the C ABI.
+    Returns (engine, SMonolith, SampleHandlerFD, par_vector)."""
+    from . import synth
+
+    e0, e1 = (0, spec.n_events) if event_range is None else event_range
+    eng = engine or Engine(device_id)
+    cx, npts = synth.knots(spec)
+
+    def chunks():
+        for a in range(e0, e1, chunk_events):
+            yield synth.monolith_chunk(spec, a, min(e1, a + chunk_events))
+
+    mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, chunks())
+    par = synth.params(spec, 0)
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(eng, spec.n_samples, synth.sample_bin_offsets(spec), par, spec.test_statistic)
+    for a in range(e0, e1, chunk_events):
+        ev = synth.events_chunk(spec, a, min(e1, a + chunk_events))
+        sh.SetupEvents(a - e0, ev["bin_idx"], ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+    sh.SetOscillationWeights(synth.osc_table(spec))
+    return eng, mono, sh, par

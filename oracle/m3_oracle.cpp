@@ -1,0 +1,841 @@
+/*
+ * m3_oracle.cpp -- TEST INFRASTRUCTURE ONLY (see m3_oracle.h).
+ *
+ * ROOT-free CPU restatement of the reference's per-step likelihood path, in the
+ * reference's data layout and operation order.  "ref:" comments give the
+ * /root/reference file:line each block follows.  PARITY UNPINNED (no golden
+ * vectors exist in the reference tree); pinned by authored known-answer tests.
+ *
+ * Built twice by oracle/Makefile:
+ *   libm3oracle_serial.so  no OpenMP: `omp simd reduction` pragmas are inert, so
+ *                          float products run strictly left to right -- the
+ *                          bit-exact reference for per-event weights.
+ *   libm3oracle_omp.so     -fopenmp -DMULTITHREAD: the reference's pragmas active;
+ *                          this is the timed CPU baseline ("port").
+ * float_t is float: SMonolith only works in the _LOW_MEMORY_STRUCTS_ build
+ * (ref: Samples/SampleHandlerFD.cpp:1244-1254).
+ */
+#include "m3_oracle.h"
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <limits>
+#include <vector>
+
+#ifdef MULTITHREAD
+#include <omp.h>
+#endif
+
+namespace {
+
+typedef float m3_float_t;  // ref: Manager/Core.h:27-34 (_LOW_MEMORY_STRUCTS_)
+typedef short m3_int_t;
+
+const double kLowMCBound = M3O_LOW_MC_BOUND;
+const m3_float_t kUnity = 1.0f;  // ref: Manager/Core.h:56-72
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------------- */
+/* Test statistics                                                           */
+/* ------------------------------------------------------------------------- */
+
+// ref: Samples/SampleHandlerBase.cpp:17-31
+double m3o_poisson_llh(double data, double mc) {
+  if (data == 0) return mc;
+  if (mc < kLowMCBound) {
+    if (data > kLowMCBound) return (kLowMCBound - data + data * std::log(data / kLowMCBound));
+    else if (data >= mc) return 0.;
+  }
+  return (mc - data + data * std::log(data / mc));
+}
+
+// ref: Samples/SampleHandlerBase.cpp:35-192
+double m3o_test_stat_llh(int kind, double data, double mc, double w2) {
+  switch (kind) {
+    case M3O_kBarlowBeeston: {  // ref: :46-87
+      double newmc = mc;
+      if (mc < kLowMCBound) {
+        if (data > kLowMCBound) newmc = kLowMCBound;
+        else if (data >= mc) return 0.;
+      }
+      const double fractional = std::sqrt(w2) / newmc;
+      const double fractional2 = fractional * fractional;
+      const double temp = newmc * fractional2 - 1;
+      const double temp2 = temp * temp + 4 * data * fractional2;
+      if (temp2 < 0) return std::numeric_limits<double>::quiet_NaN();  // reference throws
+      const double beta = (-1 * temp + sqrt(temp2)) / 2.;
+      double stat = mc * beta;
+      if (data > 0) {
+        newmc *= beta;
+        stat = newmc - data + data * std::log(data / newmc);
+      }
+      double penalty = 0;
+      if (fractional > 0) penalty = (beta - 1) * (beta - 1) / (2 * fractional2);
+      return stat + penalty;
+    }
+    case M3O_kDembinskiAbdelmotteleb: {  // ref: :90-125
+      if (w2 == 0) return m3o_poisson_llh(data, mc);
+      double newmc = mc;
+      if (mc < kLowMCBound) {
+        if (data > kLowMCBound) newmc = kLowMCBound;
+        else if (data >= mc) return 0.;
+      }
+      const double k = newmc * newmc / w2;
+      const double beta = (data + k) / (newmc + k);
+      newmc *= beta;
+      const double penalty = k * beta - k + k * std::log(k / (k * beta));
+      double stat = newmc;
+      if (data > 0) stat = newmc - data + data * std::log(data / newmc);
+      return stat + penalty;
+    }
+    case M3O_kIceCube: {  // ref: :133-159 (long double + lgammal)
+      if (w2 == 0) return m3o_poisson_llh(data, mc);
+      const long double b = mc / w2;
+      const long double a = mc * b + 1;
+      const double stat = double(-1 * (a * logl(b) + lgammal(data + a) - lgammal(data + 1) -
+                                       ((data + a) * log1pl(b)) - lgammal(a)));
+      if (mc <= data) {
+        if (data <= kLowMCBound) return 0.;
+        const double poisson = m3o_poisson_llh(data, kLowMCBound);
+        if (stat > poisson) return poisson;
+      }
+      return stat;
+    }
+    case M3O_kPearson: {  // ref: :162-176
+      if (data == 0) return mc / 2.;
+      if (mc < kLowMCBound) {
+        if (data > kLowMCBound) return (data - kLowMCBound) * (data - kLowMCBound) / (2. * kLowMCBound);
+        else if (data >= mc) return 0.;
+      }
+      return (data - mc) * (data - mc) / (2 * mc);
+    }
+    case M3O_kPoisson:  // ref: :178-183
+      return m3o_poisson_llh(data, mc);
+    default:
+      return std::numeric_limits<double>::quiet_NaN();  // reference throws
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Reduced response functions (double-precision per-spline cross-check)       */
+/* ------------------------------------------------------------------------- */
+
+// ref: Splines/SplineStructs.h:673-703 (TSpline3_red::FindX)
+int m3o_tspline3_find_x(const float* xpos, int npoints, double x) {
+  int segment = 0;
+  int kHigh = npoints - 1;
+  if (x <= xpos[0]) {
+    segment = 0;
+  } else if (x >= xpos[npoints - 1]) {
+    segment = kHigh;
+  } else {
+    int kHalf = 0;
+    while (kHigh - segment > 1) {
+      kHalf = (segment + kHigh) / 2;
+      if (x > xpos[kHalf]) segment = kHalf;
+      else kHigh = kHalf;
+    }
+  }
+  if (segment >= npoints - 1 && npoints > 1) segment = npoints - 2;
+  return segment;
+}
+
+// ref: Splines/SplineStructs.h:706-717 (TSpline3_red::Eval)
+double m3o_tspline3_eval(const float* xpos, const float* yresp, const float* par, int npoints,
+                         double var) {
+  const int segment = m3o_tspline3_find_x(xpos, npoints, var);
+  const m3_float_t x = xpos[segment], y = yresp[segment];
+  const m3_float_t b = par[3 * segment + 0], c = par[3 * segment + 1], d = par[3 * segment + 2];
+  const double dx = var - x;
+  return y + dx * (b + dx * (c + d * dx));
+}
+
+// ref: Splines/SplineStructs.h:192-193 (TF1_red::Eval)
+double m3o_tf1_eval(const float* par, double var) { return par[1] + par[0] * var; }
+
+/* ------------------------------------------------------------------------- */
+/* Spline monolith                                                            */
+/* ------------------------------------------------------------------------- */
+
+// ref: Splines/SplineStructs.h:21-44
+struct FastSplineInfo_o {
+  m3_int_t nPts = -999;
+  std::vector<m3_float_t> xPts;
+  m3_int_t CurrSegment = 0;
+  const double* splineParsPointer = nullptr;
+};
+
+struct m3o_monolith {
+  uint64_t NEvents = 0;
+  short nParams = 0;
+  short max_knots = 0;
+  uint64_t NSplines_valid = 0;
+  uint64_t NTF1_valid = 0;
+  // borrowed reference-layout arrays (ref: Splines/SplineCommon.h:30-50, SplineMonolith.h:106-137)
+  const float* coeff_x = nullptr;
+  const float* coeff_many = nullptr;
+  const unsigned int* nKnots_arr = nullptr;
+  const int16_t* paramNo_arr = nullptr;
+  const float* coeff_TF1_many = nullptr;
+  const int16_t* paramNo_TF1_arr = nullptr;
+  const unsigned int* nParamPerEvent = nullptr;
+  const unsigned int* nParamPerEvent_tf1 = nullptr;
+  // owned
+  std::vector<FastSplineInfo_o> SplineInfoArray;
+  std::vector<short> SplineSegments;
+  std::vector<float> ParamValues;
+  std::vector<short> CurrSegState;  // mirror of SplineInfoArray[i].CurrSegment for inspection
+  std::vector<float> cpu_weights_spline_var;
+  std::vector<float> cpu_weights_tf1_var;
+  std::vector<float> cpu_total_weights;
+};
+
+m3o_monolith* m3o_monolith_create(uint64_t n_events, int n_params, int max_knots,
+                                  const float* coeff_x, const int16_t* npts, uint64_t n_splines,
+                                  const float* coeff_many, const unsigned int* nknots_arr,
+                                  const int16_t* param_no, uint64_t n_tf1, const float* coeff_tf1,
+                                  const int16_t* param_no_tf1, const unsigned int* n_param_per_event,
+                                  const unsigned int* n_param_per_event_tf1) {
+  m3o_monolith* m = new m3o_monolith();
+  m->NEvents = n_events;
+  m->nParams = short(n_params);
+  m->max_knots = short(max_knots);
+  m->NSplines_valid = n_splines;
+  m->NTF1_valid = n_tf1;
+  m->coeff_x = coeff_x;
+  m->coeff_many = coeff_many;
+  m->nKnots_arr = nknots_arr;
+  m->paramNo_arr = param_no;
+  m->coeff_TF1_many = coeff_tf1;
+  m->paramNo_TF1_arr = param_no_tf1;
+  m->nParamPerEvent = n_param_per_event;
+  m->nParamPerEvent_tf1 = n_param_per_event_tf1;
+  // ref: SplineMonolith.cpp:387-401 -- xPts come from the first spline seen for the
+  // parameter; here they are read back from coeff_x, which the reference fills with
+  // the same knots (SplineMonolith.cpp:162-164).
+  m->SplineInfoArray.resize(n_params);
+  for (int i = 0; i < n_params; ++i) {
+    FastSplineInfo_o& info = m->SplineInfoArray[i];
+    if (npts[i] > 0) {
+      info.nPts = npts[i];
+      info.xPts.assign(coeff_x + size_t(i) * max_knots, coeff_x + size_t(i) * max_knots + npts[i]);
+    }
+  }
+  // ref: SplineMonolith.cpp:85-93
+  m->SplineSegments.assign(n_params, 0);
+  m->ParamValues.assign(n_params, -999.f);
+  m->CurrSegState.assign(n_params, 0);
+  // ref: SplineMonolith.cpp:240-244
+  m->cpu_total_weights.assign(n_events, 0.f);
+  m->cpu_weights_spline_var.assign(n_splines, 0.f);
+  m->cpu_weights_tf1_var.assign(n_tf1, 0.f);
+  return m;
+}
+
+void m3o_monolith_destroy(m3o_monolith* m) { delete m; }
+
+// ref: Splines/SplineMonolith.h:44-46
+void m3o_monolith_set_spline_pointers(m3o_monolith* m, const double* const* ptrs) {
+  for (m3_int_t i = 0; i < m->nParams; ++i) m->SplineInfoArray[i].splineParsPointer = ptrs[i];
+}
+
+// ref: Splines/SplineBase.cpp:44-109
+void m3o_monolith_find_spline_segment(m3o_monolith* m) {
+  for (m3_int_t i = 0; i < m->nParams; ++i) {
+    FastSplineInfo_o& info = m->SplineInfoArray[i];
+    const m3_int_t nPoints = info.nPts;
+    const std::vector<m3_float_t>& xArray = info.xPts;
+
+    const float xvar = float(*info.splineParsPointer);  // ref: :54 double -> float
+    m->ParamValues[i] = xvar;
+
+    if (xArray.size() == 0) continue;  // ref: :60
+
+    m3_int_t segment = 0;
+    m3_int_t kHigh = m3_int_t(nPoints - 1);
+    const m3_int_t PreviousSegment = info.CurrSegment;
+
+    if (xvar <= xArray[0]) {
+      segment = 0;
+    } else if (xvar >= xArray[nPoints - 1]) {
+      segment = kHigh;
+    } else if (xArray[PreviousSegment + 1] > xvar && xvar >= xArray[PreviousSegment]) {  // ref: :76
+      segment = PreviousSegment;
+    } else {
+      m3_int_t kHalf = 0;
+      while (kHigh - segment > 1) {  // ref: :84-94
+        kHalf = m3_int_t((segment + kHigh) / 2);
+        if (xvar > xArray[kHalf]) segment = kHalf;
+        else kHigh = kHalf;
+      }
+    }
+    if (segment >= nPoints - 1 && nPoints > 1) segment = m3_int_t(nPoints - 2);  // ref: :97
+
+    info.CurrSegment = segment;
+    m->SplineSegments[i] = short(info.CurrSegment);
+    m->CurrSegState[i] = segment;
+  }
+}
+
+void m3o_monolith_set_vals_segments(m3o_monolith* m, const float* vals, const int16_t* segments) {
+  for (int i = 0; i < m->nParams; ++i) {
+    m->ParamValues[i] = vals[i];
+    m->SplineSegments[i] = segments[i];
+  }
+}
+
+// ref: Splines/SplineMonolith.cpp:727-788
+void m3o_monolith_calc_spline_weights(m3o_monolith* m) {
+  const uint64_t NSplines_valid = m->NSplines_valid;
+  const uint64_t NTF1_valid = m->NTF1_valid;
+  const short* SplineSegments = m->SplineSegments.data();
+  const float* ParamValues = m->ParamValues.data();
+  const short _max_knots = m->max_knots;
+  float* cpu_weights_spline_var = m->cpu_weights_spline_var.data();
+  float* cpu_weights_tf1_var = m->cpu_weights_tf1_var.data();
+#ifdef MULTITHREAD
+#pragma omp parallel
+  {
+#endif
+#ifdef MULTITHREAD
+#pragma omp for simd nowait
+#endif
+    for (uint64_t splineNum = 0; splineNum < NSplines_valid; ++splineNum) {
+      const short Param = m->paramNo_arr[splineNum];
+      const short segment = SplineSegments[Param];
+      // the reference narrows this index to short (ref: :747); widened here so P*K > 32767 works
+      const int segment_X = int(Param) * _max_knots + segment;
+      // ref: :750 (unsigned int arithmetic, as in the reference)
+      const unsigned int CurrentKnotPos = m->nKnots_arr[splineNum] * 4 + segment * 4;
+      const float fY = m->coeff_many[CurrentKnotPos];
+      const float fB = m->coeff_many[CurrentKnotPos + 1];
+      const float fC = m->coeff_many[CurrentKnotPos + 2];
+      const float fD = m->coeff_many[CurrentKnotPos + 3];
+      const float dx = ParamValues[Param] - m->coeff_x[segment_X];
+      cpu_weights_spline_var[splineNum] = fmaf(dx, fmaf(dx, fmaf(dx, fD, fC), fB), fY);  // ref: :762
+    }
+#ifdef MULTITHREAD
+#pragma omp for simd
+#endif
+    for (uint64_t tf1Num = 0; tf1Num < NTF1_valid; ++tf1Num) {
+      const float x = ParamValues[m->paramNo_TF1_arr[tf1Num]];
+      const uint64_t TF1_Index = tf1Num * 2;  // _nTF1Coeff_ = 2 (ref: Splines/SplineCommon.h:15)
+      const float a = m->coeff_TF1_many[TF1_Index];
+      const float b = m->coeff_TF1_many[TF1_Index + 1];
+      cpu_weights_tf1_var[tf1Num] = fmaf(a, x, b);  // ref: :779
+    }
+#ifdef MULTITHREAD
+  }
+#endif
+}
+
+// ref: Splines/SplineMonolith.cpp:792-830
+void m3o_monolith_calc_total_event_weight(m3o_monolith* m) {
+  const uint64_t NEvents = m->NEvents;
+  const float* cpu_weights_spline_var = m->cpu_weights_spline_var.data();
+  const float* cpu_weights_tf1_var = m->cpu_weights_tf1_var.data();
+  float* cpu_total_weights = m->cpu_total_weights.data();
+#ifdef MULTITHREAD
+#pragma omp parallel for
+#endif
+  for (uint64_t EventNum = 0; EventNum < NEvents; ++EventNum) {
+    float totalWeight = 1.0f;
+    const uint64_t Offset = 2 * EventNum;
+    const uint64_t startIndex = m->nParamPerEvent[Offset + 1];
+    const uint64_t numParams = m->nParamPerEvent[Offset];
+#ifdef MULTITHREAD
+#pragma omp simd reduction(* : totalWeight)
+#endif
+    for (uint64_t id = 0; id < numParams; ++id) totalWeight *= cpu_weights_spline_var[startIndex + id];
+
+    const uint64_t startIndex_tf1 = m->nParamPerEvent_tf1[Offset + 1];
+    const uint64_t numParams_tf1 = m->nParamPerEvent_tf1[Offset];
+#ifdef MULTITHREAD
+#pragma omp simd reduction(* : totalWeight)
+#endif
+    for (uint64_t id = 0; id < numParams_tf1; ++id) totalWeight *= cpu_weights_tf1_var[startIndex_tf1 + id];
+
+    cpu_total_weights[EventNum] = totalWeight;
+  }
+}
+
+// ref: Splines/SplineMonolith.cpp:712-723
+void m3o_monolith_evaluate(m3o_monolith* m) {
+  m3o_monolith_find_spline_segment(m);
+  m3o_monolith_calc_spline_weights(m);
+  m3o_monolith_calc_total_event_weight(m);
+}
+
+const float* m3o_monolith_total_weights(const m3o_monolith* m) { return m->cpu_total_weights.data(); }
+const float* m3o_monolith_spline_weights(const m3o_monolith* m) { return m->cpu_weights_spline_var.data(); }
+const float* m3o_monolith_tf1_weights(const m3o_monolith* m) { return m->cpu_weights_tf1_var.data(); }
+const int16_t* m3o_monolith_segments(const m3o_monolith* m) { return m->SplineSegments.data(); }
+const float* m3o_monolith_param_values(const m3o_monolith* m) { return m->ParamValues.data(); }
+int16_t* m3o_monolith_curr_segment_state(m3o_monolith* m) {
+  // expose FastSplineInfo.CurrSegment so tests can seed/inspect the shortcut state (ref: SplineBase.cpp:73-78)
+  for (int i = 0; i < m->nParams; ++i) m->CurrSegState[i] = m->SplineInfoArray[i].CurrSegment;
+  return m->CurrSegState.data();
+}
+
+/* ------------------------------------------------------------------------- */
+/* Binning                                                                    */
+/* ------------------------------------------------------------------------- */
+
+// ref: Samples/SampleStructs.h:172-184
+struct BinShiftLookup_o {
+  double lower_binedge, lower_lower_binedge, upper_binedge, upper_upper_binedge;
+};
+
+// ref: Samples/SampleStructs.h:186-220 -- note the (lo, hi] test
+struct BinInfo_o {
+  std::vector<std::array<double, 2>> Extent;
+  bool IsEventInside(const std::vector<const double*>& KinVars) const {
+    bool inside = true;
+    const size_t N = KinVars.size();
+    for (size_t i = 0; i < N; ++i) {
+      const double Var = *KinVars[i];
+      const bool in_bin = (Var > Extent[i][0]) & (Var <= Extent[i][1]);
+      inside &= in_bin;
+    }
+    return inside;
+  }
+};
+
+// ref: Samples/SampleStructs.h:232-675
+struct SampleBinningInfo_o {
+  std::vector<std::vector<double>> BinEdges;
+  std::vector<int> AxisNBins;
+  int nBins = -999;
+  int GlobalOffset = -999;
+  std::vector<std::vector<BinShiftLookup_o>> BinLookup;
+  std::vector<int> Strides;
+  bool Uniform = true;
+  std::vector<BinInfo_o> Bins;
+  std::vector<std::vector<int>> BinGridMapping;
+
+  // ref: :648-659
+  void InitialiseStrides(int Dimension) {
+    Strides.resize(Dimension);
+    int stride = 1;
+    for (int i = 0; i < Dimension; ++i) {
+      Strides[i] = stride;
+      stride *= AxisNBins[i];
+    }
+  }
+  // ref: :615-646
+  void InitialiseLookUpSingleDimension(std::vector<BinShiftLookup_o>& Bin_Lookup,
+                                       const std::vector<double>& Bin_Edges, int TotBins) {
+    Bin_Lookup.resize(TotBins);
+    for (int bin_i = 0; bin_i < TotBins; bin_i++) {
+      double low_lower_edge = -999999.123456;  // M3::_DEFAULT_RETURN_VAL_
+      const double low_edge = Bin_Edges[bin_i];
+      const double upper_edge = Bin_Edges[bin_i + 1];
+      double upper_upper_edge = -999999.123456;
+      low_lower_edge = (bin_i == 0) ? Bin_Edges[0] : Bin_Edges[bin_i - 1];
+      if (bin_i + 2 < TotBins) upper_upper_edge = Bin_Edges[bin_i + 2];
+      else if (bin_i + 1 < TotBins) upper_upper_edge = Bin_Edges[bin_i + 1];
+      Bin_Lookup[bin_i].lower_binedge = low_edge;
+      Bin_Lookup[bin_i].upper_binedge = upper_edge;
+      Bin_Lookup[bin_i].lower_lower_binedge = low_lower_edge;
+      Bin_Lookup[bin_i].upper_upper_binedge = upper_upper_edge;
+    }
+  }
+  // ref: :663-670
+  void InitialiseBinMigrationLookUp(int Dimension) {
+    BinLookup.resize(Dimension);
+    for (int i = 0; i < Dimension; ++i) InitialiseLookUpSingleDimension(BinLookup[i], BinEdges[i], AxisNBins[i]);
+    InitialiseStrides(Dimension);
+  }
+  // ref: :250-287
+  bool InitUniform(const std::vector<std::vector<double>>& InputEdges) {
+    BinEdges = InputEdges;
+    Uniform = true;
+    AxisNBins.resize(BinEdges.size());
+    nBins = 1;
+    for (size_t iDim = 0; iDim < BinEdges.size(); iDim++) {
+      const auto& Edges = BinEdges[iDim];
+      if (!std::is_sorted(Edges.begin(), Edges.end())) return false;
+      if (Edges.size() == 0) return false;
+      AxisNBins[iDim] = int(Edges.size()) - 1;
+      nBins *= AxisNBins[iDim];
+    }
+    GlobalOffset = 0;
+    InitialiseBinMigrationLookUp(int(BinEdges.size()));
+    return true;
+  }
+  // ref: :397-462
+  void InitialiseGridMapping() {
+    const size_t Dim = BinEdges.size();
+    int NGridBins = 1;
+    for (size_t d = 0; d < Dim; ++d) NGridBins *= AxisNBins[d];
+    BinGridMapping.assign(NGridBins, std::vector<int>());
+    std::vector<int> MultiIndex(Dim, 0);
+    std::function<void(size_t, int)> scan = [&](size_t d, int LinearIndex) {
+      if (d == Dim) {
+        for (size_t iBin = 0; iBin < Bins.size(); ++iBin) {
+          bool overlap = true;
+          for (size_t i = 0; i < Dim; ++i) {
+            const double a_lo = Bins[iBin].Extent[i][0], a_hi = Bins[iBin].Extent[i][1];
+            const double b_lo = BinEdges[i][MultiIndex[i]], b_hi = BinEdges[i][MultiIndex[i] + 1];
+            if (!(a_hi > b_lo && a_lo < b_hi)) { overlap = false; break; }
+          }
+          if (overlap) BinGridMapping[LinearIndex].push_back(int(iBin));
+        }
+        return;
+      }
+      for (int i = 0; i < AxisNBins[d]; ++i) {
+        MultiIndex[d] = i;
+        int NewLinearIndex = LinearIndex;
+        if (d > 0) {
+          int stride = 1;
+          for (size_t s = 0; s < d; ++s) stride *= AxisNBins[s];
+          NewLinearIndex += i * stride;
+        } else {
+          NewLinearIndex = i;
+        }
+        scan(d + 1, NewLinearIndex);
+      }
+    };
+    scan(0, 0);
+  }
+  // ref: :465-530 (overlap / gap validation :290-394 is setup-time diagnostics, omitted)
+  bool InitNonUniform(int nbins, int ndim, const double* extents) {
+    Uniform = false;
+    nBins = 0;
+    if (ndim <= 1 || nbins <= 0) return false;  // ref: :471-474
+    Bins.resize(nbins);
+    for (int iBin = 0; iBin < nbins; ++iBin) {
+      BinInfo_o NewBin;
+      for (int d = 0; d < ndim; ++d)
+        NewBin.Extent.push_back({extents[(size_t(iBin) * ndim + d) * 2], extents[(size_t(iBin) * ndim + d) * 2 + 1]});
+      Bins[iBin] = std::move(NewBin);
+      nBins++;
+    }
+    const int BinsPerDimension = 10;  // ref: :499
+    BinEdges.resize(ndim);
+    AxisNBins.resize(ndim);
+    for (int iDim = 0; iDim < ndim; iDim++) {
+      double MinVal = std::numeric_limits<double>::max();
+      double MaxVal = std::numeric_limits<double>::lowest();
+      for (const auto& bin : Bins) {
+        MinVal = std::min(MinVal, bin.Extent[iDim][0]);
+        MaxVal = std::max(MaxVal, bin.Extent[iDim][1]);
+      }
+      BinEdges[iDim].resize(BinsPerDimension + 1);
+      const double BinWidth = (MaxVal - MinVal) / double(BinsPerDimension);
+      for (int iEdge = 0; iEdge <= BinsPerDimension; iEdge++) BinEdges[iDim][iEdge] = MinVal + double(iEdge) * BinWidth;
+      AxisNBins[iDim] = BinsPerDimension;
+    }
+    GlobalOffset = 0;
+    InitialiseBinMigrationLookUp(ndim);
+    InitialiseGridMapping();
+    return true;
+  }
+  // ref: :577-613
+  int FindBin(double KinVar, int NomBin, int N_Bins, const std::vector<double>& Bin_Edges,
+              const std::vector<BinShiftLookup_o>& Bin_Lookup) const {
+    if (KinVar < Bin_Edges[0] || KinVar >= Bin_Edges[N_Bins]) return M3O_UNDER_OVERFLOW_BIN;
+    if (NomBin > M3O_UNDER_OVERFLOW_BIN) {
+      const BinShiftLookup_o& Bin = Bin_Lookup[NomBin];
+      const double lower = Bin.lower_binedge, upper = Bin.upper_binedge;
+      const double lower_lower = Bin.lower_lower_binedge, upper_upper = Bin.upper_upper_binedge;
+      if (KinVar < upper && KinVar >= lower) return NomBin;
+      if (KinVar < lower && KinVar >= lower_lower) return NomBin - 1;
+      if (KinVar < upper_upper && KinVar >= upper) return NomBin + 1;
+    }
+    return int(std::distance(Bin_Edges.begin(), std::upper_bound(Bin_Edges.begin(), Bin_Edges.end(), KinVar)) - 1);
+  }
+  int FindBin(int Dimension, double Var, int NomBin) const {  // ref: :559-561
+    return FindBin(Var, NomBin, AxisNBins[Dimension], BinEdges[Dimension], BinLookup[Dimension]);
+  }
+};
+
+struct m3o_binning {
+  std::vector<SampleBinningInfo_o> SampleBinning;
+  int TotalNumberOfBins = 0;
+  // ref: Samples/BinningHandler.cpp:341-355
+  void SetGlobalBinNumbers() {
+    int GlobalOffsetCounter = 0;
+    for (size_t iSample = 0; iSample < SampleBinning.size(); iSample++) {
+      SampleBinning[iSample].GlobalOffset = GlobalOffsetCounter;
+      GlobalOffsetCounter += SampleBinning[iSample].nBins;
+    }
+    TotalNumberOfBins = GlobalOffsetCounter;
+  }
+  // ref: Samples/BinningHandler.cpp:257-291
+  int FindGlobalBin(int NomSample, const std::vector<const double*>& KinVar, const std::vector<int>& NomBin) const {
+    const int Dim = int(KinVar.size());
+    const SampleBinningInfo_o& Binning = SampleBinning[NomSample];
+    int GlobalBin = 0;
+    for (int i = 0; i < Dim; ++i) {
+      const double Var = *KinVar[i];
+      const int Bin = Binning.FindBin(i, Var, NomBin[i]);
+      if (Bin < 0) return M3O_UNDER_OVERFLOW_BIN;
+      GlobalBin += Bin * Binning.Strides[i];
+    }
+    if (Binning.Uniform) {
+      GlobalBin += Binning.GlobalOffset;
+      return GlobalBin;
+    } else {
+      const auto& BinMapping = Binning.BinGridMapping[GlobalBin];
+      for (size_t iBin = 0; iBin < BinMapping.size(); iBin++) {
+        const int BinNumber = BinMapping[iBin];
+        if (Binning.Bins[BinNumber].IsEventInside(KinVar)) return BinNumber + Binning.GlobalOffset;
+      }
+      return M3O_UNDER_OVERFLOW_BIN;
+    }
+  }
+  // ref: Samples/BinningHandler.cpp:294-307
+  int FindNominalBin(int iSample, int iDim, double Var) const {
+    const auto& edges = SampleBinning[iSample].BinEdges[iDim];
+    if (Var < edges.front() || Var >= edges.back()) return M3O_UNDER_OVERFLOW_BIN;
+    return int(std::distance(edges.begin(), std::upper_bound(edges.begin(), edges.end(), Var)) - 1);
+  }
+};
+
+m3o_binning* m3o_binning_create(void) { return new m3o_binning(); }
+void m3o_binning_destroy(m3o_binning* b) { delete b; }
+
+int m3o_binning_add_uniform(m3o_binning* b, int ndim, const int* n_edges, const double* edges) {
+  std::vector<std::vector<double>> in(ndim);
+  size_t off = 0;
+  for (int d = 0; d < ndim; ++d) {
+    in[d].assign(edges + off, edges + off + n_edges[d]);
+    off += n_edges[d];
+  }
+  SampleBinningInfo_o s;
+  if (!s.InitUniform(in)) return -1;
+  b->SampleBinning.emplace_back(std::move(s));
+  b->SetGlobalBinNumbers();
+  return int(b->SampleBinning.size()) - 1;
+}
+
+int m3o_binning_add_nonuniform(m3o_binning* b, int nbins, int ndim, const double* extents) {
+  SampleBinningInfo_o s;
+  if (!s.InitNonUniform(nbins, ndim, extents)) return -1;
+  b->SampleBinning.emplace_back(std::move(s));
+  b->SetGlobalBinNumbers();
+  return int(b->SampleBinning.size()) - 1;
+}
+
+int m3o_binning_n_samples(const m3o_binning* b) { return int(b->SampleBinning.size()); }
+int m3o_binning_n_bins(const m3o_binning* b) { return b->TotalNumberOfBins; }
+int m3o_binning_sample_n_bins(const m3o_binning* b, int s) { return b->SampleBinning[s].nBins; }
+int m3o_binning_sample_start(const m3o_binning* b, int s) { return b->SampleBinning[s].GlobalOffset; }
+int m3o_binning_sample_end(const m3o_binning* b, int s) {  // ref: BinningHandler.cpp:329-337
+  if (s == int(b->SampleBinning.size()) - 1) return b->TotalNumberOfBins;
+  return b->SampleBinning[s + 1].GlobalOffset;
+}
+int m3o_binning_n_dim(const m3o_binning* b, int s) { return int(b->SampleBinning[s].BinEdges.size()); }
+int m3o_binning_find_nominal_bin(const m3o_binning* b, int s, int dim, double var) { return b->FindNominalBin(s, dim, var); }
+int m3o_binning_find_bin(const m3o_binning* b, int s, int dim, double var, int nom_bin) {
+  return b->SampleBinning[s].FindBin(dim, var, nom_bin);
+}
+int m3o_binning_find_global_bin(const m3o_binning* b, int s, const double* kinvar, const int* nom_bin) {
+  const int ndim = int(b->SampleBinning[s].BinEdges.size());
+  std::vector<const double*> kv(ndim);
+  std::vector<int> nb(ndim);
+  for (int d = 0; d < ndim; ++d) { kv[d] = &kinvar[d]; nb[d] = nom_bin[d]; }
+  return b->FindGlobalBin(s, kv, nb);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sample handler                                                             */
+/* ------------------------------------------------------------------------- */
+
+// ref: Samples/FarDetectorCoreInfoStruct.h:82-126 (fields used on the hot path only)
+struct EventInfo_o {
+  std::vector<const double*> norm_pointers;
+  std::vector<const m3_float_t*> total_weight_pointers;
+  std::vector<const double*> KinVar;
+  std::vector<int> NomBin;
+  int NominalSample = -999;
+};
+
+struct m3o_sample {
+  const m3o_binning* Binning = nullptr;
+  m3o_monolith* SplineHandler = nullptr;
+  std::vector<EventInfo_o> MCSamples;
+  std::vector<double> SampleHandlerFD_array, SampleHandlerFD_array_w2, SampleHandlerFD_data;
+  int fTestStatistic = M3O_kPoisson;
+  bool FirstTimeW2 = true;  // ref: SampleHandlerFD.cpp:28-30
+  bool UpdateW2 = false;    // ref: SampleHandlerFD.cpp:62-65
+  double t_spline = 0, t_fill = 0;
+};
+
+m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int32_t* sample_id,
+                              int kin_stride, const double* kin, const uint64_t* norm_off,
+                              const int16_t* norm_idx, const double* par_base, const int32_t* osc_idx,
+                              const float* osc_table, m3o_monolith* mono) {
+  m3o_sample* s = new m3o_sample();
+  s->Binning = b;
+  s->SplineHandler = mono;
+  s->MCSamples.resize(n_events);
+  for (uint64_t e = 0; e < n_events; ++e) {
+    EventInfo_o& ev = s->MCSamples[e];
+    ev.NominalSample = sample_id ? sample_id[e] : 0;
+    const int ndim = int(b->SampleBinning[ev.NominalSample].BinEdges.size());
+    ev.KinVar.resize(ndim);
+    ev.NomBin.resize(ndim);
+    for (int d = 0; d < ndim; ++d) {
+      ev.KinVar[d] = &kin[e * kin_stride + d];
+      // ref: SampleHandlerFD.cpp:757-887 FindNominalBinAndEdges -> BinningHandler::FindNominalBin
+      ev.NomBin[d] = b->FindNominalBin(ev.NominalSample, d, *ev.KinVar[d]);
+    }
+    // ref: SampleHandlerFD.cpp:637-663 SetupNormParameters
+    if (norm_off)
+      for (uint64_t k = norm_off[e]; k < norm_off[e + 1]; ++k) ev.norm_pointers.push_back(&par_base[norm_idx[k]]);
+    // ref: SampleHandlerFD.cpp:1108-1122 osc pointer first (SetupOscParameters runs before SetupSplines)
+    if (osc_idx && osc_idx[e] >= 0) ev.total_weight_pointers.push_back(&osc_table[osc_idx[e]]);
+    // ref: SampleHandlerFD.cpp:1244-1249 then the monolith's total weight
+    if (mono) ev.total_weight_pointers.push_back(&mono->cpu_total_weights[e]);
+  }
+  const int nb = b->TotalNumberOfBins;
+  s->SampleHandlerFD_array.assign(nb, 0.);
+  s->SampleHandlerFD_array_w2.assign(nb, 0.);
+  s->SampleHandlerFD_data.assign(nb, 0.);
+  (void)kUnity;
+  return s;
+}
+
+void m3o_sample_destroy(m3o_sample* s) { delete s; }
+
+void m3o_sample_set_test_statistic(m3o_sample* s, int kind, int update_w2) {
+  s->fTestStatistic = kind;
+  s->UpdateW2 = update_w2 != 0;
+}
+
+// ref: Samples/SampleHandlerFD.cpp:1027-1044
+void m3o_sample_add_data(m3o_sample* s, const double* data) {
+  s->SampleHandlerFD_data.assign(data, data + s->Binning->TotalNumberOfBins);
+}
+
+// ref: Samples/SampleHandlerFD.cpp:568-594
+static m3_float_t CalcWeightTotal(const EventInfo_o* MCEvent) {
+  m3_float_t TotalWeight = 1.0;
+  const int nNorms = int(MCEvent->norm_pointers.size());
+#ifdef MULTITHREAD
+#pragma omp simd reduction(* : TotalWeight)
+#endif
+  for (int iParam = 0; iParam < nNorms; ++iParam) TotalWeight *= static_cast<m3_float_t>(*(MCEvent->norm_pointers[iParam]));
+  const int TotalWeights = int(MCEvent->total_weight_pointers.size());
+#ifdef MULTITHREAD
+#pragma omp simd reduction(* : TotalWeight)
+#endif
+  for (int iWeight = 0; iWeight < TotalWeights; ++iWeight) TotalWeight *= *(MCEvent->total_weight_pointers[iWeight]);
+  return TotalWeight;
+}
+
+// ref: Samples/SampleHandlerFD.cpp:454-463
+static void ResetHistograms(m3o_sample* s) {
+  const int nBins = s->Binning->TotalNumberOfBins;
+  std::fill_n(s->SampleHandlerFD_array.begin(), nBins, 0.0);
+  if (s->FirstTimeW2) std::fill_n(s->SampleHandlerFD_array_w2.begin(), nBins, 0.0);
+}
+
+// ref: Samples/SampleHandlerFD.cpp:352-383 (serial) / :390-448 (FillArray_MP)
+// ApplyShifts (no functional parameters -> early return :550), IsEventSelected (no cuts)
+// and CalcWeightFunc (default no-op, SampleHandlerFD.h:289) are empty in the synthetic configs.
+static void FillArray(m3o_sample* s) {
+  const uint64_t NumberOfEvents = s->MCSamples.size();
+  double* MC_Array_for_reduction = s->SampleHandlerFD_array.data();
+  double* W2_array_for_reduction = s->SampleHandlerFD_array_w2.data();
+  const bool FirstTimeW2 = s->FirstTimeW2;
+#ifdef MULTITHREAD
+  const int TotalBins = s->Binning->TotalNumberOfBins;
+#pragma omp parallel for reduction(+ : MC_Array_for_reduction[:TotalBins], W2_array_for_reduction[:TotalBins])
+#endif
+  for (uint64_t iEvent = 0; iEvent < NumberOfEvents; ++iEvent) {
+    const EventInfo_o* MCEvent = &s->MCSamples[iEvent];
+    const m3_float_t totalweight = CalcWeightTotal(MCEvent);
+    if (totalweight <= 0.) continue;  // ref: :432
+    const int GlobalBin = s->Binning->FindGlobalBin(MCEvent->NominalSample, MCEvent->KinVar, MCEvent->NomBin);
+    if (GlobalBin > M3O_UNDER_OVERFLOW_BIN) {  // ref: :443-446
+      MC_Array_for_reduction[GlobalBin] += totalweight;
+      if (FirstTimeW2) W2_array_for_reduction[GlobalBin] += totalweight * totalweight;  // float product, then widened
+    }
+  }
+}
+
+// ref: Samples/SampleHandlerFD.cpp:316-343
+void m3o_sample_reweight(m3o_sample* s) {
+  ResetHistograms(s);
+  // Oscillator->Evaluate(): probabilities are pre-staged in osc_table (BASELINE configs)
+  const double t0 = now_s();
+  if (s->SplineHandler) m3o_monolith_evaluate(s->SplineHandler);
+  const double t1 = now_s();
+  FillArray(s);
+  const double t2 = now_s();
+  s->t_spline = t1 - t0;
+  s->t_fill = t2 - t1;
+  if (!s->UpdateW2) s->FirstTimeW2 = false;  // ref: :342
+}
+
+// ref: Samples/SampleHandlerFD.cpp:1284-1300
+double m3o_sample_get_likelihood(const m3o_sample* s) {
+  double negLogL = 0.;
+  const int nb = s->Binning->TotalNumberOfBins;
+#ifdef MULTITHREAD
+#pragma omp parallel for reduction(+ : negLogL)
+#endif
+  for (int idx = 0; idx < nb; ++idx)
+    negLogL += m3o_test_stat_llh(s->fTestStatistic, s->SampleHandlerFD_data[idx], s->SampleHandlerFD_array[idx],
+                                 s->SampleHandlerFD_array_w2[idx]);
+  return negLogL;
+}
+
+// ref: Samples/SampleHandlerFD.cpp:1262-1281
+double m3o_sample_get_sample_likelihood(const m3o_sample* s, int isample) {
+  const int Start = m3o_binning_sample_start(s->Binning, isample);
+  const int End = m3o_binning_sample_end(s->Binning, isample);
+  double negLogL = 0.;
+#ifdef MULTITHREAD
+#pragma omp parallel for reduction(+ : negLogL)
+#endif
+  for (int idx = Start; idx < End; ++idx)
+    negLogL += m3o_test_stat_llh(s->fTestStatistic, s->SampleHandlerFD_data[idx], s->SampleHandlerFD_array[idx],
+                                 s->SampleHandlerFD_array_w2[idx]);
+  return negLogL;
+}
+
+const double* m3o_sample_mc(const m3o_sample* s) { return s->SampleHandlerFD_array.data(); }
+const double* m3o_sample_w2(const m3o_sample* s) { return s->SampleHandlerFD_array_w2.data(); }
+const double* m3o_sample_data(const m3o_sample* s) { return s->SampleHandlerFD_data.data(); }
+
+void m3o_sample_event_weights(const m3o_sample* s, float* out) {
+  for (size_t e = 0; e < s->MCSamples.size(); ++e) out[e] = CalcWeightTotal(&s->MCSamples[e]);
+}
+void m3o_sample_event_bins(const m3o_sample* s, int32_t* out) {
+  for (size_t e = 0; e < s->MCSamples.size(); ++e) {
+    const EventInfo_o& ev = s->MCSamples[e];
+    out[e] = s->Binning->FindGlobalBin(ev.NominalSample, ev.KinVar, ev.NomBin);
+  }
+}
+void m3o_sample_last_timing(const m3o_sample* s, double* t_spline, double* t_fill) {
+  *t_spline = s->t_spline;
+  *t_fill = s->t_fill;
+}
+
+int m3o_is_multithread(void) {
+#ifdef MULTITHREAD
+  return 1;
+#else
+  return 0;
+#endif
+}
+int m3o_max_threads(void) {
+#ifdef MULTITHREAD
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,154 @@
+/*
+ * m3_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's per-step likelihood path
+ * (SMonolith::Evaluate -> SampleHandlerFD::Reweight -> GetLikelihood), written
+ * from the reference sources under /root/reference (MaCh3 v2.4.2).  Every
+ * function cites the reference file:line it follows.
+ *
+ * PARITY UNPINNED: the reference tree holds no golden vectors, known-answer
+ * tests or fixtures for this path (its tests live in the external
+ * MaCh3Tutorial repository) and the reference itself cannot be compiled here
+ * (ROOT / spdlog / yaml-cpp / NuOscillator absent).  This oracle is pinned
+ * only by known-answer tests authored from the reference's source semantics
+ * (tests/test_oracle_kat.py) and by the fixtures under tests/golden/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (mach3_amd/, include/) never does.
+ */
+#ifndef M3_ORACLE_H
+#define M3_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Manager/Core.h:80-91 */
+#define M3O_LARGE_LOGL 1234567890.0
+#define M3O_LOW_MC_BOUND 0.00001
+#define M3O_UNDER_OVERFLOW_BIN (-1)
+
+/* Samples/SampleStructs.h:105-112 (enum order kept) */
+enum m3o_test_statistic {
+  M3O_kPoisson = 0,
+  M3O_kBarlowBeeston = 1,
+  M3O_kIceCube = 2,
+  M3O_kPearson = 3,
+  M3O_kDembinskiAbdelmotteleb = 4,
+  M3O_kNTestStatistics = 5
+};
+
+/* ---- test statistics: Samples/SampleHandlerBase.cpp:17-192 ---- */
+double m3o_poisson_llh(double data, double mc);
+/* returns NAN when the reference would throw (negative BB discriminant, bad kind) */
+double m3o_test_stat_llh(int kind, double data, double mc, double w2);
+
+/* ---- reduced response functions: Splines/SplineStructs.h:265-308,673-734 ---- */
+/* TSpline3_red::FindX + Eval in double on one spline given {x,y,b,c,d}[n]. */
+int m3o_tspline3_find_x(const float* xpos, int npoints, double x);
+double m3o_tspline3_eval(const float* xpos, const float* yresp, const float* par /*[n][3]*/,
+                         int npoints, double var);
+/* TF1_red::Eval: Par[1] + Par[0]*var (SplineStructs.h:192-193) */
+double m3o_tf1_eval(const float* par, double var);
+
+/* ---- spline monolith: Splines/SplineBase.cpp:44-109, SplineMonolith.cpp:712-830 ---- */
+typedef struct m3o_monolith m3o_monolith;
+
+/*
+ * Arrays are BORROWED (caller keeps them alive) and are in the reference's flat
+ * layout produced by SMonolith::PrepareForGPU (SplineMonolith.cpp:53-250):
+ *   coeff_x[P*K], npts[P] (FastSplineInfo.nPts; <=0 => parameter has no knots),
+ *   coeff_many[4*total_knots] AoS {y,b,c,d}, nknots_arr[S] (start knot of spline),
+ *   param_no[S], coeff_tf1[2*T] {a,b}, param_no_tf1[T],
+ *   n_param_per_event[2*E] {count,start}, n_param_per_event_tf1[2*E].
+ * Offsets are `unsigned int`, exactly the reference's types (SplineCommon.h:42,
+ * SplineMonolith.h:114-127): one oracle object therefore holds < 2^32 coefficients,
+ * which is all the bounded parity / cpu_baseline samples need.
+ */
+m3o_monolith* m3o_monolith_create(uint64_t n_events, int n_params, int max_knots,
+                                  const float* coeff_x, const int16_t* npts,
+                                  uint64_t n_splines, const float* coeff_many,
+                                  const unsigned int* nknots_arr, const int16_t* param_no,
+                                  uint64_t n_tf1, const float* coeff_tf1, const int16_t* param_no_tf1,
+                                  const unsigned int* n_param_per_event,
+                                  const unsigned int* n_param_per_event_tf1);
+void m3o_monolith_destroy(m3o_monolith* m);
+/* SMonolith::setSplinePointers (SplineMonolith.h:44-46) */
+void m3o_monolith_set_spline_pointers(m3o_monolith* m, const double* const* ptrs);
+/* SMonolith::Evaluate CPU branch (SplineMonolith.cpp:712-723) */
+void m3o_monolith_evaluate(m3o_monolith* m);
+/* the three stages, exposed for stage-level parity */
+void m3o_monolith_find_spline_segment(m3o_monolith* m);
+void m3o_monolith_calc_spline_weights(m3o_monolith* m);
+void m3o_monolith_calc_total_event_weight(m3o_monolith* m);
+/* run CalcSplineWeights from externally supplied vals/segments (RunGPU_SplineMonolith inputs) */
+void m3o_monolith_set_vals_segments(m3o_monolith* m, const float* vals, const int16_t* segments);
+const float* m3o_monolith_total_weights(const m3o_monolith* m);  /* cpu_total_weights[E] */
+const float* m3o_monolith_spline_weights(const m3o_monolith* m); /* cpu_weights_spline_var[S] */
+const float* m3o_monolith_tf1_weights(const m3o_monolith* m);    /* cpu_weights_tf1_var[T] */
+const int16_t* m3o_monolith_segments(const m3o_monolith* m);     /* SplineSegments[P] */
+const float* m3o_monolith_param_values(const m3o_monolith* m);   /* ParamValues[P] */
+int16_t* m3o_monolith_curr_segment_state(m3o_monolith* m);       /* FastSplineInfo.CurrSegment[P] */
+
+/* ---- binning: Samples/SampleStructs.h:172-676, Samples/BinningHandler.cpp:257-355 ---- */
+typedef struct m3o_binning m3o_binning;
+m3o_binning* m3o_binning_create(void);
+void m3o_binning_destroy(m3o_binning* b);
+/* SampleBinningInfo::InitUniform; edges concatenated over dims; returns sample index or -1 */
+int m3o_binning_add_uniform(m3o_binning* b, int ndim, const int* n_edges, const double* edges);
+/* SampleBinningInfo::InitNonUniform; extents[nbins][ndim][2]; returns sample index or -1 */
+int m3o_binning_add_nonuniform(m3o_binning* b, int nbins, int ndim, const double* extents);
+int m3o_binning_n_samples(const m3o_binning* b);
+int m3o_binning_n_bins(const m3o_binning* b);                   /* GetNBins() */
+int m3o_binning_sample_n_bins(const m3o_binning* b, int sample);
+int m3o_binning_sample_start(const m3o_binning* b, int sample); /* GetSampleStartBin */
+int m3o_binning_sample_end(const m3o_binning* b, int sample);   /* GetSampleEndBin */
+int m3o_binning_n_dim(const m3o_binning* b, int sample);
+int m3o_binning_find_nominal_bin(const m3o_binning* b, int sample, int dim, double var);
+int m3o_binning_find_bin(const m3o_binning* b, int sample, int dim, double var, int nom_bin);
+int m3o_binning_find_global_bin(const m3o_binning* b, int sample, const double* kinvar,
+                                const int* nom_bin);
+
+/* ---- sample handler: Samples/SampleHandlerFD.cpp:316-463,568-594,1262-1300 ---- */
+typedef struct m3o_sample m3o_sample;
+/*
+ * Per event (all BORROWED except what is noted):
+ *   sample_id[E]        EventInfo.NominalSample
+ *   kin[E*kin_stride]   kinematic variables; KinVar pointers alias this storage
+ *   norm_off[E+1], norm_idx[]  -> norm_pointers = &par_base[norm_idx[..]]
+ *   osc_idx[E]          >=0: total_weight_pointers gets &osc_table[osc_idx]; <0: none
+ *                       (SampleHandlerFD.cpp:1108-1122: unity pointers are not pushed)
+ *   mono                spline handler or NULL; retPointer(e) is pushed AFTER the osc
+ *                       pointer (Initialise order, SampleHandlerFD.cpp:169-197)
+ */
+m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int32_t* sample_id,
+                              int kin_stride, const double* kin,
+                              const uint64_t* norm_off, const int16_t* norm_idx,
+                              const double* par_base,
+                              const int32_t* osc_idx, const float* osc_table,
+                              m3o_monolith* mono);
+void m3o_sample_destroy(m3o_sample* s);
+void m3o_sample_set_test_statistic(m3o_sample* s, int kind, int update_w2);
+void m3o_sample_add_data(m3o_sample* s, const double* data); /* AddData for all bins */
+void m3o_sample_reweight(m3o_sample* s);                     /* Reweight() */
+double m3o_sample_get_likelihood(const m3o_sample* s);
+double m3o_sample_get_sample_likelihood(const m3o_sample* s, int isample);
+const double* m3o_sample_mc(const m3o_sample* s);
+const double* m3o_sample_w2(const m3o_sample* s);
+const double* m3o_sample_data(const m3o_sample* s);
+/* per-event CalcWeightTotal and FindGlobalBin, for event-level parity */
+void m3o_sample_event_weights(const m3o_sample* s, float* out);
+void m3o_sample_event_bins(const m3o_sample* s, int32_t* out);
+/* phase timings of the last reweight (seconds): spline eval, fill */
+void m3o_sample_last_timing(const m3o_sample* s, double* t_spline, double* t_fill);
+
+/* 1 if built with -fopenmp -DMULTITHREAD (the timed baseline), 0 for the serial reference */
+int m3o_is_multithread(void);
+int m3o_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,245 @@
+"""ctypes binding of the CPU oracle (oracle/m3_oracle.h).  TEST INFRASTRUCTURE: imported by
+tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_libs = {}
+
+
+def load(variant="serial"):
+    """variant: 'serial' (bit-exact reference order) or 'omp' (timed baseline)"""
+    if variant in _libs:
+        return _libs[variant]
+    path = os.path.join(ROOT, "oracle", f"libm3oracle_{variant}.so")
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+    vp, u64, i32, dbl = C.c_void_p, C.c_uint64, C.c_int, C.c_double
+    lib.m3o_poisson_llh.argtypes = [dbl, dbl]; lib.m3o_poisson_llh.restype = dbl
+    lib.m3o_test_stat_llh.argtypes = [i32, dbl, dbl, dbl]; lib.m3o_test_stat_llh.restype = dbl
+    lib.m3o_tspline3_find_x.argtypes = [vp, i32, dbl]; lib.m3o_tspline3_find_x.restype = i32
+    lib.m3o_tspline3_eval.argtypes = [vp, vp, vp, i32, dbl]; lib.m3o_tspline3_eval.restype = dbl
+    lib.m3o_tf1_eval.argtypes = [vp, dbl]; lib.m3o_tf1_eval.restype = dbl
+    lib.m3o_monolith_create.argtypes = [u64, i32, i32, vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]
+    lib.m3o_monolith_create.restype = vp
+    for n in ("m3o_monolith_destroy", "m3o_monolith_evaluate", "m3o_monolith_find_spline_segment",
+              "m3o_monolith_calc_spline_weights", "m3o_monolith_calc_total_event_weight"):
+        getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = None
+    lib.m3o_monolith_set_spline_pointers.argtypes = [vp, vp]; lib.m3o_monolith_set_spline_pointers.restype = None
+    lib.m3o_monolith_set_vals_segments.argtypes = [vp, vp, vp]; lib.m3o_monolith_set_vals_segments.restype = None
+    for n in ("m3o_monolith_total_weights", "m3o_monolith_spline_weights", "m3o_monolith_tf1_weights",
+              "m3o_monolith_segments", "m3o_monolith_param_values", "m3o_monolith_curr_segment_state"):
+        getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = vp
+    lib.m3o_binning_create.argtypes = []; lib.m3o_binning_create.restype = vp
+    lib.m3o_binning_destroy.argtypes = [vp]; lib.m3o_binning_destroy.restype = None
+    lib.m3o_binning_add_uniform.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_add_uniform.restype = i32
+    lib.m3o_binning_add_nonuniform.argtypes = [vp, i32, i32, vp]; lib.m3o_binning_add_nonuniform.restype = i32
+    for n in ("m3o_binning_n_samples", "m3o_binning_n_bins"):
+        getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = i32
+    for n in ("m3o_binning_sample_n_bins", "m3o_binning_sample_start", "m3o_binning_sample_end", "m3o_binning_n_dim"):
+        getattr(lib, n).argtypes = [vp, i32]; getattr(lib, n).restype = i32
+    lib.m3o_binning_find_nominal_bin.argtypes = [vp, i32, i32, dbl]; lib.m3o_binning_find_nominal_bin.restype = i32
+    lib.m3o_binning_find_bin.argtypes = [vp, i32, i32, dbl, i32]; lib.m3o_binning_find_bin.restype = i32
+    lib.m3o_binning_find_global_bin.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_find_global_bin.restype = i32
+    lib.m3o_sample_create.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp, vp, vp, vp]; lib.m3o_sample_create.restype = vp
+    lib.m3o_sample_destroy.argtypes = [vp]; lib.m3o_sample_destroy.restype = None
+    lib.m3o_sample_set_test_statistic.argtypes = [vp, i32, i32]; lib.m3o_sample_set_test_statistic.restype = None
+    lib.m3o_sample_add_data.argtypes = [vp, vp]; lib.m3o_sample_add_data.restype = None
+    lib.m3o_sample_reweight.argtypes = [vp]; lib.m3o_sample_reweight.restype = None
+    lib.m3o_sample_get_likelihood.argtypes = [vp]; lib.m3o_sample_get_likelihood.restype = dbl
+    lib.m3o_sample_get_sample_likelihood.argtypes = [vp, i32]; lib.m3o_sample_get_sample_likelihood.restype = dbl
+    for n in ("m3o_sample_mc", "m3o_sample_w2", "m3o_sample_data"):
+        getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = vp
+    lib.m3o_sample_event_weights.argtypes = [vp, vp]; lib.m3o_sample_event_weights.restype = None
+    lib.m3o_sample_event_bins.argtypes = [vp, vp]; lib.m3o_sample_event_bins.restype = None
+    lib.m3o_sample_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl)]; lib.m3o_sample_last_timing.restype = None
+    lib.m3o_is_multithread.restype = i32
+    lib.m3o_max_threads.restype = i32
+    _libs[variant] = lib
+    return lib
+
+
+def _view(ptr, n, dtype):
+    if n == 0:
+        return np.empty(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class OracleMonolith:
+    """SMonolith CPU path on one reference-layout chunk (arrays are borrowed: kept alive here)."""
+
+    def __init__(self, lib, n_params, max_knots, coeff_x, npts, ch: dict):
+        self.lib = lib
+        self.P = n_params
+        self.keep = (coeff_x, npts, ch)
+        self.E, self.S, self.T = ch["n_events"], ch["n_splines"], ch["n_tf1"]
+        self.h = lib.m3o_monolith_create(
+            self.E, n_params, max_knots, coeff_x.ctypes.data, npts.ctypes.data, self.S,
+            ch["coeff_many"].ctypes.data, ch["nknots_arr"].ctypes.data, ch["param_no"].ctypes.data, self.T,
+            ch["coeff_tf1"].ctypes.data, ch["param_no_tf1"].ctypes.data, ch["npe"].ctypes.data, ch["npe_tf1"].ctypes.data)
+        self._ptrs = None
+
+    def set_spline_pointers(self, par: np.ndarray, index=None):
+        idx = np.arange(self.P) if index is None else np.asarray(index)
+        self._par = par
+        arr = (C.c_void_p * self.P)(*[par.ctypes.data + 8 * int(i) for i in idx])
+        self._ptrs = arr
+        self.lib.m3o_monolith_set_spline_pointers(self.h, arr)
+
+    def evaluate(self):
+        self.lib.m3o_monolith_evaluate(self.h)
+
+    def find_spline_segment(self):
+        self.lib.m3o_monolith_find_spline_segment(self.h)
+
+    def eval_from(self, vals, segs):
+        self.lib.m3o_monolith_set_vals_segments(self.h, vals.ctypes.data, segs.ctypes.data)
+        self.lib.m3o_monolith_calc_spline_weights(self.h)
+        self.lib.m3o_monolith_calc_total_event_weight(self.h)
+
+    @property
+    def total_weights(self):
+        return _view(self.lib.m3o_monolith_total_weights(self.h), self.E, np.float32)
+
+    @property
+    def spline_weights(self):
+        return _view(self.lib.m3o_monolith_spline_weights(self.h), self.S, np.float32)
+
+    @property
+    def tf1_weights(self):
+        return _view(self.lib.m3o_monolith_tf1_weights(self.h), self.T, np.float32)
+
+    @property
+    def segments(self):
+        return _view(self.lib.m3o_monolith_segments(self.h), self.P, np.int16)
+
+    @property
+    def param_values(self):
+        return _view(self.lib.m3o_monolith_param_values(self.h), self.P, np.float32)
+
+    def close(self):
+        if self.h:
+            self.lib.m3o_monolith_destroy(self.h)
+            self.h = None
+
+
+class OracleBinning:
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = lib.m3o_binning_create()
+
+    def add_uniform(self, edges_per_dim):
+        ne = np.array([len(e) for e in edges_per_dim], np.int32)
+        ed = np.concatenate([np.asarray(e, np.float64) for e in edges_per_dim])
+        r = self.lib.m3o_binning_add_uniform(self.h, len(edges_per_dim), ne.ctypes.data, ed.ctypes.data)
+        assert r >= 0
+        return r
+
+    def add_nonuniform(self, extents):
+        ex = np.ascontiguousarray(extents, np.float64)
+        r = self.lib.m3o_binning_add_nonuniform(self.h, ex.shape[0], ex.shape[1], ex.ctypes.data)
+        return r
+
+    def n_bins(self):
+        return self.lib.m3o_binning_n_bins(self.h)
+
+    def find_global_bin(self, sample, kin, nom):
+        k = np.ascontiguousarray(kin, np.float64)
+        n = np.ascontiguousarray(nom, np.int32)
+        return self.lib.m3o_binning_find_global_bin(self.h, sample, k.ctypes.data, n.ctypes.data)
+
+    def find_nominal_bin(self, sample, dim, var):
+        return self.lib.m3o_binning_find_nominal_bin(self.h, sample, dim, float(var))
+
+    def find_bin(self, sample, dim, var, nom):
+        return self.lib.m3o_binning_find_bin(self.h, sample, dim, float(var), int(nom))
+
+
+class OracleSample:
+    """SampleHandlerFD CPU path (Reweight / GetLikelihood) over borrowed arrays."""
+
+    def __init__(self, lib, binning: OracleBinning, sample_id, kin, norm_off, norm_idx, par, osc_idx, osc_table,
+                 mono: OracleMonolith | None):
+        self.lib = lib
+        kin = np.ascontiguousarray(kin, np.float64)
+        if kin.ndim == 1:
+            kin = kin.reshape(-1, 1)
+        self.E = kin.shape[0]
+        self.keep = (binning, sample_id, kin, norm_off, norm_idx, par, osc_idx, osc_table, mono)
+        self.nb = binning.n_bins()
+        self.h = lib.m3o_sample_create(
+            binning.h, self.E, sample_id.ctypes.data if sample_id is not None else None, kin.shape[1], kin.ctypes.data,
+            norm_off.ctypes.data if norm_off is not None else None,
+            norm_idx.ctypes.data if norm_idx is not None else None, par.ctypes.data,
+            osc_idx.ctypes.data if osc_idx is not None else None,
+            osc_table.ctypes.data if osc_table is not None else None, mono.h if mono is not None else None)
+
+    def set_test_statistic(self, kind, update_w2=False):
+        self.lib.m3o_sample_set_test_statistic(self.h, int(kind), int(update_w2))
+
+    def add_data(self, data):
+        d = np.ascontiguousarray(data, np.float64)
+        self.lib.m3o_sample_add_data(self.h, d.ctypes.data)
+
+    def reweight(self):
+        self.lib.m3o_sample_reweight(self.h)
+
+    def get_likelihood(self):
+        return self.lib.m3o_sample_get_likelihood(self.h)
+
+    def get_sample_likelihood(self, i):
+        return self.lib.m3o_sample_get_sample_likelihood(self.h, i)
+
+    @property
+    def mc(self):
+        return _view(self.lib.m3o_sample_mc(self.h), self.nb, np.float64).copy()
+
+    @property
+    def w2(self):
+        return _view(self.lib.m3o_sample_w2(self.h), self.nb, np.float64).copy()
+
+    def event_weights(self):
+        out = np.empty(self.E, np.float32)
+        self.lib.m3o_sample_event_weights(self.h, out.ctypes.data)
+        return out
+
+    def event_bins(self):
+        out = np.empty(self.E, np.int32)
+        self.lib.m3o_sample_event_bins(self.h, out.ctypes.data)
+        return out
+
+    def last_timing(self):
+        a, b = C.c_double(0), C.c_double(0)
+        self.lib.m3o_sample_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            self.lib.m3o_sample_destroy(self.h)
+            self.h = None
+
+
+def build_oracle_from_synth(spec, e0, e1, variant="serial"):
+    """Oracle objects over events [e0,e1) of a synthetic spec (one chunk).
+    Returns (mono, sample, par_vector, chunk, events)."""
+    from mach3_amd import synth
+
+    lib = load(variant)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, e0, e1)
+    ev = synth.events_chunk(spec, e0, e1)
+    par = synth.params(spec, 0)
+    mono = OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    mono.set_spline_pointers(par)
+    b = OracleBinning(lib)
+    edges = synth.bin_edges(spec)
+    for _ in range(spec.n_samples):
+        b.add_uniform([edges])
+    tbl = synth.osc_table(spec)
+    s = OracleSample(lib, b, ev["sample_id"], ev["erec"], ev["norm_off"], ev["norm_idx"], par, ev["osc_idx"], tbl, mono)
+    s.set_test_statistic(spec.test_statistic, False)
+    return mono, s, par, ch, ev

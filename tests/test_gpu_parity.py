@@ -1,0 +1,306 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Bars: per-event float weights and integer bins bit-exact; per-bin rates 1e-12
+relative (fp64 atomics reorder the sum); total LLH 1e-9 relative (north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from helpers import make_monolith, natural_cubic
+from mach3_amd import capi, synth
+from mach3_amd.engine import SMonolith, SampleHandlerFD, build_from_synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL_BIN = 1e-12
+RTOL_LLH = 1e-9
+
+
+def _llh_close(a, b, scale=1.0):
+    assert abs(a - b) <= RTOL_LLH * max(abs(a), abs(b), scale), (a, b)
+
+
+@pytest.fixture(scope="module")
+def dense_pair(gpu_engine):
+    """C2-shaped (dense, 7 knots, Poisson) at 3000 events, 40 parameters (tail loop: 40 % 8 == 0 is
+    avoided on purpose with 37)."""
+    spec = synth.CONFIGS["c2"].scaled(3000, n_params=37)
+    eng, mono, sh, par = build_from_synth(spec, engine=gpu_engine, chunk_events=2048)
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, spec.n_events)
+    yield spec, mono, sh, par, omono, osamp, opar, ev
+    osamp.close()
+    omono.close()
+
+
+def test_spline_eval_seam2_bit_exact(dense_pair):
+    """SMonolith::Evaluate + SynchroniseMemTransfer: cpu_total_weights bit-equal to the serial oracle."""
+    spec, mono, sh, par, omono, osamp, opar, ev = dense_pair
+    for lap in (0, 1, 2, 3):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        mono.Evaluate()
+        mono.SynchroniseMemTransfer()
+        omono.evaluate()
+        assert np.array_equal(mono.SplineSegments, omono.segments)
+        assert np.array_equal(mono.ParamValues.view(np.uint32), omono.param_values.view(np.uint32))
+        assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+
+
+def test_fused_step_matches_oracle(dense_pair):
+    spec, mono, sh, par, omono, osamp, opar, ev = dense_pair
+    info = sh.eng.info()
+    assert info.n_events == spec.n_events and info.n_splines == spec.n_events * spec.n_params
+    assert info.alg_bytes_fused == 16 * info.n_splines + 8 * info.n_events
+    sh.RecordEventWeights(True)
+    # Asimov data at nominal (ref: Fitters/MaCh3Factory.h:142-153); W2 frozen there
+    par[:] = synth.params(spec, 0)
+    opar[:] = par
+    sh.Reweight()
+    osamp.reweight()
+    mc, w2 = sh.GetMCArray(), sh.GetW2Array()
+    assert np.allclose(mc, osamp.mc, rtol=RTOL_BIN, atol=0)
+    assert np.allclose(w2, osamp.w2, rtol=RTOL_BIN, atol=0)
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2, 3, 4, 5):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        sh.Reweight()
+        llh = sh.GetLikelihood()
+        osamp.reweight()
+        # device-side FindSplineSegment state == oracle state
+        seg, val = sh.GetSegments(spec.n_params)
+        assert np.array_equal(seg, omono.segments)
+        assert np.array_equal(val.view(np.uint32), omono.param_values.view(np.uint32))
+        # per-event weights bit-exact (spline total weight and full CalcWeightTotal)
+        assert np.array_equal(sh.GetSplineWeights(0, spec.n_events).view(np.uint32), omono.total_weights.view(np.uint32))
+        assert np.array_equal(sh.GetEventWeights(0, spec.n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        assert np.array_equal(sh.GetW2Array(), w2)          # frozen (SampleHandlerFD.cpp:342)
+        assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+        assert llh > 0
+    sh.RecordEventWeights(False)
+    # Step() == Reweight()+GetLikelihood()
+    assert sh.Step() == pytest.approx(llh, rel=1e-12)
+
+
+def test_bin_indices_bit_exact(dense_pair):
+    spec, mono, sh, par, omono, osamp, opar, ev = dense_pair
+    assert np.array_equal(ev["bin_idx"], osamp.event_bins())
+
+
+@pytest.mark.parametrize("kind", [capi.kPoisson, capi.kBarlowBeeston, capi.kDembinskiAbdelmotteleb, capi.kPearson,
+                                  capi.kIceCube])
+def test_every_test_statistic(dense_pair, kind):
+    spec, mono, sh, par, omono, osamp, opar, ev = dense_pair
+    par[:] = synth.params(spec, 7)
+    opar[:] = par
+    sh.SetTestStatistic(kind)
+    osamp.set_test_statistic(kind)
+    sh.Reweight()
+    osamp.reweight()
+    got, exp = sh.GetLikelihood(), osamp.get_likelihood()
+    # IceCube runs in x87 long double + lgammal in the reference; the device evaluates it in
+    # fp64 (lgamma differences cancel to ~1e-9 absolute per bin)
+    tol = 1e-6 if kind == capi.kIceCube else RTOL_LLH
+    assert abs(got - exp) <= tol * max(abs(exp), 1.0), (kind, got, exp)
+    assert sh.GetSampleLikelihood(0) == pytest.approx(got, rel=1e-12)
+    sh.SetTestStatistic(spec.test_statistic)
+    osamp.set_test_statistic(spec.test_statistic)
+
+
+def test_low_mc_and_empty_bins(dense_pair):
+    """data in bins the MC never reaches, MC below _LOW_MC_BOUND_ (ref: SampleHandlerBase.cpp:17-87)"""
+    spec, mono, sh, par, omono, osamp, opar, ev = dense_pair
+    par[:] = synth.params(spec, 3)
+    opar[:] = par
+    sh.Reweight()
+    osamp.reweight()
+    data = osamp.mc.copy()
+    data[-5:] = [0.0, 3.0, 1e-6, 5e-6, 2.0]   # the last bins hold (almost) no MC
+    data[0] = 0.0
+    for kind in (capi.kPoisson, capi.kBarlowBeeston, capi.kPearson, capi.kDembinskiAbdelmotteleb):
+        sh.SetTestStatistic(kind)
+        osamp.set_test_statistic(kind)
+        sh.AddData(data)
+        osamp.add_data(data)
+        _llh_close(sh.GetLikelihood(), osamp.get_likelihood())
+    sh.SetTestStatistic(spec.test_statistic)
+    osamp.set_test_statistic(spec.test_statistic)
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+
+
+def test_exact_knot_hits_and_out_of_range(fresh_engine):
+    """Segment edge cases through the DEVICE-side FindSplineSegment: x <= x0, x >= x_{n-1} -> n-2,
+    x == knot with and without the previous-segment shortcut (ref: Splines/SplineBase.cpp:44-109)."""
+    gpu_engine = fresh_engine
+    X7 = np.arange(-3.0, 4.0)
+    rng = np.random.default_rng(11)
+    P, E = 3, 300
+    events = [[(p, "spl", natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))) for p in range(P)] for _ in range(E)]
+    cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P)}, events)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    par = np.zeros(P)
+    opar = np.zeros(P)
+    omono.set_spline_pointers(opar)
+    mono = SMonolith(gpu_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(gpu_engine, 1, np.array([0, 4], np.int32), par)
+    sh.SetupEvents(0, np.arange(E, dtype=np.int32) % 4, None, None, None)
+    sh.RecordEventWeights(True)
+    seq = [[-5, 9, 1.5], [-3, 3, 1.0], [0.5, -0.5, 1.0], [1.0, 2.0, -2.5], [1.0, 2.5, 1.0], [0, 0, 0],
+           [2.9999, -2.9999, 1e-30], [3.0000002, -3.0000002, -1e-30]]
+    for vals in seq:
+        par[:] = vals
+        opar[:] = vals
+        sh.Reweight()
+        sh.GetLikelihood()
+        omono.evaluate()
+        seg, val = sh.GetSegments(P)
+        assert np.array_equal(seg, omono.segments), vals
+        assert np.array_equal(sh.GetSplineWeights(0, E).view(np.uint32), omono.total_weights.view(np.uint32)), vals
+    omono.close()
+
+
+def test_fill_semantics_on_device(fresh_engine):
+    """w <= 0 dropped, bin -1 dropped, norm -> osc -> spline order, W2 frozen / UpdateW2
+    (ref: Samples/SampleHandlerFD.cpp:316-463, 568-594); multi-sample likelihoods."""
+    gpu_engine = fresh_engine
+    X7 = np.arange(-3.0, 4.0)
+    c = natural_cubic(X7, 1 + 0.1 * X7)
+    E = 600
+    events = [[(0, "spl", c)] for _ in range(E)]
+    cx, npts, ch = make_monolith(1, 7, {0: X7}, events)
+    rng = np.random.default_rng(3)
+    par = np.array([0.0, 2.0, -1.0, 0.5])
+    kin = rng.uniform(-0.5, 4.5, E)
+    sample_id = (rng.random(E) < 0.5).astype(np.int32)
+    nn = rng.integers(0, 3, E)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = rng.integers(1, 4, int(norm_off[-1])).astype(np.int16)
+    osc_idx = rng.integers(-1, 3, E).astype(np.int32)
+    osc = np.array([0.5, 0.25, 0.0], np.float32)     # 0.0: NC flavour-change events (M3::Zero)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, 1, 7, cx, npts, ch)
+    opar = par.copy()
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    edges = np.array([0.0, 1.0, 2.0, 4.0])
+    b.add_uniform([edges])
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc, omono)
+    bins = synth.find_global_bin_uniform_1d(edges, kin, sample_id, 3)
+    assert np.array_equal(bins, osamp.event_bins())
+    assert (bins == -1).any()
+
+    mono = SMonolith(gpu_engine, 1, 7, cx, npts, [ch])
+    mono.setSplinePointers(par, [0])
+    sh = SampleHandlerFD(gpu_engine, 2, np.array([0, 3, 6], np.int32), par, capi.kBarlowBeeston)
+    osamp.set_test_statistic(capi.kBarlowBeeston)
+    sh.SetupEvents(0, bins, osc_idx, norm_off, norm_idx)
+    sh.SetOscillationWeights(osc)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    ew = osamp.event_weights()
+    assert (ew < 0).any() and (ew == 0).any() and (ew > 0).any()
+    assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), ew.view(np.uint32))
+    assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN)
+    assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN)
+    data = np.round(osamp.mc * 1.1)
+    sh.AddData(data)
+    osamp.add_data(data)
+    w2_first = sh.GetW2Array()
+    par[:] = [0.7, 1.5, -0.5, 0.9]
+    opar[:] = par
+    sh.Reweight()
+    osamp.reweight()
+    assert np.array_equal(sh.GetW2Array(), w2_first)
+    _llh_close(sh.GetLikelihood(), osamp.get_likelihood())
+    for s in (0, 1):
+        _llh_close(sh.GetSampleLikelihood(s), osamp.get_sample_likelihood(s))
+    osamp.close()
+    omono.close()
+
+    # UpdateW2 = true: W2 follows every reweight
+    omono = ob.OracleMonolith(lib, 1, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc, omono)
+    osamp.set_test_statistic(capi.kBarlowBeeston, True)
+    sh2 = SampleHandlerFD(gpu_engine, 2, np.array([0, 3, 6], np.int32), par, capi.kBarlowBeeston, update_w2=True)
+    for vals in ([0.0, 2.0, -1.0, 0.5], [0.7, 1.5, 0.5, 0.9]):
+        par[:] = vals
+        opar[:] = vals
+        sh2.Reweight()
+        osamp.reweight()
+        assert np.allclose(sh2.GetW2Array(), osamp.w2, rtol=RTOL_BIN)
+    osamp.close()
+    omono.close()
+
+
+def test_mixed_uniform_tf1_and_short_splines(fresh_engine):
+    """TSpline3 parameters with 3/7/5 knots and TF1 parameters in one uniform event list; the
+    product order is splines (event order) then TF1s (ref: SplineMonolith.cpp:792-830)."""
+    gpu_engine = fresh_engine
+    xs = {0: np.array([-1.0, 0, 1]), 2: np.arange(-3.0, 4.0), 3: np.array([-2.0, -1, 0, 1, 2])}
+    rng = np.random.default_rng(1)
+    E, P = 777, 6
+    events = []
+    for _ in range(E):
+        ev = []
+        for p in range(P):
+            if p in xs:
+                ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))))
+            else:
+                ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
+        events.append(ev)
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    par = np.zeros(P + 2)
+    opar = par.copy()
+    # spline parameter i is driven by global entry i+2 (setSplinePointers with a non-trivial map)
+    idx = np.arange(P) + 2
+    omono.set_spline_pointers(opar, idx)
+    mono = SMonolith(gpu_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par, idx)
+    for k in range(6):
+        par[2:] = rng.uniform(-3.5, 3.5, P)
+        opar[:] = par
+        mono.Evaluate()
+        mono.SynchroniseMemTransfer()
+        omono.evaluate()
+        assert np.array_equal(mono.SplineSegments, omono.segments)
+        assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+    omono.close()
+
+
+def test_api_error_paths(fresh_engine):
+    gpu_engine = fresh_engine
+    eng = gpu_engine
+    spec = synth.CONFIGS["c2"].scaled(300, n_params=4)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, 300)
+    bad = dict(ch)
+    bad["param_no"] = ch["param_no"].copy()
+    bad["param_no"][3] = 77
+    eng.monolith_begin(4, 7, cx, npts)
+    with pytest.raises(capi.M3HipError) as ei:
+        eng.monolith_append(bad)
+    assert ei.value.code == -1 and "paramNo" in str(ei.value)
+    # a good upload still works afterwards
+    mono = SMonolith(eng, 4, 7, cx, npts, [ch])
+    par = synth.params(spec, 1)
+    mono.setSplinePointers(par)
+    mono.SplineSegments[:] = 0
+    mono.ParamValues[:] = 0
+    with pytest.raises(capi.M3HipError):
+        seg = np.full(4, 6, np.int16)     # segment beyond nPts-2
+        eng._chk(eng.lib.m3hip_eval_splines(eng.h, capi._ptr(mono.ParamValues, np.float32), capi._ptr(seg, np.int16), None))
+    sh = SampleHandlerFD(eng, 1, np.array([0, 10], np.int32), par)
+    with pytest.raises(capi.M3HipError):
+        sh.SetupEvents(0, np.full(300, 10, np.int32), None, None, None)   # bin index out of range
+    with pytest.raises(capi.M3HipError):
+        sh.AddData(np.zeros(9))
