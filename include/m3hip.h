@@ -212,6 +212,10 @@ int m3hip_timing_enable(m3hip_handle h, int enable);
 int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches);
 int m3hip_timing_reset(m3hip_handle h);
 
+/* Test hook: overwrite the device-side bin vectors (mc, w2) so that m3hip_get_likelihood can
+ * be checked on arbitrary (data, mc, w2) triples. */
+int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins);
+
 /* Host-only probe of the upload re-layout (no device needed): sizes[4] = {n_tiles,
  * spline store in float4, TF1 store in float2, slot-meta in int32}; with non-NULL output
  * buffers of those sizes it also fills them and tile_desc[n_tiles][8] = {spl_off, tf1_off,

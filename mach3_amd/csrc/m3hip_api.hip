@@ -810,6 +810,18 @@ int m3hip_comm_destroy(m3hip_handle h) {
   return M3HIP_OK;
 }
 
+/* ---------------------------------------------------------------- test hooks */
+
+int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->n_bins == 0 || n_bins != h->n_bins || !mc || !w2) return fail(h, M3HIP_EINVAL, "debug_set_bins: n_bins mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_hist, mc, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_hist + n_bins, w2, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+  return M3HIP_OK;
+}
+
 /* ---------------------------------------------------------------- host-only layout probe */
 
 int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_t n_events, const float* coeff_many,

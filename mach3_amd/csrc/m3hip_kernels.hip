@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
       // host already ran FindSplineSegment (RunGPU_SplineMonolith inputs, gpuSplineUtils.cu:444-465)
       xvar = a.vals_in[i];
       segment = a.seg_in[i];
+      if (nPoints > 0) a.curr_seg[i] = (int16_t)segment;  // keep FastSplineInfo.CurrSegment in step with the host's
     } else {
       xvar = float(a.params_dev[a.par_map[i]]);  // SplineBase.cpp:54 (double -> float)
       if (nPoints > 0) {                         // :60 parameters without knots are skipped
@@ -261,16 +262,26 @@ __device__ double d_test_stat_llh(int kind, double data, double mc, double w2) {
     }
     case 2: {  // kIceCube, :133-159.  The reference evaluates this in x87 long double with
                // lgammal; the device has no 80-bit type, so this is fp64 (tolerance in tests).
-      if (w2 == 0) return d_poisson_llh(data, mc);
-      const double b = mc / w2;
-      const double a = mc * b + 1;
-      const double stat = -1 * (a * log(b) + lgamma(data + a) - lgamma(data + 1) - ((data + a) * log1p(b)) - lgamma(a));
-      if (mc <= data) {
-        if (data <= low) return 0.;
-        const double poisson = d_poisson_llh(data, low);
-        if (stat > poisson) return poisson;
+      // Single-exit form on purpose: with early returns hipcc (ROCm 7.2, gfx950, -O1..-O3)
+      // returned the Poisson cap even when stat < cap; tests/test_gpu_parity.py pins this.
+      double r;
+      if (w2 == 0) {
+        r = d_poisson_llh(data, mc);
+      } else {
+        const double b = mc / w2;
+        const double a = mc * b + 1;
+        const double stat = -1 * (a * log(b) + lgamma(data + a) - lgamma(data + 1) - ((data + a) * log1p(b)) - lgamma(a));
+        r = stat;
+        if (mc <= data) {
+          if (data <= low) {
+            r = 0.;
+          } else {
+            const double poisson = d_poisson_llh(data, low);
+            if (stat > poisson) r = poisson;
+          }
+        }
       }
-      return stat;
+      return r;
     }
     case 3: {  // kPearson, :162-176
       if (data == 0) return mc / 2.;

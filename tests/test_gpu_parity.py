@@ -131,6 +131,43 @@ def test_low_mc_and_empty_bins(dense_pair):
     osamp.add_data(osamp.mc)
 
 
+@pytest.mark.parametrize("kind", [capi.kPoisson, capi.kBarlowBeeston, capi.kDembinskiAbdelmotteleb, capi.kPearson,
+                                  capi.kIceCube])
+def test_llh_kernel_on_a_grid_of_bins(fresh_engine, kind):
+    """Kernel (iii) bin by bin (one sample per bin) on a grid of (data, mc, w2) triples covering
+    every branch of GetTestStatLLH (ref: Samples/SampleHandlerBase.cpp:17-192): data == 0,
+    mc below / at / above _LOW_MC_BOUND_, data <=> mc, w2 == 0, tiny and large w2."""
+    eng = fresh_engine
+    lib = ob.load("serial")
+    vals_d = [0.0, 1e-7, 5e-6, 1e-5, 2e-5, 0.3, 1.0, 7.0, 38.875538093969226, 1234.0]
+    vals_m = [0.0, 1e-7, 5e-6, 1e-5, 2e-5, 0.31, 1.0, 6.5, 38.15916385687888, 1200.0]
+    vals_w = [0.0, 1e-12, 1e-3, 0.7, 29.382163026679336, 5e3]
+    grid = np.array([(d, m, w) for d in vals_d for m in vals_m for w in vals_w if not (m == 0.0 and w > 0)])
+    if kind == capi.kIceCube:
+        # fp64 on the device vs x87 long double + lgammal in the reference: lgamma(data+a) - lgamma(a)
+        # cancels catastrophically once a = mc^2/w2 + 1 is huge (both sides lose digits there, the
+        # reference's own answer included), so the grid is kept to a <= 1e7 (MC stat error >= 3e-4).
+        grid = grid[(grid[:, 2] == 0) | (grid[:, 1] ** 2 / np.maximum(grid[:, 2], 1e-300) <= 1e7)]
+    nb = len(grid)
+    spec = synth.CONFIGS["c2"].scaled(256, n_params=2)
+    eng, mono, sh0, par = build_from_synth(spec, engine=eng)
+    sh = SampleHandlerFD(eng, nb, np.arange(nb + 1, dtype=np.int32), par, kind)
+    sh.AddData(np.ascontiguousarray(grid[:, 0]))
+    mc, w2 = np.ascontiguousarray(grid[:, 1]), np.ascontiguousarray(grid[:, 2])
+    eng._chk(eng.lib.m3hip_debug_set_bins(eng.h, capi._ptr(mc, np.float64), capi._ptr(w2, np.float64), nb))
+    total = sh.GetLikelihood()
+    per = sh._per_sample.copy()
+    exp = np.array([lib.m3o_test_stat_llh(kind, *g) for g in grid])
+    both_nan = np.isnan(per) & np.isnan(exp)
+    tol = 1e-7 if kind == capi.kIceCube else 1e-12
+    ok = both_nan | (np.abs(per - exp) <= tol * np.maximum(np.abs(exp), 1.0))
+    bad = np.nonzero(~ok)[0]
+    assert len(bad) == 0, [(grid[i], per[i], exp[i]) for i in bad[:5]]
+    fin = ~both_nan
+    if fin.all():
+        assert total == pytest.approx(exp.sum(), rel=1e-6 if kind == capi.kIceCube else 1e-12)
+
+
 def test_exact_knot_hits_and_out_of_range(fresh_engine):
     """Segment edge cases through the DEVICE-side FindSplineSegment: x <= x0, x >= x_{n-1} -> n-2,
     x == knot with and without the previous-segment shortcut (ref: Splines/SplineBase.cpp:44-109)."""
