@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# host thread pools sized to one GPU's CPU share (the reference recommends 8, allows 16 threads:
+# Manager/Monitor.cpp:122-138); must be set before any OpenMP runtime initialises
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+os.environ.setdefault("OMP_PROC_BIND", "close")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,11 +50,9 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=100_000):
     from mach3_amd import synth
 
     n = min(sample_events, spec.n_events)
-    threads = min(os.cpu_count() or 1, 16)  # the reference caps at 16 threads (Manager/Monitor.cpp:122-138)
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp")
     lib = ob.load("omp")
+    lib.m3o_set_num_threads(min(os.cpu_count() or 1, 16))  # the reference caps at 16 (Manager/Monitor.cpp:122-138)
+    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp")
     threads = lib.m3o_max_threads()
     samp.reweight()
     samp.add_data(samp.mc)

@@ -216,6 +216,10 @@ int m3hip_timing_reset(m3hip_handle h);
  * be checked on arbitrary (data, mc, w2) triples. */
 int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins);
 
+/* Host-side seconds spent in the phases of the last m3hip_reweight / m3hip_get_likelihood:
+ * {stage params, launch prep, launch reweight(+all-reduce), launch llh, wait, collect}. */
+int m3hip_debug_host_times(m3hip_handle h, double* out6);
+
 /* Host-only probe of the upload re-layout (no device needed): sizes[4] = {n_tiles,
  * spline store in float4, TF1 store in float2, slot-meta in int32}; with non-NULL output
  * buffers of those sizes it also fills them and tile_desc[n_tiles][8] = {spl_off, tf1_off,

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -122,9 +123,14 @@ struct m3hip_ctx {
   int pending = -1;
   double acc_ms[2] = {0, 0};
   uint64_t cnt[2] = {0, 0};
+  double host_t[6] = {0, 0, 0, 0, 0, 0};  // host-side seconds of the last step's phases (debug)
 };
 
 namespace {
+
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int fail(m3hip_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -150,6 +156,19 @@ int dev_alloc(m3hip_handle h, T** p, size_t n) {
 
 void dev_free(void* p) {
   if (p) (void)hipFree(p);
+}
+
+// Low-latency wait for the stream to drain.  hipStreamSynchronize can fall into a timed sleep
+// (observed: ~1 ms wake-up granularity once hipEvents are in flight on the stream), which is
+// several step times at this path's ~0.4 ms/step; polling hipStreamQuery keeps the wait at
+// the kernel's own duration.  After 5 s of polling it degrades to the blocking call.
+hipError_t wait_stream(hipStream_t s) {
+  const double t0 = now_s();
+  for (;;) {
+    hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    if (now_s() - t0 > 5.0) return hipStreamSynchronize(s);
+  }
 }
 
 void collect_timing(m3hip_handle h) {
@@ -502,7 +521,7 @@ int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment
 int m3hip_sync(m3hip_handle h) {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h->stream));
   collect_timing(h);
   return M3HIP_OK;
 }
@@ -636,6 +655,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "reweight before set_binning");
   if (!params || n_par <= 0) return fail(h, M3HIP_EINVAL, "reweight: empty parameter vector");
   if (!h->parmap_set && n_par < h->P) return fail(h, M3HIP_EINVAL, "reweight: parameter vector shorter than the spline parameters");
+  const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_param_capacity(h, n_par);
   if (rc) return rc;
@@ -664,9 +684,11 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   p.n_bins = h->n_bins;
   p.reset_hist = 1;
   p.reset_w2 = h->first_w2 ? 1 : 0;
+  const double t_b = now_s();
   launch_prep(p, h->stream);
   HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
   h->ring_used[slot] = true;
+  const double t_c = now_s();
 
   ReweightArgs a = make_rw_args(h);
   int mode = kModeFill;
@@ -690,6 +712,10 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
   }
   if (!h->update_w2) h->first_w2 = false;  // SampleHandlerFD.cpp:342
+  const double t_d = now_s();
+  h->host_t[0] = t_b - t_a;
+  h->host_t[1] = t_c - t_b;
+  h->host_t[2] = t_d - t_c;
   return M3HIP_OK;
 }
 
@@ -705,10 +731,16 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.sample_off = h->d_sample_off;
   l.kind = h->teststat;
   l.out = h->d_out;
+  const double t_a = now_s();
   launch_llh(l, h->stream);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const double t_b = now_s();
+  HIPCHK(h, wait_stream(h->stream));
+  const double t_c = now_s();
   collect_timing(h);
+  h->host_t[3] = t_b - t_a;
+  h->host_t[4] = t_c - t_b;
+  h->host_t[5] = now_s() - t_c;
   if (llh_total) *llh_total = h->h_out[0];
   if (per_sample)
     for (int s = 0; s < h->n_samples; ++s) per_sample[s] = h->h_out[1 + s];
@@ -811,6 +843,12 @@ int m3hip_comm_destroy(m3hip_handle h) {
 }
 
 /* ---------------------------------------------------------------- test hooks */
+
+int m3hip_debug_host_times(m3hip_handle h, double* out6) {
+  if (!h || !out6) return M3HIP_EINVAL;
+  for (int i = 0; i < 6; ++i) out6[i] = h->host_t[i];
+  return M3HIP_OK;
+}
 
 int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins) {
   if (!h) return M3HIP_EINVAL;

@@ -13,7 +13,7 @@ template <class F>
 void parallel_for(uint64_t n, F&& body) {
   unsigned nt = std::thread::hardware_concurrency();
   if (nt == 0) nt = 4;
-  if (nt > 32) nt = 32;
+  if (nt > 16) nt = 16;  // one GPU's share of the host
   if (n < 2 || nt == 1) {
     for (uint64_t i = 0; i < n; ++i) body(i);
     return;

@@ -832,6 +832,13 @@ int m3o_is_multithread(void) {
   return 0;
 #endif
 }
+void m3o_set_num_threads(int n) {
+#ifdef MULTITHREAD
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int m3o_max_threads(void) {
 #ifdef MULTITHREAD
   return omp_get_max_threads();

@@ -147,6 +147,7 @@ void m3o_sample_last_timing(const m3o_sample* s, double* t_spline, double* t_fil
 /* 1 if built with -fopenmp -DMULTITHREAD (the timed baseline), 0 for the serial reference */
 int m3o_is_multithread(void);
 int m3o_max_threads(void);
+void m3o_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ def load(variant="serial"):
     lib.m3o_sample_last_timing.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl)]; lib.m3o_sample_last_timing.restype = None
     lib.m3o_is_multithread.restype = i32
     lib.m3o_max_threads.restype = i32
+    lib.m3o_set_num_threads.argtypes = [i32]; lib.m3o_set_num_threads.restype = None
     _libs[variant] = lib
     return lib
 
