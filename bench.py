@@ -42,6 +42,23 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(config_name, per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_<config>_pmc_*.json: FETCH_SIZE and WRITE_SIZE collected in separate runs and
+    corrected as MI355X_MICROARCH.md prescribes).  None when no profile matches this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config_name}_pmc_*.json"))):
+        try:
+            d = json.load(open(f))
+            for k, v in d["kernels"].items():
+                if "k_reweight" in k and "hbm_bytes_per_launch" in v and d.get("events_per_gpu", 1_000_000) == per_gpu:
+                    best = {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(spec, budget_s=12.0, sample_events=100_000):
     """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events`
     events of the same workload; steps/s scaled to the full event count."""
@@ -172,6 +189,7 @@ def main():
     eng.timing_enable(False)
 
     if rank == 0:
+        tr = pmc_traffic(args.config, per_gpu)
         out = {
             "metric": "LLH evaluations/sec (MCMC steps/sec)",
             "value": n_gpus * args.steps / el,
@@ -203,7 +221,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
-                "traffic": None,
+                "traffic": tr["bytes"] if tr else None,
+                "traffic_source": tr["source"] if tr else None,
                 "alg_bytes_per_launch": int(info.alg_bytes_fused),
                 "avg_kernel_ms": k_ms,
                 "launches_timed": int(k_n),
