@@ -216,6 +216,14 @@ int m3hip_timing_reset(m3hip_handle h);
  * be checked on arbitrary (data, mc, w2) triples. */
 int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins);
 
+/* Tuning knobs of the reweight kernel: loads in flight per lane (8 / 16), non-temporal
+ * coefficient loads (0 / 1), dynamic-LDS pad in bytes (caps workgroups per CU; 0 = none). */
+int m3hip_debug_set_knobs(m3hip_handle h, int unroll, int nt, int lds_pad);
+
+/* Number of replicas of the bin vector the reweight kernel spreads its flushes over
+ * (default 32; 1 = every workgroup adds into the same addresses).  Before m3hip_set_binning. */
+int m3hip_debug_set_hist_replicas(m3hip_handle h, int n);
+
 /* Host-side seconds spent in the phases of the last m3hip_reweight / m3hip_get_likelihood:
  * {stage params, launch prep, launch reweight(+all-reduce), launch llh, wait, collect}. */
 int m3hip_debug_host_times(m3hip_handle h, double* out6);

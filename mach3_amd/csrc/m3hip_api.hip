@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,7 @@ using namespace m3hip;
 namespace {
 
 constexpr int kRing = 4;  // parameter staging slots in flight
+constexpr int kInlineResolveMax = 8192;  // unique slots resolved inside k_prep; beyond that k_resolve runs
 
 struct m3hip_unique_id_t {  // same size/layout as ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
   char internal[M3HIP_UNIQUE_ID_BYTES];
@@ -26,7 +28,6 @@ struct m3hip_unique_id_t {  // same size/layout as ncclUniqueId (rccl.h: NCCL_UN
 struct Chunk {
   void* d_spl = nullptr;
   void* d_tf1 = nullptr;
-  int32_t* d_meta = nullptr;
 };
 
 // RCCL is loaded on demand so that single-GPU users never touch it.
@@ -72,6 +73,14 @@ struct m3hip_ctx {
   std::vector<Chunk> chunks;
   std::vector<TileDev> h_tiles;
   TileDev* d_tiles = nullptr;
+  // unique slot lists (flattened) and their per-step resolved form
+  std::map<std::vector<int32_t>, uint32_t> list_index;
+  std::vector<int32_t> u_param, u_plane0;
+  std::vector<uint32_t> tile_res_off;
+  int32_t* d_u_param = nullptr;
+  int32_t* d_u_plane0 = nullptr;
+  RSlot* d_resolved = nullptr;
+  int32_t n_res = 0;
 
   // per-step parameter state
   PTab* d_ptab = nullptr;
@@ -106,7 +115,8 @@ struct m3hip_ctx {
   int n_bins = 0, n_samples = 0;
   int32_t* d_sample_off = nullptr;
   double* d_data = nullptr;
-  double* d_hist = nullptr;
+  double* d_hist = nullptr;  // [2][hist_rep][n_bins]
+  int hist_rep = 32;
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
   double* h_out = nullptr;  // pinned, device-mapped: [1 + n_samples]
@@ -123,6 +133,7 @@ struct m3hip_ctx {
   int pending = -1;
   double acc_ms[2] = {0, 0};
   uint64_t cnt[2] = {0, 0};
+  ReweightKnobs knobs;
   double host_t[6] = {0, 0, 0, 0, 0, 0};  // host-side seconds of the last step's phases (debug)
 };
 
@@ -202,11 +213,15 @@ void free_monolith(m3hip_handle h) {
   for (auto& c : h->chunks) {
     dev_free(c.d_spl);
     dev_free(c.d_tf1);
-    dev_free(c.d_meta);
   }
   h->chunks.clear();
   h->h_tiles.clear();
   dev_free(h->d_tiles); h->d_tiles = nullptr;
+  dev_free(h->d_u_param); h->d_u_param = nullptr;
+  dev_free(h->d_u_plane0); h->d_u_plane0 = nullptr;
+  dev_free(h->d_resolved); h->d_resolved = nullptr;
+  h->list_index.clear(); h->u_param.clear(); h->u_plane0.clear(); h->tile_res_off.clear();
+  h->n_res = 0;
   dev_free(h->d_coeff_x); h->d_coeff_x = nullptr;
   dev_free(h->d_npts); h->d_npts = nullptr;
   dev_free(h->d_ptab); h->d_ptab = nullptr;
@@ -244,6 +259,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.params = h->d_params;
   a.osc_table = h->d_osc_table;
   a.hist = h->d_hist;
+  a.hist_rep = h->hist_rep;
   a.e_pad = h->E_pad;
   a.n_norm_slots = h->M;
   a.n_bins = h->n_bins;
@@ -403,19 +419,18 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   HIPCHK(h, hipHostMalloc((void**)&s_tf1, b_tf1 ? b_tf1 : 16, hipHostMallocDefault));
   HIPCHK(h, hipHostMalloc((void**)&s_meta, b_meta ? b_meta : 16, hipHostMallocDefault));
   fill_chunk(h->P, h->h_npts.data(), in, plan, s_spl, s_tf1, s_meta);
+  const std::vector<int32_t> h_meta(s_meta, s_meta + plan.meta_int32);
 
   Chunk c;
   hipError_t e = hipMalloc(&c.d_spl, b_spl ? b_spl : 16);
   if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 ? b_tf1 : 16);
-  if (e == hipSuccess) e = hipMalloc((void**)&c.d_meta, b_meta ? b_meta : 16);
   if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
-  if (e == hipSuccess && b_meta) e = hipMemcpy(c.d_meta, s_meta, b_meta, hipMemcpyHostToDevice);
   (void)hipHostFree(s_spl);
   (void)hipHostFree(s_tf1);
   (void)hipHostFree(s_meta);
   if (e != hipSuccess) {
-    dev_free(c.d_spl); dev_free(c.d_tf1); dev_free(c.d_meta);
+    dev_free(c.d_spl); dev_free(c.d_tf1);
     return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("monolith_append upload: ") + hipGetErrorString(e));
   }
   h->chunks.push_back(c);
@@ -423,12 +438,32 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     TileDev td;
     td.spl = reinterpret_cast<const float4*>(c.d_spl) + th.spl_off;
     td.tf1 = reinterpret_cast<const float2*>(c.d_tf1) + th.tf1_off;
-    td.meta = c.d_meta + th.meta_off;
+    td.res = nullptr;  // set in monolith_end once the unique slot lists are known
     td.n_spl_slots = th.n_spl_slots;
     td.n_tf1_slots = th.n_tf1_slots;
     td.n_events = th.n_events;
-    td.first_event = 0;
+    td.pad_ = 0;
     h->h_tiles.push_back(td);
+    // unique ordered parameter lists: tiles that share one also share its resolved slots
+    std::vector<int32_t> key(h_meta.begin() + th.meta_off, h_meta.begin() + th.meta_off + 2 * th.n_spl_slots + th.n_tf1_slots);
+    key.push_back(int32_t(th.n_spl_slots));
+    auto it = h->list_index.find(key);
+    uint32_t off;
+    if (it == h->list_index.end()) {
+      off = uint32_t(h->u_param.size());
+      for (uint32_t j = 0; j < th.n_spl_slots; ++j) {
+        h->u_param.push_back(key[2 * j]);
+        h->u_plane0.push_back(key[2 * j + 1]);
+      }
+      for (uint32_t j = 0; j < th.n_tf1_slots; ++j) {
+        h->u_param.push_back(key[2 * th.n_spl_slots + j]);
+        h->u_plane0.push_back(-1);
+      }
+      h->list_index.emplace(std::move(key), off);
+    } else {
+      off = it->second;
+    }
+    h->tile_res_off.push_back(off);
   }
   h->n_uniform += plan.n_uniform;
   h->n_brick += plan.n_brick;
@@ -447,6 +482,17 @@ int m3hip_monolith_end(m3hip_handle h) {
   h->E_pad = ((n_tiles * M3_TE + M3_GROUP - 1) / M3_GROUP) * M3_GROUP;
   if (h->E_pad == 0) h->E_pad = M3_GROUP;
   int rc;
+  h->n_res = int32_t(h->u_param.size());
+  if ((rc = dev_alloc(h, &h->d_u_param, size_t(h->n_res)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_u_plane0, size_t(h->n_res)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_resolved, size_t(h->n_res)))) return rc;
+  if (h->n_res) {
+    HIPCHK(h, hipMemcpy(h->d_u_param, h->u_param.data(), sizeof(int32_t) * h->n_res, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_u_plane0, h->u_plane0.data(), sizeof(int32_t) * h->n_res, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(h->d_resolved, 0, sizeof(RSlot) * h->n_res));
+  }
+  for (uint64_t t = 0; t < n_tiles; ++t) h->h_tiles[t].res = h->d_resolved + h->tile_res_off[t];
+  h->list_index.clear();
   if ((rc = dev_alloc(h, &h->d_tiles, size_t(n_tiles)))) return rc;
   if (n_tiles) HIPCHK(h, hipMemcpy(h->d_tiles, h->h_tiles.data(), sizeof(TileDev) * n_tiles, hipMemcpyHostToDevice));
   if ((rc = dev_alloc(h, &h->d_spline_w, size_t(h->E_pad)))) return rc;
@@ -504,10 +550,15 @@ int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment
   p.seg_out = h->d_seg;
   p.vals_in = h->d_vals_in;
   p.seg_in = h->d_segs_in;
+  p.u_param = h->d_u_param;
+  p.u_plane0 = h->d_u_plane0;
+  p.resolved = h->d_resolved;
+  p.n_res = h->n_res <= kInlineResolveMax ? h->n_res : 0;
   launch_prep(p, h->stream);
+  if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
   ReweightArgs a = make_rw_args(h);
   if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), kModeEval, h->stream);
+  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), kModeEval, h->knobs, h->stream);
   if (h->timing) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = 1;
@@ -555,10 +606,10 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   int rc;
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2))) return rc;
+  if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2 * h->hist_rep))) return rc;
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
-  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2));
+  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
   HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (1 + n_samples), hipHostMallocMapped));
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_out, h->h_out, 0));
   h->n_bins = nb;
@@ -681,11 +732,17 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   p.pval = h->d_pval;
   p.seg_out = h->d_seg;
   p.hist = h->d_hist;
+  p.hist_rep = h->hist_rep;
   p.n_bins = h->n_bins;
   p.reset_hist = 1;
   p.reset_w2 = h->first_w2 ? 1 : 0;
+  p.u_param = h->d_u_param;
+  p.u_plane0 = h->d_u_plane0;
+  p.resolved = h->d_resolved;
+  p.n_res = h->n_res <= kInlineResolveMax ? h->n_res : 0;
   const double t_b = now_s();
   launch_prep(p, h->stream);
+  if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
   HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
   h->ring_used[slot] = true;
   const double t_c = now_s();
@@ -700,14 +757,14 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     mode |= kModeEventW | kModeEval;
   }
   if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->stream);
+  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->knobs, h->stream);
   if (h->timing) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = 0;
   }
   HIPCHK(h, hipGetLastError());
   if (h->comm && h->n_ranks > 1) {
-    const size_t count = size_t(h->n_bins) * (h->first_w2 ? 2 : 1);
+    const size_t count = size_t(h->n_bins) * h->hist_rep * (h->first_w2 ? 2 : 1);
     int r = g_rccl.AllReduce(h->d_hist, h->d_hist, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
   }
@@ -726,6 +783,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   LlhArgs l;
   l.data = h->d_data;
   l.hist = h->d_hist;
+  l.hist_rep = h->hist_rep;
   l.n_bins = h->n_bins;
   l.n_samples = h->n_samples;
   l.sample_off = h->d_sample_off;
@@ -759,8 +817,18 @@ int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
-  if (mc) HIPCHK(h, hipMemcpy(mc, h->d_hist, sizeof(double) * n_bins, hipMemcpyDeviceToHost));
-  if (w2) HIPCHK(h, hipMemcpy(w2, h->d_hist + n_bins, sizeof(double) * n_bins, hipMemcpyDeviceToHost));
+  // replicas are folded in replica order, exactly as k_llh does
+  std::vector<double> tmp(size_t(n_bins) * 2 * h->hist_rep);
+  HIPCHK(h, hipMemcpy(tmp.data(), h->d_hist, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n_bins; ++i) {
+    double m = tmp[i], v = tmp[size_t(h->hist_rep) * n_bins + i];
+    for (int r = 1; r < h->hist_rep; ++r) {
+      m += tmp[size_t(r) * n_bins + i];
+      v += tmp[size_t(h->hist_rep + r) * n_bins + i];
+    }
+    if (mc) mc[i] = m;
+    if (w2) w2[i] = v;
+  }
   return M3HIP_OK;
 }
 
@@ -844,6 +912,21 @@ int m3hip_comm_destroy(m3hip_handle h) {
 
 /* ---------------------------------------------------------------- test hooks */
 
+int m3hip_debug_set_knobs(m3hip_handle h, int unroll, int nt, int lds_pad) {
+  if (!h) return M3HIP_EINVAL;
+  h->knobs.unroll = unroll;
+  h->knobs.nt = nt;
+  h->knobs.lds_pad = lds_pad;
+  return M3HIP_OK;
+}
+
+int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) {
+  if (!h || n < 1 || n > 64) return M3HIP_EINVAL;
+  if (h->n_bins != 0) return fail(h, M3HIP_ESTATE, "set_hist_replicas must precede set_binning");
+  h->hist_rep = n;
+  return M3HIP_OK;
+}
+
 int m3hip_debug_host_times(m3hip_handle h, double* out6) {
   if (!h || !out6) return M3HIP_EINVAL;
   for (int i = 0; i < 6; ++i) out6[i] = h->host_t[i];
@@ -855,8 +938,9 @@ int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int
   if (h->n_bins == 0 || n_bins != h->n_bins || !mc || !w2) return fail(h, M3HIP_EINVAL, "debug_set_bins: n_bins mismatch");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * n_bins * 2 * h->hist_rep));
   HIPCHK(h, hipMemcpy(h->d_hist, mc, sizeof(double) * n_bins, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_hist + n_bins, w2, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_hist + size_t(h->hist_rep) * n_bins, w2, sizeof(double) * n_bins, hipMemcpyHostToDevice));
   return M3HIP_OK;
 }
 

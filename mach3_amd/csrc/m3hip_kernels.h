@@ -19,14 +19,25 @@ struct PTab {
 };
 
 // Device-side descriptor of one uniform tile: absolute pointers into the chunk stores.
+// Per-step resolved slot: what kernel (i) needs for one slot of a slot list, with the
+// parameter indirection already applied (k_prep / k_resolve write these every step).
+//   TSpline3 slot: plane = plane0[j] + seg[param], f = dx[param]
+//   TF1 slot:      plane unused,                  f = ParamValues[param]
+struct RSlot {
+  int32_t plane;
+  float f;
+};
+
 struct TileDev {
-  const float4* spl;    // [(plane0[j] + k) * M3_TE + lane]
-  const float2* tf1;    // [j * M3_TE + lane]
-  const int32_t* meta;  // [2*J_s] {param, plane0}, then [J_t] {param}
+  const float4* spl;   // [(plane0[j] + k) * M3_TE + lane]
+  const float2* tf1;   // [j * M3_TE + lane]
+  const RSlot* res;    // resolved slot list of this tile: [J_s] spline slots, then [J_t] TF1 slots.
+                       // Tiles with identical ordered parameter lists share one list, so in
+                       // structured samples it stays resident in the scalar cache / L2.
   uint32_t n_spl_slots;
   uint32_t n_tf1_slots;
   uint32_t n_events;
-  uint32_t first_event;  // low 32 bits unused here; events are addressed by tile index * M3_TE
+  uint32_t pad_;
 };
 
 struct ReweightArgs {
@@ -41,7 +52,8 @@ struct ReweightArgs {
   const int16_t* nidx;       // [M][E_pad] ELL of global parameter indices, padded with n_par (-> 1.0)
   const double* params;      // [n_par + 1], last entry 1.0
   const float* osc_table;
-  double* hist;              // [2 * n_bins]: mc then w2
+  double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
+  int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
   uint64_t e_pad;
   uint32_t n_norm_slots;     // M
   int32_t n_bins;
@@ -68,8 +80,14 @@ struct PrepArgs {
   // host-supplied vals/segments path (RunGPU_SplineMonolith inputs); params_src unused then
   const float* vals_in;
   const int16_t* seg_in;
+  // slot-list resolution (all unique lists, flattened): see RSlot
+  const int32_t* u_param;   // [n_res] parameter of the slot
+  const int32_t* u_plane0;  // [n_res] first plane of the slot, -1 for a TF1 slot
+  RSlot* resolved;          // [n_res]
+  int32_t n_res;            // 0: resolution is done by k_resolve instead
   // histogram reset (ResetHistograms)
   double* hist;
+  int32_t hist_rep;
   int32_t n_bins;
   int32_t reset_w2;
   int32_t reset_hist;
@@ -77,7 +95,8 @@ struct PrepArgs {
 
 struct LlhArgs {
   const double* data;
-  const double* hist;  // mc[n_bins], w2[n_bins]
+  const double* hist;  // [2][hist_rep][n_bins]
+  int32_t hist_rep;
   int32_t n_bins;
   int32_t n_samples;
   const int32_t* sample_off;  // [n_samples + 1]
@@ -86,7 +105,15 @@ struct LlhArgs {
 };
 
 void launch_prep(const PrepArgs& a, hipStream_t s);
-void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s);
+void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s);
+// run-time tuning knobs of the reweight kernel (m3hip_debug_set_knobs)
+struct ReweightKnobs {
+  int unroll = 8;   // loads kept in flight per lane: 8 or 16
+  int nt = 1;       // 1: non-temporal coefficient loads (+5% on C2: planes are read once per launch)
+  int lds_pad = 0;  // > 0: dynamic LDS bytes per workgroup, to cap workgroups per CU
+};
+
+void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_llh(const LlhArgs& a, hipStream_t s);
 
 }  // namespace m3hip

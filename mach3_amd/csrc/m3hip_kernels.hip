@@ -23,9 +23,10 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   const int tid = threadIdx.x;
   // ResetHistograms: mc always, w2 only while FirstTimeW2 (SampleHandlerFD.cpp:454-463)
   if (a.reset_hist) {
-    for (int b = tid; b < a.n_bins; b += 256) {
+    const int n = a.hist_rep * a.n_bins;
+    for (int b = tid; b < n; b += 256) {
       a.hist[b] = 0.0;
-      if (a.reset_w2) a.hist[a.n_bins + b] = 0.0;
+      if (a.reset_w2) a.hist[n + b] = 0.0;
     }
   }
   if (a.params_src) {
@@ -76,9 +77,47 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
     t.dx = (nPoints > 0) ? (xvar - xArray[segment]) : 0.f;
     a.ptab[i] = t;
   }
+  if (a.n_res > 0) {  // few unique slot lists: resolve them here and save a launch
+    __syncthreads();
+    for (int i = tid; i < a.n_res; i += 256) {
+      const int p = a.u_param[i];
+      const int pl0 = a.u_plane0[i];
+      RSlot r;
+      if (pl0 >= 0) {
+        const PTab t = a.ptab[p];
+        r.plane = pl0 + t.seg;
+        r.f = t.dx;
+      } else {
+        r.plane = 0;
+        r.f = a.pval[p];
+      }
+      a.resolved[i] = r;
+    }
+  }
+}
+
+// many unique slot lists (ragged samples): one thread per slot, after k_prep
+__global__ __launch_bounds__(256) void k_resolve(PrepArgs a, int32_t n_res) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_res) return;
+  const int p = a.u_param[i];
+  const int pl0 = a.u_plane0[i];
+  RSlot r;
+  if (pl0 >= 0) {
+    const PTab t = a.ptab[p];
+    r.plane = pl0 + t.seg;
+    r.f = t.dx;
+  } else {
+    r.plane = 0;
+    r.f = a.pval[p];
+  }
+  a.resolved[i] = r;
 }
 
 void launch_prep(const PrepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, a); }
+void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s) {
+  if (n_res > 0) hipLaunchKernelGGL(k_resolve, dim3((n_res + 255) / 256), dim3(256), 0, s, a, n_res);
+}
 
 // ------------------------------------------------------------------------------------
 // k_reweight_uniform: one workgroup (256 lanes = 256 events) per uniform tile.
@@ -88,14 +127,34 @@ void launch_prep(const PrepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_prep, 
 // Every vector load is lane-contiguous (64 x 16 B = 1 KiB per wave instruction); all
 // parameter-dependent state (segment, dx, value) is wave-uniform and travels in SGPRs.
 // ------------------------------------------------------------------------------------
-constexpr int kUnroll = 8;
-
 __device__ __forceinline__ float spline_poly(float dx, const float4 c) {
   // SplineMonolith.cpp:762  fmaf(dx, fmaf(dx, fmaf(dx, fD, fC), fB), fY); c = {y,b,c,d}
   return fmaf(dx, fmaf(dx, fmaf(dx, c.w, c.z), c.y), c.x);
 }
 
-template <int MODE>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// coefficient planes are read exactly once per launch: NT marks them streaming so they do
+// not displace the small, hot per-step tables in L2
+template <bool NT>
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+  if (NT) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ float2 stream_load(const float2* p) {
+  if (NT) {
+    const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
+    return make_float2(v.x, v.y);
+  }
+  return *p;
+}
+
+template <int MODE, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 (kModeFill only)
   const uint32_t tile = a.tile_base + blockIdx.x;
@@ -107,51 +166,52 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
   }
 
-  // ---- kernel (i): TSpline3 responses, then TF1 responses, product in the reference's order
+  // ---- kernel (i): TSpline3 responses, then TF1 responses, product in the reference's order.
+  // The slot list is wave-uniform: it is fetched with scalar loads (16 dwords = 8 slots at a
+  // time) and carries the already-resolved plane index and dx, so there is no dependent
+  // look-up between a slot and its vector load.
   float w = 1.0f;  // SplineMonolith.cpp:798
   {
     const float4* __restrict__ sp = td.spl + lane;
-    const int2* __restrict__ meta = reinterpret_cast<const int2*>(td.meta);
+    const RSlot* __restrict__ rs = td.res;
     const uint32_t J = td.n_spl_slots;
     uint32_t j = 0;
-    for (; j + kUnroll <= J; j += kUnroll) {
-      float4 c[kUnroll];
-      float dx[kUnroll];
+    for (; j + UNROLL <= J; j += UNROLL) {
+      float4 c[UNROLL];
+      float dx[UNROLL];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const int2 m = meta[j + u];
-        const PTab pt = a.ptab[m.x];
-        c[u] = sp[(size_t)(uint32_t)(m.y + pt.seg) * M3_TE];
-        dx[u] = pt.dx;
+      for (int u = 0; u < UNROLL; ++u) {
+        const RSlot r = rs[j + u];
+        c[u] = stream_load<NT>(&sp[(size_t)(uint32_t)r.plane * M3_TE]);
+        dx[u] = r.f;
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) w *= spline_poly(dx[u], c[u]);
+      for (int u = 0; u < UNROLL; ++u) w *= spline_poly(dx[u], c[u]);
     }
     for (; j < J; ++j) {
-      const int2 m = meta[j];
-      const PTab pt = a.ptab[m.x];
-      w *= spline_poly(pt.dx, sp[(size_t)(uint32_t)(m.y + pt.seg) * M3_TE]);
+      const RSlot r = rs[j];
+      w *= spline_poly(r.f, stream_load<NT>(&sp[(size_t)(uint32_t)r.plane * M3_TE]));
     }
   }
   {
     const float2* __restrict__ tp = td.tf1 + lane;
-    const int32_t* __restrict__ tmeta = td.meta + 2 * td.n_spl_slots;
+    const RSlot* __restrict__ rt = td.res + td.n_spl_slots;
     const uint32_t J = td.n_tf1_slots;
     uint32_t j = 0;
-    for (; j + kUnroll <= J; j += kUnroll) {
-      float2 c[kUnroll];
-      float x[kUnroll];
+    for (; j + UNROLL <= J; j += UNROLL) {
+      float2 c[UNROLL];
+      float x[UNROLL];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        x[u] = a.pval[tmeta[j + u]];
-        c[u] = tp[(size_t)(j + u) * M3_TE];
+      for (int u = 0; u < UNROLL; ++u) {
+        x[u] = rt[j + u].f;
+        c[u] = stream_load<NT>(&tp[(size_t)(j + u) * M3_TE]);
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) w *= fmaf(c[u].x, x[u], c[u].y);  // SplineMonolith.cpp:779
+      for (int u = 0; u < UNROLL; ++u) w *= fmaf(c[u].x, x[u], c[u].y);  // SplineMonolith.cpp:779
     }
     for (; j < J; ++j) {
-      const float x = a.pval[tmeta[j]];
-      const float2 c = tp[(size_t)j * M3_TE];
+      const float x = rt[j].f;
+      const float2 c = stream_load<NT>(&tp[(size_t)j * M3_TE]);
       w *= fmaf(c.x, x, c.y);
     }
   }
@@ -181,29 +241,38 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
       }
       __syncthreads();
       const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+      // one flush per workgroup, spread over hist_rep replicas of the bin vector: thousands of
+      // workgroups adding into the same few hundred addresses serialise at the memory side
+      const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
       for (int i = lane; i < nb; i += 256) {
         const double v = lds_hist[i];
-        if (v != 0.0) atomicAdd(&a.hist[i], v);
+        const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
+        if (v != 0.0) atomicAdd(&a.hist[slot], v);
       }
     }
   }
 }
 
-void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s) {
-  if (n_tiles == 0) return;
-  const size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
-  const dim3 g(n_tiles), b(256);
-  switch (mode) {
-    case kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeEval>, g, b, 0, s, a); break;
-    case kModeFill: hipLaunchKernelGGL(k_reweight_uniform<kModeFill>, g, b, lds, s, a); break;
-    case kModeFill | kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEval>, g, b, lds, s, a); break;
-    case kModeFill | kModeEventW: hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEventW>, g, b, lds, s, a); break;
-    case kModeFill | kModeEval | kModeEventW:
-      hipLaunchKernelGGL(k_reweight_uniform<kModeFill | kModeEval | kModeEventW>, g, b, lds, s, a);
-      break;
-    case kModeEventW | kModeEval: hipLaunchKernelGGL(k_reweight_uniform<kModeEventW | kModeEval>, g, b, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_reweight_uniform<kModeEventW>, g, b, 0, s, a); break;
+template <int MODE>
+static void launch_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
+  const dim3 b(256);
+  if (k.unroll >= 16) {
+    if (k.nt) hipLaunchKernelGGL((k_reweight_uniform<MODE, 16, true>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((k_reweight_uniform<MODE, 16, false>), g, b, lds, s, a);
+  } else {
+    if (k.nt) hipLaunchKernelGGL((k_reweight_uniform<MODE, 8, true>), g, b, lds, s, a);
+    else hipLaunchKernelGGL((k_reweight_uniform<MODE, 8, false>), g, b, lds, s, a);
   }
+}
+
+void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s) {
+  if (n_tiles == 0) return;
+  size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
+  const dim3 g(n_tiles);
+  if (mode == kModeEval) launch_mode<kModeEval>(a, g, lds, k, s);
+  else if (mode == kModeFill) launch_mode<kModeFill>(a, g, lds, k, s);
+  else launch_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -315,8 +384,22 @@ __device__ double block_sum_256(double v, double* scratch /*[4]*/) {
 
 __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   __shared__ double scratch[4];
-  const double* mc = a.hist;
-  const double* w2 = a.hist + a.n_bins;
+  // fold the flush replicas (fixed order) into the first one; afterwards mc / w2 are plain vectors
+  double* mc = const_cast<double*>(a.hist);
+  double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
+  for (int i = threadIdx.x; i < a.n_bins; i += 256) {
+    double m = mc[i], v = w2[i];
+    for (int r = 1; r < a.hist_rep; ++r) {
+      m += mc[r * a.n_bins + i];
+      v += w2[r * a.n_bins + i];
+    }
+    if (a.hist_rep > 1) {
+      mc[i] = m;
+      w2[i] = v;
+      for (int r = 1; r < a.hist_rep; ++r) mc[r * a.n_bins + i] = w2[r * a.n_bins + i] = 0.0;
+    }
+  }
+  __syncthreads();
   // GetLikelihood(): all global bins (SampleHandlerFD.cpp:1284-1300)
   double acc = 0.0;
   for (int i = threadIdx.x; i < a.n_bins; i += 256) acc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
