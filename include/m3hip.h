@@ -228,17 +228,20 @@ int m3hip_debug_set_hist_replicas(m3hip_handle h, int n);
  * {stage params, launch prep, launch reweight(+all-reduce), launch llh, wait, collect}. */
 int m3hip_debug_host_times(m3hip_handle h, double* out6);
 
-/* Host-only probe of the upload re-layout (no device needed): sizes[4] = {n_tiles,
- * spline store in float4, TF1 store in float2, slot-meta in int32}; with non-NULL output
- * buffers of those sizes it also fills them and tile_desc[n_tiles][8] = {spl_off, tf1_off,
- * meta_off, n_spl_slots, n_tf1_slots, n_events, kind, n_planes}.  Used by the CPU tests. */
+/* Host-only probe of the upload re-layout (no device needed): sizes[6] = {n_tiles,
+ * spline store in float4, TF1 store in float2, slot-meta in int32, n_bricks, brick words};
+ * with non-NULL output buffers of those sizes it also fills them,
+ * tile_desc[n_tiles][8] = {spl_off, tf1_off, meta_off, n_spl_slots, n_tf1_slots, n_events,
+ * first_event, n_planes} and brick_desc[n_bricks][8] = {spl_off, tf1_off, words_off,
+ * n_spl_float4, n_tf1_float2, n_events, first_event, n_words}.  Used by the CPU tests. */
 int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_t n_events,
                        const float* coeff_many, uint64_t total_nknots,
                        const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                        const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
                        const unsigned int* n_param_per_event,
                        const unsigned int* n_param_per_event_tf1, uint64_t* sizes, float* spl,
-                       float* tf1, int32_t* meta, uint64_t* tile_desc);
+                       float* tf1, int32_t* meta, uint64_t* tile_desc, uint64_t* brick_desc,
+                       uint32_t* brick_words);
 
 const char* m3hip_version(void);
 

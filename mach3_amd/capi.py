@@ -124,7 +124,7 @@ def load_m3hip():
         "m3hip_debug_host_times": [vp, vp],
         "m3hip_debug_set_knobs": [vp, i32, i32, i32],
         "m3hip_debug_set_hist_replicas": [vp, i32],
-        "m3hip_debug_layout": [i32, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp],
+        "m3hip_debug_layout": [i32, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(lib, name)

@@ -28,6 +28,7 @@ struct m3hip_unique_id_t {  // same size/layout as ncclUniqueId (rccl.h: NCCL_UN
 struct Chunk {
   void* d_spl = nullptr;
   void* d_tf1 = nullptr;
+  uint32_t* d_words = nullptr;  // brick metadata streams
 };
 
 // RCCL is loaded on demand so that single-GPU users never touch it.
@@ -73,6 +74,8 @@ struct m3hip_ctx {
   std::vector<Chunk> chunks;
   std::vector<TileDev> h_tiles;
   TileDev* d_tiles = nullptr;
+  std::vector<BrickDev> h_bricks;
+  BrickDev* d_bricks = nullptr;
   // unique slot lists (flattened) and their per-step resolved form
   std::map<std::vector<int32_t>, uint32_t> list_index;
   std::vector<int32_t> u_param, u_plane0;
@@ -213,8 +216,11 @@ void free_monolith(m3hip_handle h) {
   for (auto& c : h->chunks) {
     dev_free(c.d_spl);
     dev_free(c.d_tf1);
+    dev_free(c.d_words);
   }
   h->chunks.clear();
+  h->h_bricks.clear();
+  dev_free(h->d_bricks); h->d_bricks = nullptr;
   h->h_tiles.clear();
   dev_free(h->d_tiles); h->d_tiles = nullptr;
   dev_free(h->d_u_param); h->d_u_param = nullptr;
@@ -249,6 +255,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   ReweightArgs a;
   memset(&a, 0, sizeof(a));
   a.tiles = h->d_tiles;
+  a.bricks = h->d_bricks;
   a.ptab = h->d_ptab;
   a.pval = h->d_pval;
   a.spline_w = h->d_spline_w;
@@ -391,6 +398,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_append before monolith_begin");
   if (h->E % M3_GROUP != 0) return fail(h, M3HIP_EINVAL, "only the last chunk may hold a non-multiple of 1024 events");
+  if (h->E + n_events > 0xFFFFF000ull) return fail(h, M3HIP_EINVAL, "more than 2^32 events on one device");
   if (n_events == 0) return M3HIP_OK;
   if ((n_splines && (!coeff_many || !nknots_arr || !param_no)) || (n_tf1 && (!coeff_tf1 || !param_no_tf1)))
     return fail(h, M3HIP_EINVAL, "monolith_append: NULL coefficient arrays");
@@ -424,13 +432,16 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   Chunk c;
   hipError_t e = hipMalloc(&c.d_spl, b_spl ? b_spl : 16);
   if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 ? b_tf1 : 16);
+  const size_t b_words = plan.brick_words.size() * sizeof(uint32_t);
+  if (e == hipSuccess && b_words) e = hipMalloc((void**)&c.d_words, b_words);
+  if (e == hipSuccess && b_words) e = hipMemcpy(c.d_words, plan.brick_words.data(), b_words, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
   (void)hipHostFree(s_spl);
   (void)hipHostFree(s_tf1);
   (void)hipHostFree(s_meta);
   if (e != hipSuccess) {
-    dev_free(c.d_spl); dev_free(c.d_tf1);
+    dev_free(c.d_spl); dev_free(c.d_tf1); dev_free(c.d_words);
     return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("monolith_append upload: ") + hipGetErrorString(e));
   }
   h->chunks.push_back(c);
@@ -442,7 +453,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     td.n_spl_slots = th.n_spl_slots;
     td.n_tf1_slots = th.n_tf1_slots;
     td.n_events = th.n_events;
-    td.pad_ = 0;
+    td.first_event = uint32_t(h->E + th.first_event);
     h->h_tiles.push_back(td);
     // unique ordered parameter lists: tiles that share one also share its resolved slots
     std::vector<int32_t> key(h_meta.begin() + th.meta_off, h_meta.begin() + th.meta_off + 2 * th.n_spl_slots + th.n_tf1_slots);
@@ -465,6 +476,15 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     }
     h->tile_res_off.push_back(off);
   }
+  for (const BrickHost& bh : plan.bricks) {
+    BrickDev bd;
+    bd.spl = reinterpret_cast<const float4*>(c.d_spl) + bh.spl_off;
+    bd.tf1 = reinterpret_cast<const float2*>(c.d_tf1) + bh.tf1_off;
+    bd.words = c.d_words + bh.words_off;
+    bd.n_events = bh.n_events;
+    bd.first_event = uint32_t(h->E + bh.first_event);
+    h->h_bricks.push_back(bd);
+  }
   h->n_uniform += plan.n_uniform;
   h->n_brick += plan.n_brick;
   h->E += n_events;
@@ -479,7 +499,7 @@ int m3hip_monolith_end(m3hip_handle h) {
   if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_end before monolith_begin");
   HIPCHK(h, hipSetDevice(h->device));
   const uint64_t n_tiles = h->h_tiles.size();
-  h->E_pad = ((n_tiles * M3_TE + M3_GROUP - 1) / M3_GROUP) * M3_GROUP;
+  h->E_pad = ((h->E + M3_GROUP - 1) / M3_GROUP) * M3_GROUP;
   if (h->E_pad == 0) h->E_pad = M3_GROUP;
   int rc;
   h->n_res = int32_t(h->u_param.size());
@@ -493,6 +513,9 @@ int m3hip_monolith_end(m3hip_handle h) {
   }
   for (uint64_t t = 0; t < n_tiles; ++t) h->h_tiles[t].res = h->d_resolved + h->tile_res_off[t];
   h->list_index.clear();
+  if ((rc = dev_alloc(h, &h->d_bricks, h->h_bricks.size()))) return rc;
+  if (!h->h_bricks.empty())
+    HIPCHK(h, hipMemcpy(h->d_bricks, h->h_bricks.data(), sizeof(BrickDev) * h->h_bricks.size(), hipMemcpyHostToDevice));
   if ((rc = dev_alloc(h, &h->d_tiles, size_t(n_tiles)))) return rc;
   if (n_tiles) HIPCHK(h, hipMemcpy(h->d_tiles, h->h_tiles.data(), sizeof(TileDev) * n_tiles, hipMemcpyHostToDevice));
   if ((rc = dev_alloc(h, &h->d_spline_w, size_t(h->E_pad)))) return rc;
@@ -559,6 +582,7 @@ int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment
   ReweightArgs a = make_rw_args(h);
   if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), kModeEval, h->knobs, h->stream);
+  launch_reweight_brick(a, uint32_t(h->h_bricks.size()), kModeEval, h->knobs, h->stream);
   if (h->timing) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = 1;
@@ -758,6 +782,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   }
   if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->knobs, h->stream);
+  launch_reweight_brick(a, uint32_t(h->h_bricks.size()), mode, h->knobs, h->stream);
   if (h->timing) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = 0;
@@ -950,7 +975,8 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
                        uint64_t total_nknots, const unsigned int* nknots_arr, const int16_t* param_no,
                        uint64_t n_splines, const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
                        const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1,
-                       uint64_t* sizes, float* spl, float* tf1, int32_t* meta, uint64_t* tile_desc) {
+                       uint64_t* sizes, float* spl, float* tf1, int32_t* meta, uint64_t* tile_desc,
+                       uint64_t* brick_desc, uint32_t* brick_words) {
   if (!npts || !sizes) return fail(nullptr, M3HIP_EINVAL, "debug_layout: NULL arguments");
   ChunkInput in;
   in.n_events = n_events;
@@ -971,14 +997,23 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   sizes[1] = plan.spl_float4;
   sizes[2] = plan.tf1_float2;
   sizes[3] = plan.meta_int32;
-  if (!spl || !tf1 || !meta || !tile_desc) return M3HIP_OK;  // plan only
+  sizes[4] = plan.bricks.size();
+  sizes[5] = plan.brick_words.size();
+  if (!spl || !tf1 || !meta || !tile_desc || !brick_desc || !brick_words) return M3HIP_OK;  // plan only
   fill_chunk(n_params, npts, in, plan, spl, tf1, meta);
   for (size_t t = 0; t < plan.tiles.size(); ++t) {
     const TileHost& th = plan.tiles[t];
     uint64_t* d = tile_desc + 8 * t;
     d[0] = th.spl_off; d[1] = th.tf1_off; d[2] = th.meta_off; d[3] = th.n_spl_slots;
-    d[4] = th.n_tf1_slots; d[5] = th.n_events; d[6] = th.kind; d[7] = th.n_planes;
+    d[4] = th.n_tf1_slots; d[5] = th.n_events; d[6] = th.first_event; d[7] = th.n_planes;
   }
+  for (size_t b = 0; b < plan.bricks.size(); ++b) {
+    const BrickHost& bh = plan.bricks[b];
+    uint64_t* d = brick_desc + 8 * b;
+    d[0] = bh.spl_off; d[1] = bh.tf1_off; d[2] = bh.words_off; d[3] = bh.n_spl_f4;
+    d[4] = bh.n_tf1_f2; d[5] = bh.n_events; d[6] = bh.first_event; d[7] = bh.n_words;
+  }
+  if (!plan.brick_words.empty()) memcpy(brick_words, plan.brick_words.data(), plan.brick_words.size() * sizeof(uint32_t));
   return M3HIP_OK;
 }
 

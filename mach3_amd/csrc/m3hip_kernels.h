@@ -37,11 +37,21 @@ struct TileDev {
   uint32_t n_spl_slots;
   uint32_t n_tf1_slots;
   uint32_t n_events;
-  uint32_t pad_;
+  uint32_t first_event;  // padded global index of lane 0
+};
+
+// Device-side descriptor of one brick (ragged 1024-event group), see m3hip_layout.h
+struct BrickDev {
+  const float4* spl;
+  const float2* tf1;
+  const uint32_t* words;  // metadata stream
+  uint32_t n_events;
+  uint32_t first_event;
 };
 
 struct ReweightArgs {
   const TileDev* tiles;
+  const BrickDev* bricks;
   const PTab* ptab;          // [P]
   const float* pval;         // [P] ParamValues
   float* spline_w;           // [E_pad] monolith total weight per event (may be null)
@@ -114,6 +124,7 @@ struct ReweightKnobs {
 };
 
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_llh(const LlhArgs& a, hipStream_t s);
 
 }  // namespace m3hip

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     }
   }
 
-  const uint64_t ev = (uint64_t)tile * M3_TE + lane;
+  const uint64_t ev = (uint64_t)td.first_event + lane;
   if (MODE & kModeEval) a.spline_w[ev] = w;  // cpu_total_weights[EventNum] (SplineMonolith.cpp:828)
 
   if (MODE & (kModeFill | kModeEventW)) {
@@ -273,6 +273,142 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
   if (mode == kModeEval) launch_mode<kModeEval>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_mode<kModeFill>(a, g, lds, k, s);
   else launch_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
+}
+
+
+// ------------------------------------------------------------------------------------
+// k_reweight_brick: one workgroup per brick (<= 1024 events with ragged parameter lists).
+//
+// Stage by stage (<= 8192 responses each): phase A evaluates the stage's responses
+// lane-per-response in PARAMETER-major order -- a run's active segment plane is contiguous,
+// so the float4 loads coalesce -- and scatters each weight to its event-major slot of an LDS
+// staging array; phase B lets every event multiply its slice in ascending parameter order.
+// HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
+// ------------------------------------------------------------------------------------
+constexpr int kBrickEvPerLane = M3_GROUP / 256;
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void k_reweight_brick(ReweightArgs a) {
+  __shared__ float stage_w[M3_BRICK_CAP];
+  extern __shared__ double lds_hist[];
+  const uint32_t lane = threadIdx.x;
+  const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
+  const uint32_t* __restrict__ words = bd.words;
+
+  if (MODE & kModeFill) {
+    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+    for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
+  }
+
+  float w[kBrickEvPerLane];
+#pragma unroll
+  for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
+
+  const uint32_t n_stages = words[0];
+  for (uint32_t s = 0; s < n_stages; ++s) {
+    const uint32_t* __restrict__ h = words + 1 + M3_STAGE_HDR * s;
+    const uint32_t kind = h[0], n_resp = h[1];
+    if (kind == 0) {
+      const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
+      const uint32_t* __restrict__ resp = words + h[4];
+      constexpr int U = 4;
+      uint32_t r = lane;
+      for (; r + (U - 1) * 256 < n_resp; r += U * 256) {
+        float4 c[U];
+        float dx[U];
+        uint32_t dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t m = resp[r + u * 256];
+          const uint4 rt = runs[m & 0xFFFFu];  // {coef_off, n_run, start_r, param}
+          const PTab pt = a.ptab[rt.w];
+          c[u] = stream_load<NT>(&bd.spl[(size_t)rt.x + (size_t)pt.seg * rt.y + (r + u * 256 - rt.z)]);
+          dx[u] = pt.dx;
+          dst[u] = m >> 16;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) stage_w[dst[u]] = spline_poly(dx[u], c[u]);
+      }
+      for (; r < n_resp; r += 256) {
+        const uint32_t m = resp[r];
+        const uint4 rt = runs[m & 0xFFFFu];
+        const PTab pt = a.ptab[rt.w];
+        const float4 c = stream_load<NT>(&bd.spl[(size_t)rt.x + (size_t)pt.seg * rt.y + (r - rt.z)]);
+        stage_w[m >> 16] = spline_poly(pt.dx, c);
+      }
+    } else {
+      const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
+      const float2* __restrict__ tp = bd.tf1 + h[6];
+      for (uint32_t r = lane; r < n_resp; r += 256) {
+        const float x = a.pval[par[r]];
+        const float2 c = stream_load<NT>(&tp[r]);
+        stage_w[r] = fmaf(c.x, x, c.y);  // SplineMonolith.cpp:779
+      }
+    }
+    __syncthreads();
+    const uint32_t* __restrict__ evt = words + h[5];
+#pragma unroll
+    for (int q = 0; q < kBrickEvPerLane; ++q) {
+      const uint32_t e = lane * kBrickEvPerLane + q;
+      if (e < bd.n_events) {
+        const uint32_t ec = evt[e];
+        const uint32_t start = ec & 0xFFFFu, cnt = ec >> 16;
+        for (uint32_t i = 0; i < cnt; ++i) w[q] *= stage_w[start + i];  // ascending parameter = reference order
+      }
+    }
+    __syncthreads();
+  }
+  if (MODE & kModeFill) __syncthreads();  // lds_hist zeroing is complete even for a brick without stages
+
+#pragma unroll
+  for (int q = 0; q < kBrickEvPerLane; ++q) {
+    const uint32_t e = lane * kBrickEvPerLane + q;
+    const uint64_t ev = (uint64_t)bd.first_event + e;
+    if (MODE & kModeEval) a.spline_w[ev] = w[q];
+    if (MODE & (kModeFill | kModeEventW)) {
+      float tw = 1.0f;  // CalcWeightTotal, as in k_reweight_uniform
+      for (uint32_t m = 0; m < a.n_norm_slots; ++m) {
+        const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
+        if (idx >= 0) tw *= static_cast<float>(a.params[idx]);
+      }
+      const int oi = a.osc[ev];
+      if (oi >= 0) tw *= a.osc_table[oi];
+      tw *= w[q];
+      if (MODE & kModeEventW) a.event_w[ev] = tw;
+      if (MODE & kModeFill) {
+        const int b = a.bin[ev];
+        if (e < bd.n_events && tw > 0.f && b >= 0) {
+          atomicAdd(&lds_hist[b], (double)tw);
+          if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
+        }
+      }
+    }
+  }
+  if (MODE & kModeFill) {
+    __syncthreads();
+    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+    const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+    for (int i = lane; i < nb; i += 256) {
+      const double v = lds_hist[i];
+      const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
+      if (v != 0.0) atomicAdd(&a.hist[slot], v);
+    }
+  }
+}
+
+template <int MODE>
+static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
+  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true>), g, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((k_reweight_brick<MODE, false>), g, dim3(256), lds, s, a);
+}
+
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {
+  if (n_bricks == 0) return;
+  const size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  const dim3 g(n_bricks);
+  if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
+  else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
+  else launch_brick_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
 }
 
 // ------------------------------------------------------------------------------------

@@ -42,11 +42,200 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
   return true;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Brick metadata stream (uint32 words, offsets relative to the brick's first word):
+//   [0]                      n_stages
+//   [1 + 8*s .. 8 + 8*s]     stage header: kind (0 TSpline3, 1 TF1), n_resp, n_runs, off_runs,
+//                            off_resp, off_evt, coef_off, 0
+//   off_runs  (TSpline3)     n_runs x {coef_off (float4 from the brick's spline store), n_run,
+//                            start_r (first response of the run in the stage), param}
+//   off_resp  TSpline3: n_resp words {run : 16 | dst << 16}; TF1: n_resp parameters packed two
+//             per word (low half first)
+//   off_evt   n_events words {start : 16 | count << 16}: the event's slice of the staging array
+//   coef_off  TF1 only: float2 index of the stage's first {a,b} in the brick's TF1 store
+// ------------------------------------------------------------------------------------
+bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_t e0, uint64_t e1, BrickHost* bh,
+                std::vector<uint32_t>* words_all, std::string* err) {
+  const uint32_t ne = uint32_t(e1 - e0);
+  bh->n_events = ne;
+  bh->first_event = e0;
+  bh->words_off = words_all->size();
+  std::vector<uint32_t> w;  // this brick's stream
+
+  // the per-event product must visit parameters in the event's own order; the brick regroups
+  // by parameter, which preserves that order only if every event lists them ascending
+  for (uint64_t e = e0; e < e1; ++e) {
+    const unsigned int c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
+    for (unsigned int i = 1; i < c; ++i)
+      if (in.param_no[s0 + i] <= in.param_no[s0 + i - 1]) {
+        *err = "event " + std::to_string(e) + ": spline parameters are not in ascending order (required for ragged tiles)";
+        return false;
+      }
+    const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+    for (unsigned int i = 1; i < ct; ++i)
+      if (in.param_no_tf1[t0 + i] <= in.param_no_tf1[t0 + i - 1]) {
+        *err = "event " + std::to_string(e) + ": TF1 parameters are not in ascending order (required for ragged tiles)";
+        return false;
+      }
+  }
+
+  // ---- inverted index: responses per parameter (counting sort keeps events ascending)
+  std::vector<uint32_t> cnt_s(n_params + 1, 0), cnt_t(n_params + 1, 0);
+  for (uint64_t e = e0; e < e1; ++e) {
+    const unsigned int c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
+    for (unsigned int i = 0; i < c; ++i) cnt_s[in.param_no[s0 + i] + 1]++;
+    const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+    for (unsigned int i = 0; i < ct; ++i) cnt_t[in.param_no_tf1[t0 + i] + 1]++;
+  }
+  for (int p = 0; p < n_params; ++p) { cnt_s[p + 1] += cnt_s[p]; cnt_t[p + 1] += cnt_t[p]; }
+  const uint32_t S = cnt_s[n_params], T = cnt_t[n_params];
+  std::vector<uint32_t> inv_s(S), inv_ev(S);  // spline index / local event, parameter-major
+  {
+    std::vector<uint32_t> cur(cnt_s.begin(), cnt_s.end() - 1);
+    for (uint64_t e = e0; e < e1; ++e) {
+      const unsigned int c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
+      for (unsigned int i = 0; i < c; ++i) {
+        const uint32_t pos = cur[in.param_no[s0 + i]]++;
+        inv_s[pos] = s0 + i;
+        inv_ev[pos] = uint32_t(e - e0);
+      }
+    }
+  }
+
+  // ---- stage boundaries: ascending parameter ranges holding <= M3_BRICK_CAP responses
+  struct Range { int p0, p1; };
+  auto split = [&](const std::vector<uint32_t>& cnt) {
+    std::vector<Range> st;
+    int p0 = 0;
+    while (p0 < n_params) {
+      int p1 = p0;
+      uint32_t tot = 0;
+      while (p1 < n_params && tot + (cnt[p1 + 1] - cnt[p1]) <= uint32_t(M3_BRICK_CAP)) { tot += cnt[p1 + 1] - cnt[p1]; ++p1; }
+      if (p1 == p0) ++p1;  // cannot happen: a run holds at most M3_GROUP <= M3_BRICK_CAP responses
+      if (tot > 0) st.push_back({p0, p1});
+      p0 = p1;
+    }
+    return st;
+  };
+  const std::vector<Range> st_s = split(cnt_s), st_t = split(cnt_t);
+  const uint32_t n_stages = uint32_t(st_s.size() + st_t.size());
+  w.assign(1 + size_t(M3_STAGE_HDR) * n_stages, 0u);
+  w[0] = n_stages;
+
+  uint64_t spl_f4 = 0;
+  bh->spl_src.clear();
+  bh->spl_src.reserve(S);
+  uint32_t stage = 0;
+  std::vector<uint32_t> ev_cnt(ne), ev_start(ne), ev_cur(ne);
+  for (const Range& rg : st_s) {
+    const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
+    // event-major staging slots
+    std::fill(ev_cnt.begin(), ev_cnt.end(), 0u);
+    for (uint32_t r = r0; r < r1; ++r) ev_cnt[inv_ev[r]]++;
+    uint32_t acc = 0;
+    for (uint32_t e = 0; e < ne; ++e) { ev_start[e] = acc; acc += ev_cnt[e]; ev_cur[e] = ev_start[e]; }
+    // runs
+    std::vector<uint32_t> runs, resp(n_resp);
+    uint32_t n_runs = 0;
+    for (int p = rg.p0; p < rg.p1; ++p) {
+      const uint32_t a = cnt_s[p], b = cnt_s[p + 1];
+      if (a == b) continue;
+      const uint32_t n_run = b - a, nseg = uint32_t(npts[p] - 1);
+      if (n_runs >= 65536u) { *err = "brick: more than 65536 runs in a stage"; return false; }
+      runs.push_back(uint32_t(spl_f4));
+      runs.push_back(n_run);
+      runs.push_back(a - r0);
+      runs.push_back(uint32_t(p));
+      for (uint32_t r = a; r < b; ++r) {
+        const uint32_t dst = ev_cur[inv_ev[r]]++;  // parameters ascend, so slots fill in product order
+        resp[r - r0] = (n_runs & 0xFFFFu) | (dst << 16);
+        bh->spl_src.push_back(inv_s[r]);
+      }
+      spl_f4 += uint64_t(n_run) * nseg;
+      ++n_runs;
+    }
+    uint32_t* h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[0] = 0; h[1] = n_resp; h[2] = n_runs;
+    h[3] = uint32_t(w.size());
+    w.insert(w.end(), runs.begin(), runs.end());
+    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[4] = uint32_t(w.size());
+    w.insert(w.end(), resp.begin(), resp.end());
+    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[5] = uint32_t(w.size());
+    for (uint32_t e = 0; e < ne; ++e) w.push_back((ev_start[e] & 0xFFFFu) | (ev_cnt[e] << 16));
+    ++stage;
+  }
+  bh->n_spl_f4 = spl_f4;
+
+  // TF1 stages: responses event-major inside the stage, so the staging slot is the response index
+  uint64_t tf1_f2 = 0;
+  bh->tf1_src.clear();
+  bh->tf1_src.reserve(T);
+  for (const Range& rg : st_t) {
+    std::vector<uint32_t> params;
+    std::fill(ev_cnt.begin(), ev_cnt.end(), 0u);
+    for (uint64_t e = e0; e < e1; ++e) {
+      const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+      for (unsigned int i = 0; i < ct; ++i) {
+        const int p = in.param_no_tf1[t0 + i];
+        if (p >= rg.p0 && p < rg.p1) {
+          params.push_back(uint32_t(p));
+          bh->tf1_src.push_back(t0 + i);
+          ev_cnt[e - e0]++;
+        }
+      }
+    }
+    const uint32_t n_resp = uint32_t(params.size());
+    uint32_t acc = 0;
+    for (uint32_t e = 0; e < ne; ++e) { ev_start[e] = acc; acc += ev_cnt[e]; }
+    uint32_t* h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[0] = 1; h[1] = n_resp; h[2] = 0; h[3] = 0;
+    h[4] = uint32_t(w.size());
+    for (uint32_t i = 0; i < n_resp; i += 2) w.push_back(params[i] | ((i + 1 < n_resp ? params[i + 1] : 0u) << 16));
+    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[5] = uint32_t(w.size());
+    for (uint32_t e = 0; e < ne; ++e) w.push_back((ev_start[e] & 0xFFFFu) | (ev_cnt[e] << 16));
+    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
+    h[6] = uint32_t(tf1_f2);
+    tf1_f2 += n_resp;
+    ++stage;
+  }
+  bh->n_tf1_f2 = tf1_f2;
+  bh->n_words = w.size();
+  words_all->insert(words_all->end(), w.begin(), w.end());
+  return true;
+}
+
+// copies a brick's coefficients: TSpline3 runs become [segment][event-in-run] planes
+void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, const uint32_t* words, float* spl, float* tf1) {
+  float* bs = spl + 4 * bh.spl_off;
+  float* bt = tf1 + 2 * bh.tf1_off;
+  const uint32_t n_stages = words[0];
+  size_t src_i = 0;
+  for (uint32_t s = 0; s < n_stages; ++s) {
+    const uint32_t* h = words + 1 + size_t(M3_STAGE_HDR) * s;
+    if (h[0] != 0) continue;
+    const uint32_t* runs = words + h[3];
+    for (uint32_t r = 0; r < h[2]; ++r) {
+      const uint32_t coef_off = runs[4 * r], n_run = runs[4 * r + 1], p = runs[4 * r + 3];
+      const uint32_t nseg = uint32_t(npts[p] - 1);
+      for (uint32_t q = 0; q < n_run; ++q) {
+        const float* src = in.coeff_many + 4ull * in.nknots_arr[bh.spl_src[src_i++]];
+        for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (uint64_t(coef_off) + uint64_t(k) * n_run + q) * 4, src + 4 * k, 16);
+      }
+    }
+  }
+  for (size_t i = 0; i < bh.tf1_src.size(); ++i) std::memcpy(bt + 2 * i, in.coeff_tf1 + 2ull * bh.tf1_src[i], 8);
+}
+
 }  // namespace
 
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
                 std::string* err) {
   plan->tiles.clear();
+  plan->tiles.reserve((in.n_events + M3_TE - 1) / M3_TE);
   plan->spl_float4 = plan->tf1_float2 = plan->meta_int32 = 0;
   plan->n_uniform = plan->n_brick = 0;
   if (in.n_events == 0) return true;
@@ -82,38 +271,54 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
     if (p < 0 || p >= n_params) { *err = "TF1 " + std::to_string(t) + ": paramNo out of range"; return false; }
   }
 
-  // ---- tiles
+  // ---- tiles: classify per group of M3_GROUP events
   const uint64_t n_tiles = (in.n_events + M3_TE - 1) / M3_TE;
-  plan->tiles.resize(n_tiles);
   std::vector<uint8_t> uniform(n_tiles, 0);
   parallel_for(n_tiles, [&](uint64_t t) {
     const uint64_t e0 = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, e0 + M3_TE);
     uniform[t] = tile_is_uniform(in, e0, e1) ? 1 : 0;
   });
-  for (uint64_t t = 0; t < n_tiles; ++t) {
-    TileHost& th = plan->tiles[t];
-    const uint64_t e0 = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, e0 + M3_TE);
-    th.n_events = uint32_t(e1 - e0);
-    if (!uniform[t]) {
-      th.kind = kTileBrick;
+  const uint64_t n_groups = (in.n_events + M3_GROUP - 1) / M3_GROUP;
+  const uint64_t tiles_per_group = M3_GROUP / M3_TE;
+  plan->bricks.clear();
+  plan->brick_words.clear();
+  for (uint64_t g = 0; g < n_groups; ++g) {
+    const uint64_t t0 = g * tiles_per_group, t1 = std::min<uint64_t>(n_tiles, t0 + tiles_per_group);
+    bool all_uniform = true;
+    for (uint64_t t = t0; t < t1; ++t) all_uniform = all_uniform && uniform[t];
+    if (all_uniform) {
+      for (uint64_t t = t0; t < t1; ++t) {
+        TileHost th;
+        const uint64_t e0 = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, e0 + M3_TE);
+        th.first_event = e0;
+        th.n_events = uint32_t(e1 - e0);
+        th.kind = kTileUniform;
+        th.n_spl_slots = in.npe[2 * e0];
+        th.n_tf1_slots = in.npe_tf1[2 * e0];
+        uint64_t planes = 0;
+        const unsigned int s0 = in.npe[2 * e0 + 1];
+        for (uint32_t j = 0; j < th.n_spl_slots; ++j) planes += uint64_t(npts[in.param_no[s0 + j]] - 1);
+        th.n_planes = planes;
+        th.spl_off = plan->spl_float4;
+        th.tf1_off = plan->tf1_float2;
+        th.meta_off = plan->meta_int32;
+        plan->spl_float4 += planes * M3_TE;
+        plan->tf1_float2 += uint64_t(th.n_tf1_slots) * M3_TE;
+        plan->meta_int32 += 2ull * th.n_spl_slots + th.n_tf1_slots;
+        plan->tiles.push_back(th);
+        plan->n_uniform++;
+      }
+    } else {
+      const uint64_t e0 = g * M3_GROUP, e1 = std::min<uint64_t>(in.n_events, e0 + M3_GROUP);
+      BrickHost bh;
+      if (!plan_brick(n_params, npts, in, e0, e1, &bh, &plan->brick_words, err)) return false;
+      bh.spl_off = plan->spl_float4;
+      bh.tf1_off = plan->tf1_float2;
+      plan->spl_float4 += bh.n_spl_f4;
+      plan->tf1_float2 += bh.n_tf1_f2;
+      plan->bricks.push_back(std::move(bh));
       plan->n_brick++;
-      *err = "tile " + std::to_string(t) + ": events carry different parameter lists (ragged tiles not supported yet)";
-      return false;
     }
-    th.kind = kTileUniform;
-    plan->n_uniform++;
-    th.n_spl_slots = in.npe[2 * e0];
-    th.n_tf1_slots = in.npe_tf1[2 * e0];
-    uint64_t planes = 0;
-    const unsigned int s0 = in.npe[2 * e0 + 1];
-    for (uint32_t j = 0; j < th.n_spl_slots; ++j) planes += uint64_t(npts[in.param_no[s0 + j]] - 1);
-    th.n_planes = planes;
-    th.spl_off = plan->spl_float4;
-    th.tf1_off = plan->tf1_float2;
-    th.meta_off = plan->meta_int32;
-    plan->spl_float4 += planes * M3_TE;
-    plan->tf1_float2 += uint64_t(th.n_tf1_slots) * M3_TE;
-    plan->meta_int32 += 2ull * th.n_spl_slots + th.n_tf1_slots;
   }
   return true;
 }
@@ -123,7 +328,7 @@ void fill_chunk(int /*n_params*/, const int16_t* npts, const ChunkInput& in, con
   parallel_for(plan.tiles.size(), [&](uint64_t t) {
     const TileHost& th = plan.tiles[t];
     if (th.kind != kTileUniform) return;
-    const uint64_t e0 = t * M3_TE;
+    const uint64_t e0 = th.first_event;
     const unsigned int s0 = in.npe[2 * e0 + 1];
     const unsigned int t0 = in.npe_tf1[2 * e0 + 1];
     int32_t* m = meta + th.meta_off;
@@ -166,6 +371,10 @@ void fill_chunk(int /*n_params*/, const int16_t* npts, const ChunkInput& in, con
         }
       }
     }
+  });
+  parallel_for(plan.bricks.size(), [&](uint64_t b) {
+    const BrickHost& bh = plan.bricks[b];
+    fill_brick(npts, in, bh, plan.brick_words.data() + bh.words_off, spl, tf1);
   });
 }
 

@@ -15,7 +15,17 @@
 //       wavefront's 64 loads are one 1 KB line-aligned burst.  TF1: tf1[j * M3_TE + lane]
 //       float2 {a,b}.  Lane = event inside the tile; the per-event product runs over j in
 //       the reference's order (splines in event order, then TF1s).
-//   BRICK tile (ragged parameter lists): see m3hip_layout.cpp.
+//   BRICK (ragged parameter lists; one per M3_GROUP = 1024 consecutive events in which the
+//   lists differ): a per-brick CSC.  Responses are regrouped by PARAMETER so that the quads
+//   a step needs for (parameter p, segment seg[p]) are again contiguous:
+//       run (p) = the n_run events of the brick that carry p, ascending event order;
+//       spl[coef_off(p) + k * n_run + q]   float4 of segment k for the q-th event of the run
+//   Runs are packed into STAGES of <= M3_BRICK_CAP responses (ascending parameter ranges).  A
+//   stage's weights are evaluated lane-per-response (coalesced), scattered into an LDS staging
+//   array at their EVENT-major position `dst`, and then multiplied per event in ascending
+//   parameter order -- the reference's order, so the float product is bit-identical.  TF1
+//   responses have no segment and are stored event-major per stage (dst = index).
+//   Per-brick metadata is a uint32 word stream (layout in m3hip_layout.cpp).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -26,6 +36,9 @@ namespace m3hip {
 
 constexpr int M3_TE = 256;       // events per tile (= workgroup size of the reweight kernels)
 constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
+constexpr int M3_BRICK_CAP = 8192;  // responses per brick stage (= floats of LDS staging)
+constexpr int M3_STAGE_HDR = 8;     // words per stage header
+constexpr int M3_RUN_WORDS = 4;     // words per run entry
 
 enum TileKind : uint32_t { kTileUniform = 0, kTileBrick = 1 };
 
@@ -39,6 +52,20 @@ struct TileHost {
   uint32_t n_events = 0;  // valid lanes (<= M3_TE)
   uint32_t kind = kTileUniform;
   uint64_t n_planes = 0;  // spline planes in the tile (sum of segments over slots)
+  uint64_t first_event = 0;  // chunk-local index of lane 0
+};
+
+// Host-side brick descriptor.
+struct BrickHost {
+  uint64_t spl_off = 0;    // float4 index of the brick's spline store
+  uint64_t tf1_off = 0;    // float2 index of the brick's TF1 store
+  uint64_t words_off = 0;  // uint32 index of the brick's metadata stream
+  uint64_t n_spl_f4 = 0, n_tf1_f2 = 0, n_words = 0;
+  uint32_t n_events = 0;
+  uint64_t first_event = 0;  // chunk-local
+  // fill-time copy lists: source spline / TF1 index of every response, in store order
+  std::vector<uint32_t> spl_src;   // per spline response (run-major): index into the chunk's spline arrays
+  std::vector<uint32_t> tf1_src;   // per TF1 response (stage-major, event-major inside)
 };
 
 struct ChunkInput {
@@ -61,6 +88,8 @@ struct ChunkPlan {
   uint64_t tf1_float2 = 0;  // size of the TF1 store, float2 units
   uint64_t meta_int32 = 0;  // size of the slot-meta store
   uint64_t n_uniform = 0, n_brick = 0;
+  std::vector<BrickHost> bricks;
+  std::vector<uint32_t> brick_words;  // metadata streams of all bricks, concatenated
 };
 
 // Validates the chunk against (n_params, npts) and sizes the tile store.

@@ -341,3 +341,71 @@ def test_api_error_paths(fresh_engine):
         sh.SetupEvents(0, np.full(300, 10, np.int32), None, None, None)   # bin index out of range
     with pytest.raises(capi.M3HipError):
         sh.AddData(np.zeros(9))
+
+
+@pytest.mark.parametrize("cfg,n_events,n_params", [("c3", 5000, 96), ("c5", 3000, 512), ("c3", 1024 * 9 + 77, 512)])
+def test_ragged_bricks_match_oracle(fresh_engine, cfg, n_events, n_params):
+    """Configs 3-5 shape: random sparse occupancy, mixed TSpline3 / TF1, Barlow-Beeston.  Goes
+    through the brick kernel; weights bit-exact, bins 1e-12, LLH 1e-9."""
+    spec = synth.CONFIGS[cfg].scaled(n_events, n_params=n_params)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine, chunk_events=4096)
+    info = eng.info()
+    assert info.n_tiles_brick == (n_events + 1023) // 1024 and info.n_tiles_uniform == 0
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
+    assert info.n_splines == ch["n_splines"] and info.n_tf1 == ch["n_tf1"]
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+    assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2, 3):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetSplineWeights(0, n_events).view(np.uint32), omono.total_weights.view(np.uint32))
+        assert np.array_equal(sh.GetEventWeights(0, n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    # seam 2 on the same data
+    mono.Evaluate()
+    mono.SynchroniseMemTransfer()
+    omono.evaluate()
+    assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+    osamp.close()
+    omono.close()
+
+
+def test_uniform_and_ragged_groups_in_one_sample(fresh_engine):
+    """1024 dense events followed by ragged ones, plus events without any response."""
+    P = 12
+    X7 = np.arange(-3.0, 4.0)
+    rng = np.random.default_rng(7)
+    quad = lambda: natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))
+    resp = lambda p: (p, "spl", quad()) if p % 3 else (p, "tf1", (0.1 * rng.standard_normal(), 1.0))
+    events = [[resp(p) for p in range(P)] for _ in range(1024)]
+    events += [[resp(p) for p in range(P) if rng.random() < 0.6] for _ in range(700)]
+    events[1100] = []
+    events[1500] = []
+    E = len(events)
+    cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P) if p % 3}, events)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    par = np.zeros(P)
+    opar = np.zeros(P)
+    omono.set_spline_pointers(opar)
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    info = fresh_engine.info()
+    assert info.n_tiles_uniform == 4 and info.n_tiles_brick == 1
+    mono.setSplinePointers(par)
+    for k in range(4):
+        par[:] = rng.uniform(-3.2, 3.2, P)
+        opar[:] = par
+        mono.Evaluate()
+        mono.SynchroniseMemTransfer()
+        omono.evaluate()
+        assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+    assert mono.cpu_total_weights[1100] == 1.0 and mono.cpu_total_weights[1500] == 1.0
+    omono.close()

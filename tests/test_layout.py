@@ -16,9 +16,7 @@ def check_uniform_tiles(n_params, K, npts, ch, lay):
     npe = ch["npe"].reshape(-1, 2)
     npt = ch["npe_tf1"].reshape(-1, 2)
     for t, d in enumerate(desc):
-        spl_off, tf1_off, meta_off, js, jt, nev, kind, nplanes = [int(v) for v in d]
-        assert kind == 0
-        e0 = t * TE
+        spl_off, tf1_off, meta_off, js, jt, nev, e0, nplanes = [int(v) for v in d]
         assert nev == min(TE, ch["n_events"] - e0)
         m = meta[meta_off: meta_off + 2 * js + jt]
         plane = 0
@@ -100,3 +98,108 @@ def test_layout_rejects_inconsistent_input():
     npts2[1] = -999                             # a spline on a parameter that has no knots
     rc, err, _ = debug_layout(4, 7, npts2, ch)
     assert rc != 0 and "knot count" in err
+
+
+def brick_event_lists(npts, ch, lay, b):
+    """Replay a brick's metadata stream on the CPU with coefficient quads instead of weights:
+    returns, per event of the brick, the ordered list of (param, kind, coefficients) the kernel
+    would multiply -- phase A scatter to `dst`, phase B read-back per event."""
+    spl, tf1, words = lay["spl"], lay["tf1"], lay["words"]
+    spl_off, tf1_off, w_off, n_f4, n_f2, nev, e0, nw = [int(v) for v in lay["bdesc"][b]]
+    w = words[w_off: w_off + nw]
+    out = [[] for _ in range(nev)]
+    for s in range(int(w[0])):
+        h = w[1 + 8 * s: 9 + 8 * s]
+        kind, n_resp, n_runs = int(h[0]), int(h[1]), int(h[2])
+        stage = [None] * n_resp
+        if kind == 0:
+            runs = w[int(h[3]): int(h[3]) + 4 * n_runs].reshape(-1, 4)
+            resp = w[int(h[4]): int(h[4]) + n_resp]
+            for r in range(n_resp):
+                run, dst = int(resp[r]) & 0xFFFF, int(resp[r]) >> 16
+                coef_off, n_run, start_r, p = [int(v) for v in runs[run]]
+                q = r - start_r
+                assert 0 <= q < n_run
+                nseg = int(npts[p]) - 1
+                quads = np.stack([spl[spl_off + coef_off + k * n_run + q] for k in range(nseg)])
+                assert stage[dst] is None
+                stage[dst] = (p, "spl", quads)
+        else:
+            par = w[int(h[4]): int(h[4]) + (n_resp + 1) // 2].view(np.uint16)[:n_resp]
+            for r in range(n_resp):
+                stage[r] = (int(par[r]), "tf1", tf1[tf1_off + int(h[6]) + r])
+        evt = w[int(h[5]): int(h[5]) + nev]
+        for e in range(nev):
+            start, cnt = int(evt[e]) & 0xFFFF, int(evt[e]) >> 16
+            out[e] += stage[start: start + cnt]
+        assert all(x is not None for x in stage)
+    return e0, out
+
+
+def check_bricks(npts, ch, lay):
+    cm = ch["coeff_many"].reshape(-1, 4)
+    ct = ch["coeff_tf1"].reshape(-1, 2)
+    npe = ch["npe"].reshape(-1, 2)
+    npt = ch["npe_tf1"].reshape(-1, 2)
+    for b in range(lay["n_bricks"]):
+        e0, lists = brick_event_lists(npts, ch, lay, b)
+        for le, got in enumerate(lists):
+            e = e0 + le
+            exp = []
+            for i in range(int(npe[e, 0])):
+                s = int(npe[e, 1]) + i
+                p = int(ch["param_no"][s])
+                k0 = int(ch["nknots_arr"][s])
+                exp.append((p, "spl", cm[k0: k0 + int(npts[p]) - 1]))
+            for i in range(int(npt[e, 0])):
+                t = int(npt[e, 1]) + i
+                exp.append((int(ch["param_no_tf1"][t]), "tf1", ct[t]))
+            assert len(got) == len(exp), (e, len(got), len(exp))
+            for g, x in zip(got, exp):
+                assert g[0] == x[0] and g[1] == x[1]
+                assert np.array_equal(np.asarray(g[2]).view(np.uint32), np.asarray(x[2]).view(np.uint32))
+
+
+@pytest.mark.parametrize("n_events,cfg", [(700, "c3"), (2048 + 300, "c3"), (1500, "c5")])
+def test_ragged_brick_layout(n_events, cfg):
+    """Sparse random occupancy (configs 3-5): every event's product list, replayed from the brick
+    stream, equals its reference-layout run: same parameters, same order, same coefficient bits."""
+    spec = synth.CONFIGS[cfg].scaled(n_events)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, n_events)
+    rc, err, lay = debug_layout(spec.n_params, spec.n_knots, npts, ch)
+    assert rc == 0, err
+    assert lay["n_bricks"] == (n_events + 1023) // 1024 and lay["n_tiles"] == 0
+    check_bricks(npts, ch, lay)
+
+
+def test_mixed_uniform_and_ragged_groups():
+    """A chunk whose first 1024 events are dense and whose tail is ragged: uniform tiles and a
+    brick side by side, stages split at the 8192-response cap."""
+    P = 12
+    X7 = np.arange(-3.0, 4.0)
+    rng = np.random.default_rng(7)
+    quad = lambda: natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))
+    events = []
+    for e in range(1024):
+        events.append([(p, "spl", quad()) if p % 3 else (p, "tf1", (0.1 * rng.standard_normal(), 1.0)) for p in range(P)])
+    for e in range(900):
+        events.append([(p, "spl", quad()) if p % 3 else (p, "tf1", (0.1 * rng.standard_normal(), 1.0))
+                       for p in range(P) if rng.random() < 0.9])
+    cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P) if p % 3}, events)
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0, err
+    assert lay["n_tiles"] == 4 and lay["n_bricks"] == 1
+    check_uniform_tiles(P, 7, npts, ch, lay)
+    check_bricks(npts, ch, lay)
+    w = lay["words"]
+    assert int(w[0]) >= 2  # ~7000 spline responses + TF1s: at least one TSpline3 and one TF1 stage
+
+
+def test_ragged_requires_ascending_parameters():
+    X7 = np.arange(-3.0, 4.0)
+    c = natural_cubic(X7, 1 + 0.1 * X7)
+    events = [[(0, "spl", c), (1, "spl", c)], [(1, "spl", c), (0, "spl", c)]]  # second event descending
+    cx, npts, ch = make_monolith(2, 7, {0: X7, 1: X7}, events)
+    rc, err, _ = debug_layout(2, 7, npts, ch)
+    assert rc != 0 and "ascending" in err
