@@ -285,11 +285,18 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 // staging array; phase B lets every event multiply its slice in ascending parameter order.
 // HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
 // ------------------------------------------------------------------------------------
-constexpr int kBrickEvPerLane = M3_GROUP / 256;
+constexpr int kBrickThreads = M3_GROUP;                      // one lane per event in phase B
+constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;  // 8 responses per lane in phase A
+
+struct RRun {      // per-step resolved run: address = base + r, dx of the run's parameter
+  int32_t base;    // coef_off + seg * n_run - start_r   (float4 units from the brick's store)
+  float dx;
+};
 
 template <int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_reweight_brick(ReweightArgs a) {
+__global__ __launch_bounds__(kBrickThreads) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
+  __shared__ RRun lds_runs[M3_BRICK_MAX_RUNS];
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
@@ -297,87 +304,91 @@ __global__ __launch_bounds__(256) void k_reweight_brick(ReweightArgs a) {
 
   if (MODE & kModeFill) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
-    for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
+    for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
 
-  float w[kBrickEvPerLane];
-#pragma unroll
-  for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
-
+  float w = 1.0f;  // SplineMonolith.cpp:798; lane = event of the brick
   const uint32_t n_stages = words[0];
   for (uint32_t s = 0; s < n_stages; ++s) {
     const uint32_t* __restrict__ h = words + 1 + M3_STAGE_HDR * s;
     const uint32_t kind = h[0], n_resp = h[1];
     if (kind == 0) {
+      // resolve the stage's runs for this step: one lane per run
       const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
-      const uint32_t* __restrict__ resp = words + h[4];
-      constexpr int U = 4;
-      uint32_t r = lane;
-      for (; r + (U - 1) * 256 < n_resp; r += U * 256) {
-        float4 c[U];
-        float dx[U];
-        uint32_t dst[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t m = resp[r + u * 256];
-          const uint4 rt = runs[m & 0xFFFFu];  // {coef_off, n_run, start_r, param}
-          const PTab pt = a.ptab[rt.w];
-          c[u] = stream_load<NT>(&bd.spl[(size_t)rt.x + (size_t)pt.seg * rt.y + (r + u * 256 - rt.z)]);
-          dx[u] = pt.dx;
-          dst[u] = m >> 16;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) stage_w[dst[u]] = spline_poly(dx[u], c[u]);
-      }
-      for (; r < n_resp; r += 256) {
-        const uint32_t m = resp[r];
-        const uint4 rt = runs[m & 0xFFFFu];
+      if (lane < h[2]) {
+        const uint4 rt = runs[lane];  // {coef_off, n_run, start_r, param}
         const PTab pt = a.ptab[rt.w];
-        const float4 c = stream_load<NT>(&bd.spl[(size_t)rt.x + (size_t)pt.seg * rt.y + (r - rt.z)]);
-        stage_w[m >> 16] = spline_poly(pt.dx, c);
+        RRun rr;
+        rr.base = (int32_t)(rt.x + (uint32_t)pt.seg * rt.y) - (int32_t)rt.z;
+        rr.dx = pt.dx;
+        lds_runs[lane] = rr;
+      }
+      __syncthreads();
+      // phase A: all of the lane's responses are in flight at once (no dependent global look-up
+      // between the response word and its coefficient load)
+      const uint32_t* __restrict__ resp = words + h[4];
+      uint32_t m[kBrickRespPerLane];
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        m[u] = r < n_resp ? resp[r] : 0xFFFFFFFFu;
+      }
+      float4 c[kBrickRespPerLane];
+      float dx[kBrickRespPerLane];
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        if (r < n_resp) {
+          const RRun rr = lds_runs[m[u] & 0xFFFFu];
+          c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(rr.base + (int32_t)r)]);
+          dx[u] = rr.dx;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        if (r < n_resp) stage_w[m[u] >> 16] = spline_poly(dx[u], c[u]);
       }
     } else {
       const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
       const float2* __restrict__ tp = bd.tf1 + h[6];
-      for (uint32_t r = lane; r < n_resp; r += 256) {
-        const float x = a.pval[par[r]];
-        const float2 c = stream_load<NT>(&tp[r]);
-        stage_w[r] = fmaf(c.x, x, c.y);  // SplineMonolith.cpp:779
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        if (r < n_resp) {
+          const float x = a.pval[par[r]];
+          const float2 c = stream_load<NT>(&tp[r]);
+          stage_w[r] = fmaf(c.x, x, c.y);  // SplineMonolith.cpp:779
+        }
       }
     }
     __syncthreads();
-    const uint32_t* __restrict__ evt = words + h[5];
-#pragma unroll
-    for (int q = 0; q < kBrickEvPerLane; ++q) {
-      const uint32_t e = lane * kBrickEvPerLane + q;
-      if (e < bd.n_events) {
-        const uint32_t ec = evt[e];
-        const uint32_t start = ec & 0xFFFFu, cnt = ec >> 16;
-        for (uint32_t i = 0; i < cnt; ++i) w[q] *= stage_w[start + i];  // ascending parameter = reference order
-      }
+    // phase B: the event's slice of the staging array, ascending parameter = reference order
+    if (lane < bd.n_events) {
+      const uint32_t ec = words[h[5] + lane];
+      const uint32_t start = ec & 0xFFFFu, cnt = ec >> 16;
+      for (uint32_t i = 0; i < cnt; ++i) w *= stage_w[start + i];
     }
     __syncthreads();
   }
   if (MODE & kModeFill) __syncthreads();  // lds_hist zeroing is complete even for a brick without stages
 
-#pragma unroll
-  for (int q = 0; q < kBrickEvPerLane; ++q) {
-    const uint32_t e = lane * kBrickEvPerLane + q;
-    const uint64_t ev = (uint64_t)bd.first_event + e;
-    if (MODE & kModeEval) a.spline_w[ev] = w[q];
+  {
+    const uint64_t ev = (uint64_t)bd.first_event + lane;
+    if (MODE & kModeEval) a.spline_w[ev] = w;
     if (MODE & (kModeFill | kModeEventW)) {
       float tw = 1.0f;  // CalcWeightTotal, as in k_reweight_uniform
-      for (uint32_t m = 0; m < a.n_norm_slots; ++m) {
-        const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
+      for (uint32_t mm = 0; mm < a.n_norm_slots; ++mm) {
+        const int idx = a.nidx[(uint64_t)mm * a.e_pad + ev];
         if (idx >= 0) tw *= static_cast<float>(a.params[idx]);
       }
       const int oi = a.osc[ev];
       if (oi >= 0) tw *= a.osc_table[oi];
-      tw *= w[q];
+      tw *= w;
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
         const int b = a.bin[ev];
-        if (e < bd.n_events && tw > 0.f && b >= 0) {
+        if (lane < bd.n_events && tw > 0.f && b >= 0) {
           atomicAdd(&lds_hist[b], (double)tw);
           if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
         }
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256) void k_reweight_brick(ReweightArgs a) {
     __syncthreads();
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
-    for (int i = lane; i < nb; i += 256) {
+    for (int i = lane; i < nb; i += kBrickThreads) {
       const double v = lds_hist[i];
       const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
       if (v != 0.0) atomicAdd(&a.hist[slot], v);
@@ -398,8 +409,8 @@ __global__ __launch_bounds__(256) void k_reweight_brick(ReweightArgs a) {
 
 template <int MODE>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true>), g, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((k_reweight_brick<MODE, false>), g, dim3(256), lds, s, a);
+  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true>), g, dim3(kBrickThreads), lds, s, a);
+  else hipLaunchKernelGGL((k_reweight_brick<MODE, false>), g, dim3(kBrickThreads), lds, s, a);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {

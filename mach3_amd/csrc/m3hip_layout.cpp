@@ -110,8 +110,12 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
     int p0 = 0;
     while (p0 < n_params) {
       int p1 = p0;
-      uint32_t tot = 0;
-      while (p1 < n_params && tot + (cnt[p1 + 1] - cnt[p1]) <= uint32_t(M3_BRICK_CAP)) { tot += cnt[p1 + 1] - cnt[p1]; ++p1; }
+      uint32_t tot = 0, runs = 0;
+      while (p1 < n_params && tot + (cnt[p1 + 1] - cnt[p1]) <= uint32_t(M3_BRICK_CAP) && runs < uint32_t(M3_BRICK_MAX_RUNS)) {
+        tot += cnt[p1 + 1] - cnt[p1];
+        runs += (cnt[p1 + 1] != cnt[p1]);
+        ++p1;
+      }
       if (p1 == p0) ++p1;  // cannot happen: a run holds at most M3_GROUP <= M3_BRICK_CAP responses
       if (tot > 0) st.push_back({p0, p1});
       p0 = p1;

@@ -37,6 +37,7 @@ namespace m3hip {
 constexpr int M3_TE = 256;       // events per tile (= workgroup size of the reweight kernels)
 constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
 constexpr int M3_BRICK_CAP = 8192;  // responses per brick stage (= floats of LDS staging)
+constexpr int M3_BRICK_MAX_RUNS = 1024;  // runs per stage (resolved run table lives in LDS)
 constexpr int M3_STAGE_HDR = 8;     // words per stage header
 constexpr int M3_RUN_WORDS = 4;     // words per run entry
 
