@@ -36,6 +36,12 @@ clean:
 
 .PHONY: all oracle clean isa
 
-examples:
-	@true
+# C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
+examples: build/mr2t2_dragrace
+
+build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude -o $@ examples/mr2t2_dragrace.cpp -L$(LIBDIR) -lm3hip -lm3synth \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
 .PHONY: examples

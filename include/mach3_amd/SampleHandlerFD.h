@@ -1,0 +1,239 @@
+// SampleHandlerFD.h -- the sample operator of the per-step path on the GPU.
+//
+//   SampleHandlerBase  Samples/SampleHandlerBase.h:37-56, 181-185 (what a fitter calls per step)
+//   BinningHandler     Samples/BinningHandler.h (uniform N-D binning: FindGlobalBin /
+//                      FindNominalBin, Samples/BinningHandler.cpp:257-355, SampleStructs.h:577-613)
+//   SampleHandlerFD    Samples/SampleHandlerFD.h:21-413 -- only the per-step surface: Reweight,
+//                      GetLikelihood, GetSampleLikelihood, GetMCArray / GetW2Array / GetDataArray,
+//                      AddData, SetTestStatistic.  Configuration (YAML), ROOT I/O, plotting
+//                      projections and functional-parameter callbacks are out of scope; events
+//                      are registered through AddEvent*/FinaliseEvents instead of SetupExperimentMC.
+//
+// Reweight() runs spline evaluation, weight product, bin fill and (on GetLikelihood) the bin
+// likelihood on the device; per step only the proposed parameter values cross PCIe.
+#pragma once
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../m3hip.h"
+#include "Core.h"
+#include "SplineMonolith.h"
+
+/// ref: Samples/SampleHandlerBase.h:37-56
+class SampleHandlerBase {
+ public:
+  virtual ~SampleHandlerBase() {}
+  virtual M3::int_t GetNsamples() { return nSamples; }
+  virtual std::string GetName() const = 0;
+  virtual std::string GetSampleTitle(const int Sample) const = 0;
+  virtual void Reweight() = 0;
+  virtual double GetLikelihood() const = 0;
+  virtual double GetSampleLikelihood(const int isample) const = 0;
+  virtual void CleanMemoryBeforeFit() = 0;
+  virtual void PrintRates(const bool DataOnly = false) = 0;
+  void SetTestStatistic(TestStatistic testStat) { fTestStatistic = testStat; TestStatisticChanged(); }
+
+ protected:
+  virtual void TestStatisticChanged() {}
+  TestStatistic fTestStatistic = kPoisson;
+  M3::int_t nSamples = 0;
+  unsigned int nEvents = 0;
+};
+
+/// Uniform N-dimensional binning of several samples in one global bin space.
+class BinningHandler {
+ public:
+  /// edges[dim] = increasing bin edges of that axis; returns the sample index
+  int AddUniformSample(const std::vector<std::vector<double>>& edges) {
+    for (const auto& e : edges)
+      if (e.size() < 2 || !std::is_sorted(e.begin(), e.end())) throw MaCh3Exception(__FILE__, __LINE__, "bin edges must be increasing");
+    Sample s;
+    s.Edges = edges;
+    int stride = 1;
+    for (const auto& e : edges) {
+      s.Strides.push_back(stride);
+      stride *= int(e.size()) - 1;
+    }
+    s.nBins = stride;
+    s.GlobalOffset = TotalBins;
+    TotalBins += s.nBins;
+    Samples.push_back(std::move(s));
+    return int(Samples.size()) - 1;
+  }
+  int GetNBins() const { return TotalBins; }
+  int GetNBins(int Sample) const { return Samples[Sample].nBins; }
+  int GetNSamples() const { return int(Samples.size()); }
+  int GetNDim(int Sample) const { return int(Samples[Sample].Edges.size()); }
+  int GetSampleStartBin(int Sample) const { return Samples[Sample].GlobalOffset; }
+  int GetSampleEndBin(int Sample) const { return Samples[Sample].GlobalOffset + Samples[Sample].nBins; }
+  /// ref: Samples/BinningHandler.cpp:294-307
+  int FindNominalBin(int iSample, int iDim, double Var) const {
+    const auto& e = Samples[iSample].Edges[iDim];
+    if (Var < e.front() || Var >= e.back()) return M3::UnderOverFlowBin;
+    return int(std::upper_bound(e.begin(), e.end(), Var) - e.begin()) - 1;
+  }
+  /// Bins are [lo, hi); a value outside any axis gives UnderOverFlowBin.  NomBin is the cached
+  /// nominal bin per axis (ref: Samples/SampleStructs.h:577-613: nominal, +-1 neighbour, then
+  /// upper_bound; all four routes return the same index, the fast ones just skip the search).
+  int FindGlobalBin(int NomSample, const std::vector<const double*>& KinVar, const std::vector<int>& NomBin) const {
+    const Sample& s = Samples[NomSample];
+    int Global = 0;
+    for (size_t d = 0; d < KinVar.size(); ++d) {
+      const auto& e = s.Edges[d];
+      const double v = *KinVar[d];
+      const int n = int(e.size()) - 1;
+      if (v < e[0] || v >= e[n]) return M3::UnderOverFlowBin;
+      int b = NomBin[d];
+      if (!(b > M3::UnderOverFlowBin && v >= e[b] && v < e[b + 1])) {
+        if (b > 0 && v < e[b] && v >= e[b - 1]) b = b - 1;
+        else if (b > M3::UnderOverFlowBin && b + 2 <= n && v >= e[b + 1] && v < e[b + 2]) b = b + 1;
+        else b = int(std::upper_bound(e.begin(), e.end(), v) - e.begin()) - 1;
+      }
+      Global += b * s.Strides[d];
+    }
+    return Global + s.GlobalOffset;
+  }
+  std::vector<int32_t> SampleBinOffsets() const {
+    std::vector<int32_t> off;
+    for (const auto& s : Samples) off.push_back(s.GlobalOffset);
+    off.push_back(TotalBins);
+    return off;
+  }
+
+ private:
+  struct Sample {
+    std::vector<std::vector<double>> Edges;
+    std::vector<int> Strides;
+    int nBins = 0, GlobalOffset = 0;
+  };
+  std::vector<Sample> Samples;
+  int TotalBins = 0;
+};
+
+class SampleHandlerFD : public SampleHandlerBase {
+ public:
+  /// `Splines` keeps ownership of the device handle; `ParameterValues` plays
+  /// ParameterHandlerBase::_fPropVal (read at every Reweight, like the reference's pointers).
+  SampleHandlerFD(std::string Name, std::unique_ptr<SMonolith> Splines, std::unique_ptr<BinningHandler> Bins,
+                  const double* ParameterValues, int nParameters, bool UpdateW2_ = false)
+      : SampleName(std::move(Name)), SplineHandler(std::move(Splines)), Binning(std::move(Bins)), fPropVal(ParameterValues),
+        nPar(nParameters), UpdateW2(UpdateW2_) {
+    h = SplineHandler->Handle();
+    nSamples = M3::int_t(Binning->GetNSamples());
+    nEvents = SplineHandler->GetNEvents();
+    const std::vector<int32_t> off = Binning->SampleBinOffsets();
+    M3HIP_CALL(h, m3hip_set_binning(h, nSamples, off.data()));
+    M3HIP_CALL(h, m3hip_set_test_statistic(h, int(fTestStatistic), UpdateW2 ? 1 : 0));
+    bin_idx.assign(nEvents, M3::UnderOverFlowBin);
+    osc_idx.assign(nEvents, -1);
+    norm_off.assign(size_t(nEvents) + 1, 0);
+  }
+
+  /// Which entry of the parameter vector drives spline parameter i (SMonolith::setSplinePointers)
+  void SetSplineParameterIndices(const std::vector<int32_t>& idx) { M3HIP_CALL(h, m3hip_set_spline_param_map(h, idx.data(), int(idx.size()))); }
+
+  /// Per-event set-up, in event order: the binning variables, the normalisation parameters
+  /// that apply (indices into the parameter vector -> norm_pointers) and the event's entry in
+  /// the oscillation-weight table (-1: no oscillation weight, e.g. NC; ref:
+  /// Samples/SampleHandlerFD.cpp:637-663, 1108-1133).
+  void AddEvent(unsigned int iEvent, int Sample, const std::vector<double>& KinVars, const std::vector<int16_t>& NormParams, int OscIndex) {
+    if (iEvent != n_added) throw MaCh3Exception(__FILE__, __LINE__, "events must be added in order");
+    std::vector<const double*> kv;
+    std::vector<int> nom;
+    for (size_t d = 0; d < KinVars.size(); ++d) {
+      kv.push_back(&KinVars[d]);
+      nom.push_back(Binning->FindNominalBin(Sample, int(d), KinVars[d]));
+    }
+    bin_idx[iEvent] = Binning->FindGlobalBin(Sample, kv, nom);
+    osc_idx[iEvent] = OscIndex;
+    norm_idx.insert(norm_idx.end(), NormParams.begin(), NormParams.end());
+    norm_off[iEvent + 1] = norm_idx.size();
+    ++n_added;
+  }
+  void FinaliseEvents() {
+    if (n_added != nEvents) throw MaCh3Exception(__FILE__, __LINE__, "not every event was added");
+    M3HIP_CALL(h, m3hip_upload_events(h, 0, nEvents, bin_idx.data(), osc_idx.data(), norm_off.data(), norm_idx.data()));
+  }
+  /// weights OscillationHandler::Evaluate would have left behind the event pointers
+  void SetOscillationWeights(const std::vector<float>& w) { M3HIP_CALL(h, m3hip_set_osc_table(h, w.data(), w.size())); }
+
+  // ---- per step (ref: Samples/SampleHandlerFD.cpp:316-343, 1262-1300)
+  void Reweight() override { M3HIP_CALL(h, m3hip_reweight(h, fPropVal, nPar)); }
+  double GetLikelihood() const override {
+    double llh = 0;
+    per_sample.assign(size_t(nSamples), 0.0);
+    M3HIP_CALL(h, m3hip_get_likelihood(h, &llh, per_sample.data()));
+    return llh;
+  }
+  double GetSampleLikelihood(const int isample) const override {
+    GetLikelihood();
+    return per_sample.at(size_t(isample));
+  }
+
+  // ---- data and predictions (ref: Samples/SampleHandlerFD.h:162-187, .cpp:1027-1044)
+  void AddData(const int Sample, const std::vector<double>& Data) {
+    if (int(Data.size()) != Binning->GetNBins(Sample)) throw MaCh3Exception(__FILE__, __LINE__, "AddData: wrong number of bins");
+    if (data.empty()) data.assign(size_t(Binning->GetNBins()), 0.0);
+    std::copy(Data.begin(), Data.end(), data.begin() + Binning->GetSampleStartBin(Sample));
+    M3HIP_CALL(h, m3hip_set_data(h, data.data(), int(data.size())));
+  }
+  std::vector<double> GetMCArray(const int Sample) const { return Slice(Bins(true), Sample); }
+  std::vector<double> GetW2Array(const int Sample) const { return Slice(Bins(false), Sample); }
+  std::vector<double> GetDataArray(const int Sample) const { return Slice(data, Sample); }
+  std::vector<double> GetMCArray() const { return Bins(true); }
+  std::vector<double> GetW2Array() const { return Bins(false); }
+
+  std::string GetName() const override { return SampleName; }
+  std::string GetSampleTitle(const int Sample) const override { return SampleName + "_" + std::to_string(Sample); }
+  void CleanMemoryBeforeFit() override {
+    std::vector<int32_t>().swap(bin_idx);
+    std::vector<int32_t>().swap(osc_idx);
+    std::vector<uint64_t>().swap(norm_off);
+    std::vector<int16_t>().swap(norm_idx);
+  }
+  void PrintRates(const bool DataOnly = false) override {
+    const std::vector<double> mc = Bins(true);
+    for (int s = 0; s < nSamples; ++s) {
+      double d = 0, m = 0;
+      for (int b = Binning->GetSampleStartBin(s); b < Binning->GetSampleEndBin(s); ++b) {
+        if (!data.empty()) d += data[size_t(b)];
+        m += mc[size_t(b)];
+      }
+      if (DataOnly) std::printf("%s: data %.3f\n", GetSampleTitle(s).c_str(), d);
+      else std::printf("%s: data %.3f  MC %.3f\n", GetSampleTitle(s).c_str(), d, m);
+    }
+  }
+  const BinningHandler* GetBinning() const { return Binning.get(); }
+  SMonolith* GetSplineHandler() { return SplineHandler.get(); }
+
+ protected:
+  void TestStatisticChanged() override { M3HIP_CALL(h, m3hip_set_test_statistic(h, int(fTestStatistic), UpdateW2 ? 1 : 0)); }
+
+ private:
+  std::vector<double> Bins(bool mc) const {
+    std::vector<double> a(size_t(Binning->GetNBins())), b(a.size());
+    M3HIP_CALL(h, m3hip_get_bins(h, a.data(), b.data(), int(a.size())));
+    return mc ? a : b;
+  }
+  std::vector<double> Slice(const std::vector<double>& all, int Sample) const {
+    if (all.empty()) return {};
+    return std::vector<double>(all.begin() + Binning->GetSampleStartBin(Sample), all.begin() + Binning->GetSampleEndBin(Sample));
+  }
+
+  std::string SampleName;
+  std::unique_ptr<SMonolith> SplineHandler;
+  std::unique_ptr<BinningHandler> Binning;
+  const double* fPropVal;
+  int nPar;
+  bool UpdateW2;
+  m3hip_handle h = nullptr;
+  std::vector<int32_t> bin_idx, osc_idx;
+  std::vector<uint64_t> norm_off;
+  std::vector<int16_t> norm_idx;
+  std::vector<double> data;
+  mutable std::vector<double> per_sample;
+  unsigned int n_added = 0;
+};
