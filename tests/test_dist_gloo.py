@@ -1,0 +1,103 @@
+"""N > 1 path on CPUs: world_size-2 gloo.  Each rank takes its event shard, fills its partial
+bin vector (the oracle stands in for the device here), one all-reduce, then every rank
+evaluates the same likelihood -- which must equal the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_events, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import oracle_binding as ob
+    from mach3_amd import capi, dist as m3dist, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
+    e0, e1 = m3dist.shard_ranges(n_events, world)[rank]
+    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, e0, e1)
+    lib = ob.load("serial")
+    out = []
+    data = None
+    for lap in (0, 1, 2):
+        par[:] = synth.params(spec, lap)
+        samp.reweight()
+        mc, w2 = samp.mc, samp.w2
+        m3dist.allreduce_bins(mc, w2)
+        if lap == 0:
+            data = mc.copy()
+        llh = sum(lib.m3o_test_stat_llh(capi.kBarlowBeeston, data[i], mc[i], w2[i]) for i in range(len(mc)))
+        out.append((llh, mc.sum()))
+    q.put((rank, (e0, e1), out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_event_sharding_matches_unsharded():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    from mach3_amd import capi, synth
+
+    n_events, world = 5000, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_events, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # shards tile the sample on 1024-event boundaries
+    assert res[0][1] == (0, 3072) and res[1][1] == (3072, 5000)
+    # unsharded reference
+    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
+    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
+    samp.set_test_statistic(capi.kBarlowBeeston)
+    exp = []
+    for lap in (0, 1, 2):
+        par[:] = synth.params(spec, lap)
+        samp.reweight()
+        if lap == 0:
+            samp.add_data(samp.mc)
+        exp.append((samp.get_likelihood(), samp.mc.sum()))
+    for rank in range(world):
+        for (llh, tot), (ellh, etot) in zip(res[rank][2], exp):
+            assert tot == pytest.approx(etot, rel=1e-12)
+            assert abs(llh - ellh) <= 1e-9 * max(abs(ellh), 1.0)
+    assert res[0][2] == res[1][2]  # every rank holds the identical all-reduced result
+
+
+def test_shard_ranges():
+    from mach3_amd.dist import shard_ranges
+
+    r = shard_ranges(10_000_000, 8)
+    assert r[0][0] == 0 and r[-1][1] == 10_000_000
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert all((a[1] - a[0]) % 1024 == 0 for a in r[:-1])
+    assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 8 * 1024
+    # weighted: the heavy second half gets more ranks
+    w = np.ones(81920)
+    w[40960:] = 3.0
+    rw = shard_ranges(81920, 4, w)
+    loads = [w[a:b].sum() for a, b in rw]
+    assert max(loads) / min(loads) < 1.1 and rw[-1][1] == 81920 and rw[0][1] == 40960
+    assert shard_ranges(100, 4)[0] == (0, 100)  # fewer events than one group: rank 0 holds them all
