@@ -788,7 +788,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     h->pending = 0;
   }
   HIPCHK(h, hipGetLastError());
-  if (h->comm && h->n_ranks > 1) {
+  if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
     const size_t count = size_t(h->n_bins) * h->hist_rep * (h->first_w2 ? 2 : 1);
     int r = g_rccl.AllReduce(h->d_hist, h->d_hist, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));

@@ -409,3 +409,23 @@ def test_uniform_and_ragged_groups_in_one_sample(fresh_engine):
         assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
     assert mono.cpu_total_weights[1100] == 1.0 and mono.cpu_total_weights[1500] == 1.0
     omono.close()
+
+
+def test_in_library_rccl_allreduce_single_rank(fresh_engine):
+    """m3hip_comm_init + the per-step ncclAllReduce on a one-rank communicator: the RCCL code path
+    (dlopen, ncclCommInitRank, in-place f64 sum on the engine's stream) runs and changes nothing."""
+    spec = synth.CONFIGS["c2"].scaled(4000, n_params=16)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    sh.Reweight()
+    sh.AddData(sh.GetMCArray())
+    par[:] = synth.params(spec, 2)
+    ref = sh.Step()
+    mc_ref = sh.GetMCArray()
+    uid = eng.comm_unique_id()
+    assert len(uid) == capi.UNIQUE_ID_BYTES
+    eng.comm_init(uid, 0, 1)
+    got = sh.Step()
+    assert got == pytest.approx(ref, rel=1e-12)
+    assert np.allclose(sh.GetMCArray(), mc_ref, rtol=1e-12)
+    with pytest.raises(capi.M3HipError):
+        eng.comm_init(uid, 3, 2)   # rank out of range
