@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--events", type=int, default=0, help="override events per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--spinup-seconds", type=float, default=2.0,
+                    help="untimed steps before the warm-up: the first ~1 s of GPU work on a fresh process shows one-off "
+                         "50-100 ms stalls (clock / runtime ramp-up) that would otherwise land in a short timed region")
     args = ap.parse_args()
 
     import torch  # device sync + torch.distributed (RCCL) plumbing only
@@ -166,6 +169,11 @@ def main():
         par[:] = laps[i % len(laps)]
         return sh.Step()
 
+    t_spin = time.perf_counter()
+    n_spin = 0
+    while time.perf_counter() - t_spin < args.spinup_seconds:
+        step(n_spin)
+        n_spin += 1
     for i in range(args.warmup):
         step(i)
     eng.timing_enable(True)

@@ -142,6 +142,12 @@ int main(int argc, char** argv) {
     std::mt19937_64 rng(1234);
     std::normal_distribution<double> gaus(0.0, 1.0);
     double t_rw = 0, t_llh = 0;
+    // spin-up: a fresh process shows one-off 50-100 ms stalls in its first second of GPU work
+    for (const double t_s = now_s(); now_s() - t_s < 1.0;) {
+      for (int i = 0; i < nPar; ++i) par[i] = nominal[i] + 0.3 * sigma[i] * gaus(rng);
+      sample.Reweight();
+      (void)sample.GetLikelihood();
+    }
     for (int lap = 0; lap < NLaps + 10; ++lap) {
       for (int i = 0; i < nPar; ++i) par[i] = nominal[i] + 0.3 * sigma[i] * gaus(rng);
       const double a = now_s();

@@ -228,6 +228,11 @@ int m3hip_debug_set_hist_replicas(m3hip_handle h, int n);
  * {stage params, launch prep, launch reweight(+all-reduce), launch llh, wait, collect}. */
 int m3hip_debug_host_times(m3hip_handle h, double* out6);
 
+/* Diagnostics: device-side time (us, 100 MHz wall clock) from the start of k_prep to the end of
+ * k_llh of the last step; enable = 1 allocates the two clock words.  last_us[5] = {span, device
+ * clock at k_prep start, at k_llh end, host clock at the k_prep launch, at completion seen}. */
+int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us);
+
 /* Host-only probe of the upload re-layout (no device needed): sizes[6] = {n_tiles,
  * spline store in float4, TF1 store in float2, slot-meta in int32, n_bricks, brick words};
  * with non-NULL output buffers of those sizes it also fills them,

@@ -22,7 +22,7 @@ M3HIP_SYMBOLS = [
     "m3hip_get_bins", "m3hip_get_spline_weights", "m3hip_record_event_weights", "m3hip_get_event_weights",
     "m3hip_get_segments",
     "m3hip_comm_get_unique_id", "m3hip_comm_init", "m3hip_comm_destroy",
-    "m3hip_debug_layout", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas",
+    "m3hip_debug_layout", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
     "m3hip_get_info", "m3hip_timing_enable", "m3hip_timing_read", "m3hip_timing_reset", "m3hip_version",
 ]
 
@@ -124,6 +124,7 @@ def load_m3hip():
         "m3hip_debug_host_times": [vp, vp],
         "m3hip_debug_set_knobs": [vp, i32, i32, i32],
         "m3hip_debug_set_hist_replicas": [vp, i32],
+        "m3hip_debug_device_span": [vp, i32, C.POINTER(C.c_double)],
         "m3hip_debug_layout": [i32, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():

@@ -94,9 +94,13 @@ struct m3hip_ctx {
   bool parmap_set = false;
   double* h_params[kRing] = {nullptr, nullptr, nullptr, nullptr};  // pinned, device-mapped
   double* d_params_src[kRing] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
-  bool ring_used[kRing] = {false, false, false, false};
+  uint64_t ring_ticket[kRing] = {0, 0, 0, 0};  // step that last used the slot
   int ring_pos = 0;
+  uint64_t ticket = 0;       // steps submitted
+  uint64_t ticket_done = 0;  // steps known to have completed
+  uint64_t llh_ticket = 0;
+  uint64_t* d_dbg_clock = nullptr;  // 2 x uint64 device words (diagnostics)
+  double dbg_dev_us = 0;            // device-side k_prep start -> k_llh end of the last step
   int par_cap = 0;
   double* d_params = nullptr;  // [par_cap + 1]
   float* h_vals = nullptr;     // pinned staging for the vals/segments path
@@ -122,7 +126,7 @@ struct m3hip_ctx {
   int hist_rep = 32;
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
-  double* h_out = nullptr;  // pinned, device-mapped: [1 + n_samples]
+  double* h_out = nullptr;  // pinned, device-mapped: [1 + n_samples], then one uint64 ticket word
   double* d_out = nullptr;
   bool want_event_w = false;
 
@@ -138,6 +142,7 @@ struct m3hip_ctx {
   uint64_t cnt[2] = {0, 0};
   ReweightKnobs knobs;
   double host_t[6] = {0, 0, 0, 0, 0, 0};  // host-side seconds of the last step's phases (debug)
+  double host_abs[2] = {0, 0};             // absolute host time (s): k_prep launch call, flag seen
 };
 
 namespace {
@@ -203,7 +208,7 @@ int ensure_param_capacity(m3hip_handle h, int n_par) {
     if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
     HIPCHK(h, hipHostMalloc((void**)&h->h_params[i], sizeof(double) * n_par, hipHostMallocMapped));
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_params_src[i], h->h_params[i], 0));
-    h->ring_used[i] = false;
+    h->ring_ticket[i] = 0;
   }
   dev_free(h->d_params);
   int rc = dev_alloc(h, &h->d_params, size_t(n_par) + 1);
@@ -300,7 +305,6 @@ int m3hip_create(int device_id, m3hip_handle* out) {
     delete h;
     return fail(nullptr, M3HIP_EHIP, "device initialisation failed: " + m);
   }
-  for (int i = 0; i < kRing; ++i) (void)hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming);
   h->stream = h->own_stream;
   *out = h;
   return M3HIP_OK;
@@ -314,7 +318,6 @@ int m3hip_destroy(m3hip_handle h) {
   free_monolith(h);
   for (int i = 0; i < kRing; ++i) {
     if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
-    if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
   }
   dev_free(h->d_params);
   dev_free(h->d_osc_table);
@@ -634,7 +637,8 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
   HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
-  HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (1 + n_samples), hipHostMallocMapped));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (2 + n_samples), hipHostMallocMapped));
+  memset(h->h_out, 0, sizeof(double) * (2 + n_samples));
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_out, h->h_out, 0));
   h->n_bins = nb;
   h->n_samples = n_samples;
@@ -738,7 +742,11 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   // stage the proposed values; the slot is free once the k_prep that read it has run
   const int slot = h->ring_pos;
   h->ring_pos = (h->ring_pos + 1) % kRing;
-  if (h->ring_used[slot]) HIPCHK(h, hipEventSynchronize(h->ring_ev[slot]));
+  if (h->ring_ticket[slot] > h->ticket_done) {  // the k_prep that read this slot may still be pending
+    HIPCHK(h, wait_stream(h->stream));
+    h->ticket_done = h->ticket;
+  }
+  h->ring_ticket[slot] = ++h->ticket;
   memcpy(h->h_params[slot], params, sizeof(double) * n_par);
 
   PrepArgs p;
@@ -760,15 +768,15 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   p.n_bins = h->n_bins;
   p.reset_hist = 1;
   p.reset_w2 = h->first_w2 ? 1 : 0;
+  p.dbg_clock = h->d_dbg_clock;
   p.u_param = h->d_u_param;
   p.u_plane0 = h->d_u_plane0;
   p.resolved = h->d_resolved;
   p.n_res = h->n_res <= kInlineResolveMax ? h->n_res : 0;
   const double t_b = now_s();
+  h->host_abs[0] = t_b;
   launch_prep(p, h->stream);
   if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
-  HIPCHK(h, hipEventRecord(h->ring_ev[slot], h->stream));
-  h->ring_used[slot] = true;
   const double t_c = now_s();
 
   ReweightArgs a = make_rw_args(h);
@@ -814,12 +822,37 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.sample_off = h->d_sample_off;
   l.kind = h->teststat;
   l.out = h->d_out;
+  // completion is signalled through host memory: k_llh writes the results, then this ticket
+  volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(h->h_out + 1 + h->n_samples);
+  l.done_flag = reinterpret_cast<volatile uint64_t*>(h->d_out + 1 + h->n_samples);
+  l.ticket = ++h->llh_ticket;
+  l.dbg_clock = h->d_dbg_clock;
   const double t_a = now_s();
   launch_llh(l, h->stream);
   HIPCHK(h, hipGetLastError());
   const double t_b = now_s();
-  HIPCHK(h, wait_stream(h->stream));
+  {
+    // The host-memory flag gives the completion with PCIe-write latency; the periodic
+    // hipStreamQuery keeps the runtime submitting / retiring commands (with flag polling alone
+    // steps stalled intermittently for 0.4-0.9 ms) and surfaces device errors.
+    const double t0 = now_s();
+    uint64_t spins = 0;
+    (void)hipStreamQuery(h->stream);
+    while (*flag != l.ticket) {
+      if ((++spins & 0xFFu) == 0) {
+        hipError_t e = hipStreamQuery(h->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return fail(h, M3HIP_EHIP, std::string("get_likelihood: ") + hipGetErrorString(e));
+        if (e == hipSuccess && *flag != l.ticket && now_s() - t0 > 5.0) return fail(h, M3HIP_EHIP, "get_likelihood: kernel finished without publishing its result");
+        if (now_s() - t0 > 60.0) return fail(h, M3HIP_EHIP, "get_likelihood: timed out waiting for the device");
+      }
+    }
+  }
+  // Let the runtime retire the finished commands (non-blocking).  Without any query/sync call the
+  // HIP command list only grows and a later launch stalls for ~1 ms when it has to be trimmed.
+  (void)hipStreamQuery(h->stream);
+  h->ticket_done = h->ticket;  // everything submitted before k_llh has completed (stream order)
   const double t_c = now_s();
+  h->host_abs[1] = t_c;
   collect_timing(h);
   h->host_t[3] = t_b - t_a;
   h->host_t[4] = t_c - t_b;
@@ -955,6 +988,25 @@ int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) {
 int m3hip_debug_host_times(m3hip_handle h, double* out6) {
   if (!h || !out6) return M3HIP_EINVAL;
   for (int i = 0; i < 6; ++i) out6[i] = h->host_t[i];
+  return M3HIP_OK;
+}
+
+int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us) {
+  if (!h) return M3HIP_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (enable && !h->d_dbg_clock) {
+    HIPCHK(h, hipMalloc((void**)&h->d_dbg_clock, 16));
+    HIPCHK(h, hipMemset(h->d_dbg_clock, 0, 16));
+  }
+  if (last_us && h->d_dbg_clock) {
+    uint64_t c[2];
+    HIPCHK(h, hipMemcpy(c, h->d_dbg_clock, 16, hipMemcpyDeviceToHost));
+    last_us[0] = double(int64_t(c[1] - c[0])) * 0.01;  // wall_clock64 ticks at 100 MHz
+    last_us[1] = double(c[0]) * 0.01;                  // device clock (us) at k_prep start
+    last_us[2] = double(c[1]) * 0.01;                  // ... at k_llh end
+    last_us[3] = h->host_abs[0] * 1e6;                 // host clock (us) at the k_prep launch call
+    last_us[4] = h->host_abs[1] * 1e6;                 // ... when the completion flag was seen
+  }
   return M3HIP_OK;
 }
 

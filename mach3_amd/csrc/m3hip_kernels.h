@@ -95,6 +95,7 @@ struct PrepArgs {
   const int32_t* u_plane0;  // [n_res] first plane of the slot, -1 for a TF1 slot
   RSlot* resolved;          // [n_res]
   int32_t n_res;            // 0: resolution is done by k_resolve instead
+  uint64_t* dbg_clock;      // optional: [0] <- wall_clock64() at k_prep start (diagnostics)
   // histogram reset (ResetHistograms)
   double* hist;
   int32_t hist_rep;
@@ -112,6 +113,9 @@ struct LlhArgs {
   const int32_t* sample_off;  // [n_samples + 1]
   int32_t kind;
   double* out;  // [1 + n_samples] (device pointer, may be mapped pinned host memory)
+  uint64_t* dbg_clock;           // optional: [1] <- wall_clock64() at k_llh end
+  volatile uint64_t* done_flag;  // mapped pinned host word; set to `ticket` after `out` is written
+  uint64_t ticket;
 };
 
 void launch_prep(const PrepArgs& a, hipStream_t s);

@@ -21,6 +21,7 @@ namespace m3hip {
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   const int tid = threadIdx.x;
+  if (a.dbg_clock && tid == 0) a.dbg_clock[0] = wall_clock64();
   // ResetHistograms: mc always, w2 only while FirstTimeW2 (SampleHandlerFD.cpp:454-463)
   if (a.reset_hist) {
     const int n = a.hist_rep * a.n_bins;
@@ -559,6 +560,12 @@ __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
     for (int i = b0 + threadIdx.x; i < b1; i += 256) sacc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
     const double st = block_sum_256(sacc, scratch);
     if (threadIdx.x == 0) a.out[1 + s] = st;
+  }
+  // publish: results first, then the ticket the host is spinning on (system scope: host memory)
+  if (threadIdx.x == 0 && a.dbg_clock) a.dbg_clock[1] = wall_clock64();
+  if (threadIdx.x == 0 && a.done_flag) {
+    __threadfence_system();
+    *a.done_flag = a.ticket;
   }
 }
 
