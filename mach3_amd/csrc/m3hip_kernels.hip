@@ -536,10 +536,22 @@ __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   double* mc = const_cast<double*>(a.hist);
   double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
   for (int i = threadIdx.x; i < a.n_bins; i += 256) {
-    double m = mc[i], v = w2[i];
-    for (int r = 1; r < a.hist_rep; ++r) {
-      m += mc[r * a.n_bins + i];
-      v += w2[r * a.n_bins + i];
+    // replica order is fixed (0, 1, 2, ...); loads are issued eight at a time so the fold costs
+    // a few memory round trips, not hist_rep of them
+    double m = 0.0, v = 0.0;
+    for (int r0 = 0; r0 < a.hist_rep; r0 += 8) {
+      double am[8], av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = r0 + u < a.hist_rep;
+        am[u] = ok ? mc[(r0 + u) * a.n_bins + i] : 0.0;
+        av[u] = ok ? w2[(r0 + u) * a.n_bins + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        m += am[u];
+        v += av[u];
+      }
     }
     if (a.hist_rep > 1) {
       mc[i] = m;
