@@ -486,6 +486,8 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     bd.words = c.d_words + bh.words_off;
     bd.n_events = bh.n_events;
     bd.first_event = uint32_t(h->E + bh.first_event);
+    bd.n_hdr_words = 1 + uint32_t(M3_STAGE_HDR) * plan.brick_words[bh.words_off];
+    bd.pad_ = 0;
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;

@@ -47,6 +47,8 @@ struct BrickDev {
   const uint32_t* words;  // metadata stream
   uint32_t n_events;
   uint32_t first_event;
+  uint32_t n_hdr_words;   // 1 + 8 * n_stages
+  uint32_t pad_;
 };
 
 struct ReweightArgs {

@@ -286,97 +286,129 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 // staging array; phase B lets every event multiply its slice in ascending parameter order.
 // HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
 // ------------------------------------------------------------------------------------
-constexpr int kBrickThreads = M3_GROUP;                      // one lane per event in phase B
-constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;  // 8 responses per lane in phase A
+constexpr int kBrickThreads = 512;                               // 4 workgroups per CU (LDS: 4 x ~37 KiB)
+constexpr int kBrickEvPerLane = M3_GROUP / kBrickThreads;         // events per lane in phase B
+constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;   // responses per lane and stage
+constexpr int kBrickBatch = 4;                                    // coefficient loads in flight per lane
+constexpr int kBrickMaxStages = 30;
 
 struct RRun {      // per-step resolved run: address = base + r, dx of the run's parameter
   int32_t base;    // coef_off + seg * n_run - start_r   (float4 units from the brick's store)
   float dx;
 };
 
+// Latency structure per stage: {run entries, response words, event words} are independent global
+// loads issued together; the only dependent global access is the coefficient load itself.
 template <int MODE, bool NT>
-__global__ __launch_bounds__(kBrickThreads) void k_reweight_brick(ReweightArgs a) {
+__global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
-  __shared__ RRun lds_runs[M3_BRICK_MAX_RUNS];
+  __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
+  __shared__ uint32_t lds_hdr[1 + M3_STAGE_HDR * kBrickMaxStages];
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
   const uint32_t* __restrict__ words = bd.words;
 
+  // all stage headers in one round trip
+  if (lane < 1 + M3_STAGE_HDR * kBrickMaxStages) lds_hdr[lane] = words[lane < bd.n_hdr_words ? lane : 0];
   if (MODE & kModeFill) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
+  __syncthreads();
 
-  float w = 1.0f;  // SplineMonolith.cpp:798; lane = event of the brick
-  const uint32_t n_stages = words[0];
+  float w[kBrickEvPerLane];
+#pragma unroll
+  for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
+
+  const uint32_t n_stages = lds_hdr[0];
   for (uint32_t s = 0; s < n_stages; ++s) {
-    const uint32_t* __restrict__ h = words + 1 + M3_STAGE_HDR * s;
+    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
     const uint32_t kind = h[0], n_resp = h[1];
+    // event slices of this stage (used in phase B; issued now so the miss overlaps phase A)
+    uint32_t ec[kBrickEvPerLane];
+#pragma unroll
+    for (int q = 0; q < kBrickEvPerLane; ++q) {
+      const uint32_t e = lane * kBrickEvPerLane + q;
+      ec[q] = e < bd.n_events ? words[h[5] + e] : 0u;
+    }
     if (kind == 0) {
-      // resolve the stage's runs for this step: one lane per run
+      RRun* runs_s = lds_runs[s & 1];
       const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
-      if (lane < h[2]) {
-        const uint4 rt = runs[lane];  // {coef_off, n_run, start_r, param}
+      const uint32_t* __restrict__ resp = words + h[4];
+      const uint32_t n_runs = h[2];
+      for (uint32_t r = lane; r < n_runs; r += kBrickThreads) {  // resolve the stage's runs for this step
+        const uint4 rt = runs[r];  // {coef_off, n_run, start_r, param}
         const PTab pt = a.ptab[rt.w];
         RRun rr;
         rr.base = (int32_t)(rt.x + (uint32_t)pt.seg * rt.y) - (int32_t)rt.z;
         rr.dx = pt.dx;
-        lds_runs[lane] = rr;
+        runs_s[r] = rr;
       }
-      __syncthreads();
-      // phase A: all of the lane's responses are in flight at once (no dependent global look-up
-      // between the response word and its coefficient load)
-      const uint32_t* __restrict__ resp = words + h[4];
+      // every response word of the lane for this stage, issued together with the run entries
       uint32_t m[kBrickRespPerLane];
 #pragma unroll
       for (int u = 0; u < kBrickRespPerLane; ++u) {
         const uint32_t r = lane + u * kBrickThreads;
-        m[u] = r < n_resp ? resp[r] : 0xFFFFFFFFu;
+        m[u] = r < n_resp ? resp[r] : 0u;
       }
-      float4 c[kBrickRespPerLane];
-      float dx[kBrickRespPerLane];
+      __syncthreads();
 #pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        if (r < n_resp) {
-          const RRun rr = lds_runs[m[u] & 0xFFFFu];
-          c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(rr.base + (int32_t)r)]);
-          dx[u] = rr.dx;
+      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += kBrickBatch) {
+        if ((uint32_t)(b0 * kBrickThreads) < n_resp) {  // wave-uniform
+          float4 c[kBrickBatch];
+          float dx[kBrickBatch];
+#pragma unroll
+          for (int u = 0; u < kBrickBatch; ++u) {
+            const uint32_t r = lane + (b0 + u) * kBrickThreads;
+            const RRun rr = runs_s[m[b0 + u] & 0xFFFFu];
+            // lanes past the end read the stage's first quad (in range) and discard it
+            c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(r < n_resp ? rr.base + (int32_t)r : rr.base + (int32_t)0)]);
+            dx[u] = rr.dx;
+          }
+#pragma unroll
+          for (int u = 0; u < kBrickBatch; ++u) {
+            const uint32_t r = lane + (b0 + u) * kBrickThreads;
+            if (r < n_resp) stage_w[m[b0 + u] >> 16] = spline_poly(dx[u], c[u]);
+          }
         }
-      }
-#pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        if (r < n_resp) stage_w[m[u] >> 16] = spline_poly(dx[u], c[u]);
       }
     } else {
       const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
       const float2* __restrict__ tp = bd.tf1 + h[6];
+      for (uint32_t r0 = 0; r0 < n_resp; r0 += kBrickBatch * kBrickThreads) {
+        float2 c[kBrickBatch];
+        uint32_t p[kBrickBatch];
 #pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        if (r < n_resp) {
-          const float x = a.pval[par[r]];
-          const float2 c = stream_load<NT>(&tp[r]);
-          stage_w[r] = fmaf(c.x, x, c.y);  // SplineMonolith.cpp:779
+        for (int u = 0; u < kBrickBatch; ++u) {
+          const uint32_t r = r0 + lane + u * kBrickThreads;
+          if (r < n_resp) {
+            p[u] = par[r];
+            c[u] = stream_load<NT>(&tp[r]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kBrickBatch; ++u) {
+          const uint32_t r = r0 + lane + u * kBrickThreads;
+          if (r < n_resp) stage_w[r] = fmaf(c[u].x, a.pval[p[u]], c[u].y);  // SplineMonolith.cpp:779
         }
       }
     }
     __syncthreads();
     // phase B: the event's slice of the staging array, ascending parameter = reference order
-    if (lane < bd.n_events) {
-      const uint32_t ec = words[h[5] + lane];
-      const uint32_t start = ec & 0xFFFFu, cnt = ec >> 16;
-      for (uint32_t i = 0; i < cnt; ++i) w *= stage_w[start + i];
+#pragma unroll
+    for (int q = 0; q < kBrickEvPerLane; ++q) {
+      const uint32_t start = ec[q] & 0xFFFFu, cnt = ec[q] >> 16;
+      for (uint32_t i = 0; i < cnt; ++i) w[q] *= stage_w[start + i];
     }
     __syncthreads();
   }
-  if (MODE & kModeFill) __syncthreads();  // lds_hist zeroing is complete even for a brick without stages
 
-  {
-    const uint64_t ev = (uint64_t)bd.first_event + lane;
-    if (MODE & kModeEval) a.spline_w[ev] = w;
+#pragma unroll
+  for (int q = 0; q < kBrickEvPerLane; ++q) {
+    const uint32_t e = lane * kBrickEvPerLane + q;
+    const uint64_t ev = (uint64_t)bd.first_event + e;
+    if (MODE & kModeEval) a.spline_w[ev] = w[q];
     if (MODE & (kModeFill | kModeEventW)) {
       float tw = 1.0f;  // CalcWeightTotal, as in k_reweight_uniform
       for (uint32_t mm = 0; mm < a.n_norm_slots; ++mm) {
@@ -385,11 +417,11 @@ __global__ __launch_bounds__(kBrickThreads) void k_reweight_brick(ReweightArgs a
       }
       const int oi = a.osc[ev];
       if (oi >= 0) tw *= a.osc_table[oi];
-      tw *= w;
+      tw *= w[q];
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
         const int b = a.bin[ev];
-        if (lane < bd.n_events && tw > 0.f && b >= 0) {
+        if (e < bd.n_events && tw > 0.f && b >= 0) {
           atomicAdd(&lds_hist[b], (double)tw);
           if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
         }

@@ -124,6 +124,11 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
   };
   const std::vector<Range> st_s = split(cnt_s), st_t = split(cnt_t);
   const uint32_t n_stages = uint32_t(st_s.size() + st_t.size());
+  if (n_stages > uint32_t(M3_BRICK_MAX_STAGES)) {
+    *err = "brick: " + std::to_string(n_stages) + " stages exceed the supported " + std::to_string(M3_BRICK_MAX_STAGES) +
+           " (more than ~245k responses in 1024 events)";
+    return false;
+  }
   w.assign(1 + size_t(M3_STAGE_HDR) * n_stages, 0u);
   w[0] = n_stages;
 

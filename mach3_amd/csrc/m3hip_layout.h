@@ -38,6 +38,7 @@ constexpr int M3_TE = 256;       // events per tile (= workgroup size of the rew
 constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
 constexpr int M3_BRICK_CAP = 8192;  // responses per brick stage (= floats of LDS staging)
 constexpr int M3_BRICK_MAX_RUNS = 1024;  // runs per stage (resolved run table lives in LDS)
+constexpr int M3_BRICK_MAX_STAGES = 30;  // stage headers are staged in LDS
 constexpr int M3_STAGE_HDR = 8;     // words per stage header
 constexpr int M3_RUN_WORDS = 4;     // words per run entry
 
