@@ -129,12 +129,21 @@ def main():
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     n_gpus = world
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+        local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks share the card
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("M3_BENCH_BACKEND", "nccl")  # "gloo": plumbing rehearsal on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     base = synth.CONFIGS[args.config]
     per_gpu = args.events or base.n_events
@@ -150,12 +159,14 @@ def main():
             f"{info.n_tiles_brick}b, setup {time.perf_counter() - t_setup:.1f} s")
 
     comm_mode = "none"
-    if world > 1:
+    if world > 1 and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
         # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0], rank, world)
-        comm_mode = "rccl-allreduce(f64[n_bins]) in-library"
+        comm_mode = "rccl-allreduce(f64[32 x n_bins]) in-library"
+    elif world > 1:
+        comm_mode = "none (rehearsal backend: ranks do not exchange bins)"
 
     # Asimov data at nominal (ref: Fitters/MaCh3Factory.h:142-153); freezes W2 as the reference does
     par[:] = synth.params(spec, 0)
@@ -201,7 +212,7 @@ def main():
         out = {
             "metric": "LLH evaluations/sec (MCMC steps/sec)",
             "value": n_gpus * args.steps / el,
-            "unit": "steps/s" if n_gpus == 1 else "steps/s x shards (one 1e6-event shard per GPU)",
+            "unit": "steps/s" if n_gpus == 1 else f"steps/s x shards (one {per_gpu}-event shard per GPU)",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
