@@ -161,24 +161,53 @@ def main():
     comm_mode = "none"
     if world > 1 and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
         # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], rank, world)
-        comm_mode = "rccl-allreduce(f64[32 x n_bins]) in-library"
+        try:
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init(uid[0], rank, world)
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:  # keep the scaling run alive: exchange the bins through torch.distributed instead
+            log(f"rank {rank}: in-library RCCL init failed ({e}); falling back to torch.distributed all_reduce")
+            ok = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            comm_mode = "rccl-allreduce(f64[32 x n_bins]) in-library"
+        else:
+            comm_mode = "torch.distributed all_reduce of the bin vector (fallback)"
     elif world > 1:
         comm_mode = "none (rehearsal backend: ranks do not exchange bins)"
+
+    fallback = comm_mode.startswith("torch.distributed")
+    w2_tot = [None]
+
+    def reduce_bins():
+        """fallback only: sum this rank's partial bins over ranks through torch.distributed"""
+        mc, w2 = sh._bins()
+        if w2_tot[0] is None:  # w2 is frozen after the first Reweight (SampleHandlerFD.cpp:342): reduce it once
+            t2 = torch.from_numpy(w2).cuda()
+            dist.all_reduce(t2)
+            w2_tot[0] = t2.cpu().numpy()
+        t = torch.from_numpy(mc).cuda()
+        dist.all_reduce(t)
+        tot = np.ascontiguousarray(t.cpu().numpy())
+        eng._chk(eng.lib.m3hip_debug_set_bins(eng.h, tot.ctypes.data, w2_tot[0].ctypes.data, len(tot)))
+        return tot
 
     # Asimov data at nominal (ref: Fitters/MaCh3Factory.h:142-153); freezes W2 as the reference does
     par[:] = synth.params(spec, 0)
     sh.Reweight()
-    sh.AddData(sh.GetMCArray())
+    sh.AddData(reduce_bins() if fallback else sh.GetMCArray())
     assert abs(sh.GetLikelihood()) < 1e-9
 
     laps = [synth.params(spec, 1 + i) for i in range(64)]
 
     def step(i):
         par[:] = laps[i % len(laps)]
-        return sh.Step()
+        if not fallback:
+            return sh.Step()
+        sh.Reweight()  # partial bins of this rank's shard
+        reduce_bins()
+        return sh.GetLikelihood()
 
     t_spin = time.perf_counter()
     n_spin = 0
