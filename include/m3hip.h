@@ -150,6 +150,32 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n,
                         const int32_t* bin_idx, const int32_t* osc_idx,
                         const uint64_t* norm_off, const int16_t* norm_idx);
 
+/*
+ * Device-side binning: instead of precomputed bin_idx, hand over the
+ * binning and the nominal kinematic variables and let the device run
+ * BinningHandler::FindGlobalBin / SampleBinningInfo::FindBin (Samples/BinningHandler.cpp:257-307,
+ * Samples/SampleStructs.h:577-613).  Uniform N-D binning, N <= 4.
+ *   m3hip_set_binning_edges  per sample: n_dim[s] axes with n_edges[..] increasing edges each,
+ *                            edges concatenated in (sample, axis) order (SampleBinningInfo::InitUniform,
+ *                            SampleStructs.h:250-287); also defines the global bin space, so it
+ *                            replaces m3hip_set_binning
+ *   m3hip_upload_kinematics  EventInfo.NominalSample and the KinVar values, kin[n][kin_stride]
+ *   m3hip_compute_bins       nominal bins (FindNominalBin) and the global bin of every event
+ *   m3hip_add_kin_shift      a functional-parameter shift of axis `dim` driven by params[param_index]:
+ *                            kind 1: x *= (1 + theta), kind 2: x += theta.  The reference applies
+ *                            arbitrary std::function callbacks per event (SampleHandlerFD.cpp:545-564);
+ *                            the device supports this closed set.  With shifts registered, every
+ *                            m3hip_reweight re-bins all events (nominal bin, +-1 neighbour, binary search).
+ */
+int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges,
+                            const double* edges);
+int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id,
+                            const double* kin, int kin_stride);
+int m3hip_compute_bins(m3hip_handle h);
+int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index);
+int m3hip_clear_kin_shifts(m3hip_handle h);
+int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, uint64_t n);
+
 /* Pre-staged oscillation weights (what OscillationHandler::Evaluate leaves behind the
  * event pointers, Samples/OscillationHandler.cpp:81-119).  May be re-uploaded per step. */
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n);

@@ -118,6 +118,19 @@ struct m3hip_ctx {
   float* d_osc_table = nullptr;
   uint64_t n_osc = 0;
 
+  // device-side binning (optional): axes, nominal kinematics, shifts
+  BinSample* d_bin_samples = nullptr;
+  BinAxis* d_bin_axes = nullptr;
+  double* d_edges = nullptr;
+  std::vector<int> h_sample_ndim;
+  int32_t* d_sample_id = nullptr;
+  double* d_kin = nullptr;
+  int32_t* d_nom_bin = nullptr;
+  int kin_stride = 0;
+  bool bins_computed = false;
+  std::vector<KinShift> h_shifts;
+  KinShift* d_shifts = nullptr;
+
   // bins
   int n_bins = 0, n_samples = 0;
   int32_t* d_sample_off = nullptr;
@@ -246,6 +259,11 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_osc); h->d_osc = nullptr;
   dev_free(h->d_nidx); h->d_nidx = nullptr;
   dev_free(h->d_spline_w); h->d_spline_w = nullptr;
+  dev_free(h->d_sample_id); h->d_sample_id = nullptr;
+  dev_free(h->d_kin); h->d_kin = nullptr;
+  dev_free(h->d_nom_bin); h->d_nom_bin = nullptr;
+  h->kin_stride = 0;
+  h->bins_computed = false;
   dev_free(h->d_event_w); h->d_event_w = nullptr;
   if (h->h_vals) { (void)hipHostFree(h->h_vals); h->h_vals = nullptr; }
   if (h->h_segs) { (void)hipHostFree(h->h_segs); h->h_segs = nullptr; }
@@ -254,6 +272,24 @@ void free_monolith(m3hip_handle h) {
   h->n_uniform = h->n_brick = 0;
   h->mono_open = h->mono_done = false;
   h->parmap_set = false;
+}
+
+BinArgs make_bin_args(m3hip_handle h) {
+  BinArgs b;
+  memset(&b, 0, sizeof(b));
+  b.samples = h->d_bin_samples;
+  b.axes = h->d_bin_axes;
+  b.edges = h->d_edges;
+  b.sample_id = h->d_sample_id;
+  b.kin = h->d_kin;
+  b.nom_bin = h->d_nom_bin;
+  b.bin = h->d_bin;
+  b.shifts = h->d_shifts;
+  b.n_shifts = int32_t(h->h_shifts.size());
+  b.params = h->d_params;
+  b.kin_stride = h->kin_stride;
+  b.n_events = h->E;
+  return b;
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
@@ -321,6 +357,10 @@ int m3hip_destroy(m3hip_handle h) {
   }
   dev_free(h->d_params);
   dev_free(h->d_osc_table);
+  dev_free(h->d_bin_samples);
+  dev_free(h->d_bin_axes);
+  dev_free(h->d_edges);
+  dev_free(h->d_shifts);
   dev_free(h->d_sample_off);
   dev_free(h->d_data);
   dev_free(h->d_hist);
@@ -694,6 +734,131 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   return M3HIP_OK;
 }
 
+int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) {
+  if (!h) return M3HIP_EINVAL;
+  if (n_samples <= 0 || !n_dim || !n_edges || !edges) return fail(h, M3HIP_EINVAL, "set_binning_edges: NULL / empty arguments");
+  std::vector<BinSample> bs(n_samples);
+  std::vector<BinAxis> ax;
+  std::vector<int32_t> off(size_t(n_samples) + 1, 0);
+  int e_off = 0, k = 0;
+  for (int s = 0; s < n_samples; ++s) {
+    if (n_dim[s] < 1 || n_dim[s] > M3_MAX_DIM) return fail(h, M3HIP_EINVAL, "set_binning_edges: 1..4 dimensions per sample");
+    bs[s].n_dim = n_dim[s];
+    bs[s].axis_off = int32_t(ax.size());
+    bs[s].global_offset = off[s];
+    bs[s].pad_ = 0;
+    int stride = 1;
+    for (int d = 0; d < n_dim[s]; ++d, ++k) {
+      const int ne = n_edges[k];
+      if (ne < 2) return fail(h, M3HIP_EINVAL, "set_binning_edges: an axis needs at least two edges");
+      for (int i = 1; i < ne; ++i)
+        if (edges[e_off + i] < edges[e_off + i - 1]) return fail(h, M3HIP_EINVAL, "set_binning_edges: bin edges must be increasing");  // SampleStructs.h:259-263
+      BinAxis a;
+      a.edge_off = e_off;
+      a.n_bins = ne - 1;
+      a.stride = stride;  // SampleStructs.h:648-659
+      a.pad_ = 0;
+      ax.push_back(a);
+      stride *= ne - 1;
+      e_off += ne;
+    }
+    off[s + 1] = off[s] + stride;
+  }
+  int rc = m3hip_set_binning(h, n_samples, off.data());
+  if (rc) return rc;
+  dev_free(h->d_bin_samples); dev_free(h->d_bin_axes); dev_free(h->d_edges);
+  h->d_bin_samples = nullptr; h->d_bin_axes = nullptr; h->d_edges = nullptr;
+  if ((rc = dev_alloc(h, &h->d_bin_samples, bs.size()))) return rc;
+  if ((rc = dev_alloc(h, &h->d_bin_axes, ax.size()))) return rc;
+  if ((rc = dev_alloc(h, &h->d_edges, size_t(e_off)))) return rc;
+  HIPCHK(h, hipMemcpy(h->d_bin_samples, bs.data(), sizeof(BinSample) * bs.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_bin_axes, ax.data(), sizeof(BinAxis) * ax.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_edges, edges, sizeof(double) * size_t(e_off), hipMemcpyHostToDevice));
+  h->h_sample_ndim.assign(n_dim, n_dim + n_samples);
+  h->bins_computed = false;
+  return M3HIP_OK;
+}
+
+int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id, const double* kin, int kin_stride) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_done) return fail(h, M3HIP_ESTATE, "upload_kinematics before monolith_end");
+  if (h->h_sample_ndim.empty()) return fail(h, M3HIP_ESTATE, "upload_kinematics before set_binning_edges");
+  if (event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "upload_kinematics: range exceeds the monolith's events");
+  if (kin_stride < 1 || kin_stride > M3_MAX_DIM || (h->kin_stride && kin_stride != h->kin_stride)) return fail(h, M3HIP_EINVAL, "upload_kinematics: bad kin_stride");
+  if (n == 0) return M3HIP_OK;
+  if (!kin) return fail(h, M3HIP_EINVAL, "upload_kinematics: kin is NULL");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  int rc;
+  if (!h->d_kin) {
+    if ((rc = dev_alloc(h, &h->d_sample_id, size_t(h->E_pad)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_kin, size_t(h->E_pad) * kin_stride))) return rc;
+    if ((rc = dev_alloc(h, &h->d_nom_bin, size_t(h->E_pad) * kin_stride))) return rc;
+    HIPCHK(h, hipMemset(h->d_sample_id, 0, sizeof(int32_t) * h->E_pad));
+    HIPCHK(h, hipMemset(h->d_kin, 0, sizeof(double) * h->E_pad * kin_stride));
+    HIPCHK(h, hipMemset(h->d_nom_bin, 0xFF, sizeof(int32_t) * h->E_pad * kin_stride));
+    h->kin_stride = kin_stride;
+  }
+  if (sample_id) {
+    for (uint64_t i = 0; i < n; ++i) {
+      if (sample_id[i] < 0 || sample_id[i] >= int(h->h_sample_ndim.size())) return fail(h, M3HIP_EINVAL, "upload_kinematics: sample id out of range");
+      if (h->h_sample_ndim[sample_id[i]] > kin_stride) return fail(h, M3HIP_EINVAL, "upload_kinematics: kin_stride smaller than the sample's dimension");
+    }
+    HIPCHK(h, hipMemcpy(h->d_sample_id + event_offset, sample_id, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  }
+  HIPCHK(h, hipMemcpy(h->d_kin + event_offset * kin_stride, kin, sizeof(double) * n * kin_stride, hipMemcpyHostToDevice));
+  h->bins_computed = false;
+  return M3HIP_OK;
+}
+
+int m3hip_compute_bins(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->d_kin || !h->d_bin_samples) return fail(h, M3HIP_ESTATE, "compute_bins needs set_binning_edges and upload_kinematics");
+  HIPCHK(h, hipSetDevice(h->device));
+  BinArgs b = make_bin_args(h);
+  b.compute_nominal = 1;
+  b.n_shifts = 0;
+  launch_find_bins(b, h->stream);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, wait_stream(h->stream));
+  h->bins_computed = true;
+  return M3HIP_OK;
+}
+
+int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index) {
+  if (!h) return M3HIP_EINVAL;
+  if (dim < 0 || dim >= M3_MAX_DIM || (kind != 1 && kind != 2) || param_index < 0 || sample < -1) return fail(h, M3HIP_EINVAL, "add_kin_shift: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  KinShift k;
+  k.sample = sample; k.dim = dim; k.kind = kind; k.param = param_index;
+  h->h_shifts.push_back(k);
+  dev_free(h->d_shifts);
+  h->d_shifts = nullptr;
+  int rc = dev_alloc(h, &h->d_shifts, h->h_shifts.size());
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(h->d_shifts, h->h_shifts.data(), sizeof(KinShift) * h->h_shifts.size(), hipMemcpyHostToDevice));
+  return M3HIP_OK;
+}
+
+int m3hip_clear_kin_shifts(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  h->h_shifts.clear();
+  if (h->bins_computed) return m3hip_compute_bins(h);  // back to the nominal bins
+  return M3HIP_OK;
+}
+
+int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, uint64_t n) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_bins: bad range");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_bin + event_offset, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
   if (!h) return M3HIP_EINVAL;
   if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table: empty table");
@@ -736,6 +901,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "reweight before set_binning");
   if (!params || n_par <= 0) return fail(h, M3HIP_EINVAL, "reweight: empty parameter vector");
   if (!h->parmap_set && n_par < h->P) return fail(h, M3HIP_EINVAL, "reweight: parameter vector shorter than the spline parameters");
+  for (const KinShift& k : h->h_shifts)
+    if (k.param >= n_par) return fail(h, M3HIP_EINVAL, "reweight: a kinematic shift points past the parameter vector");
   const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_param_capacity(h, n_par);
@@ -779,6 +946,12 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   h->host_abs[0] = t_b;
   launch_prep(p, h->stream);
   if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
+  if (!h->h_shifts.empty()) {  // functional shifts: re-bin every event from its shifted kinematics
+    if (!h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
+    BinArgs b = make_bin_args(h);
+    b.compute_nominal = 0;
+    launch_find_bins(b, h->stream);
+  }
   const double t_c = now_s();
 
   ReweightArgs a = make_rw_args(h);

@@ -106,6 +106,43 @@ struct PrepArgs {
   int32_t reset_hist;
 };
 
+// ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307
+constexpr int M3_MAX_DIM = 4;
+struct BinAxis {       // one axis of one sample
+  int32_t edge_off;    // first edge in the concatenated edge array
+  int32_t n_bins;
+  int32_t stride;      // SampleBinningInfo::Strides
+  int32_t pad_;
+};
+struct BinSample {
+  int32_t n_dim;
+  int32_t axis_off;       // first BinAxis of the sample
+  int32_t global_offset;  // SampleBinningInfo::GlobalOffset
+  int32_t pad_;
+};
+struct KinShift {      // closed set of functional-parameter shifts (stand-ins for the reference's
+  int32_t sample;      // std::function callbacks, SampleHandlerFD.cpp:545-564); -1 = every sample
+  int32_t dim;
+  int32_t kind;        // 1: x *= (1 + theta)   2: x += theta
+  int32_t param;       // index into the global parameter vector
+};
+struct BinArgs {
+  const BinSample* samples;
+  const BinAxis* axes;
+  const double* edges;
+  const int32_t* sample_id;  // [E_pad]
+  const double* kin;         // [E_pad][kin_stride] nominal kinematic variables
+  int32_t* nom_bin;          // [E_pad][kin_stride] nominal bin per axis (FindNominalBin)
+  int32_t* bin;              // [E_pad] out: global bin
+  const KinShift* shifts;
+  int32_t n_shifts;
+  const double* params;      // device parameter vector (needed when n_shifts > 0)
+  int32_t kin_stride;
+  int32_t compute_nominal;   // 1: set-up pass, fill nom_bin with upper_bound; 0: per-step pass using nom_bin
+  uint64_t n_events;
+};
+void launch_find_bins(const BinArgs& a, hipStream_t s);
+
 struct LlhArgs {
   const double* data;
   const double* hist;  // [2][hist_rep][n_bins]

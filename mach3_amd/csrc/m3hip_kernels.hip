@@ -300,7 +300,7 @@ struct RRun {      // per-step resolved run: address = base + r, dx of the run's
 // Latency structure per stage: {run entries, response words, event words} are independent global
 // loads issued together; the only dependent global access is the coefficient load itself.
 template <int MODE, bool NT>
-__global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
+__global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
   __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
   __shared__ uint32_t lds_hdr[1 + M3_STAGE_HDR * kBrickMaxStages];
@@ -453,6 +453,74 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
   else launch_brick_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
+}
+
+// ------------------------------------------------------------------------------------
+// k_find_bins: a9, BinningHandler::FindGlobalBin / SampleBinningInfo::FindBin per event, on the
+// device.  Set-up pass (compute_nominal): FindNominalBin = upper_bound - 1.  Per-step pass: apply
+// the registered shifts to the nominal kinematics, then nominal bin -> +-1 neighbour -> binary
+// search, exactly the reference's cascade (all routes give the same index; the integer result
+// is what the parity tests pin).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_upper_bound_bin(const double* e, int n_edges, double v) {
+  // std::distance(begin, std::upper_bound(begin, end, v)) - 1
+  int lo = 0, hi = n_edges;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v < e[mid]) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo - 1;
+}
+
+__device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin) {
+  // Samples/SampleStructs.h:577-613
+  if (KinVar < e[0] || KinVar >= e[N_Bins]) return -1;
+  if (NomBin > -1) {
+    const double lower = e[NomBin], upper = e[NomBin + 1];
+    const double lower_lower = NomBin == 0 ? e[0] : e[NomBin - 1];                       // :615-646
+    const double upper_upper = (NomBin + 2 < N_Bins) ? e[NomBin + 2] : ((NomBin + 1 < N_Bins) ? e[NomBin + 1] : -999999.123456);
+    if (KinVar < upper && KinVar >= lower) return NomBin;
+    if (KinVar < lower && KinVar >= lower_lower) return NomBin - 1;
+    if (KinVar < upper_upper && KinVar >= upper) return NomBin + 1;
+  }
+  return d_upper_bound_bin(e, N_Bins + 1, KinVar);
+}
+
+__global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
+  const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ev >= a.n_events) return;
+  const BinSample sm = a.samples[a.sample_id[ev]];
+  int global = 0;
+  bool out = false;
+  for (int d = 0; d < sm.n_dim; ++d) {
+    const BinAxis ax = a.axes[sm.axis_off + d];
+    const double* e = a.edges + ax.edge_off;
+    double x = a.kin[ev * a.kin_stride + d];
+    int b;
+    if (a.compute_nominal) {
+      // BinningHandler::FindNominalBin (BinningHandler.cpp:294-307)
+      b = (x < e[0] || x >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x);
+      a.nom_bin[ev * a.kin_stride + d] = b;
+    } else {
+      for (int s = 0; s < a.n_shifts; ++s) {  // ApplyShifts: nominal value, then every shift in order
+        const KinShift sh = a.shifts[s];
+        if (sh.dim == d && (sh.sample < 0 || sh.sample == a.sample_id[ev])) {
+          const double th = a.params[sh.param];
+          x = sh.kind == 1 ? x * (1.0 + th) : x + th;
+        }
+      }
+      b = d_find_bin(e, ax.n_bins, x, a.nom_bin[ev * a.kin_stride + d]);
+    }
+    if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
+    global += b * ax.stride;
+  }
+  a.bin[ev] = out ? -1 : global + sm.global_offset;
+}
+
+void launch_find_bins(const BinArgs& a, hipStream_t s) {
+  if (a.n_events == 0) return;
+  hipLaunchKernelGGL(k_find_bins, dim3((unsigned)((a.n_events + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------

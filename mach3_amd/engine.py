@@ -191,13 +191,26 @@ class SampleHandlerFD:
     arrays instead of YAML + ROOT files."""
 
     def __init__(self, engine: Engine, n_samples: int, sample_bin_offset, par_vector: np.ndarray,
-                 test_statistic=capi.kPoisson, update_w2=False):
+                 test_statistic=capi.kPoisson, update_w2=False, bin_edges=None):
+        """bin_edges = [[edges_dim0, edges_dim1, ...] per sample] switches to device-side binning
+        (SetupKinematics / ComputeBins / AddKinShift); otherwise global bins come precomputed
+        through SetupEvents and `sample_bin_offset` defines the global bin space."""
         self.eng = engine
         self.nSamples = int(n_samples)
-        off = np.ascontiguousarray(sample_bin_offset, np.int32)
+        if bin_edges is not None:
+            assert len(bin_edges) == n_samples
+            n_dim = np.array([len(s) for s in bin_edges], np.int32)
+            n_edges = np.array([len(e) for s in bin_edges for e in s], np.int32)
+            edges = np.ascontiguousarray(np.concatenate([np.asarray(e, np.float64) for s in bin_edges for e in s]))
+            engine._chk(engine.lib.m3hip_set_binning_edges(engine.h, n_samples, _ptr(n_dim, np.int32), _ptr(n_edges, np.int32),
+                                                           _ptr(edges, np.float64)))
+            nb = [int(np.prod([len(e) - 1 for e in s])) for s in bin_edges]
+            off = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
+        else:
+            off = np.ascontiguousarray(sample_bin_offset, np.int32)
+            engine._chk(engine.lib.m3hip_set_binning(engine.h, n_samples, _ptr(off, np.int32)))
         self.sample_bin_offset = off
         self.nBins = int(off[-1])
-        engine._chk(engine.lib.m3hip_set_binning(engine.h, n_samples, _ptr(off, np.int32)))
         self.par = par_vector  # plays _fPropVal; read at Reweight() time
         self.SetTestStatistic(test_statistic, update_w2)
 
@@ -217,6 +230,30 @@ class SampleHandlerFD:
             _ptr(np.ascontiguousarray(osc_idx, np.int32), np.int32) if osc_idx is not None else None,
             _ptr(np.ascontiguousarray(norm_off, np.uint64), np.uint64) if norm_off is not None else None,
             _ptr(np.ascontiguousarray(norm_idx, np.int16), np.int16) if norm_off is not None else None))
+
+    # ---- device-side binning (ref: Samples/BinningHandler.cpp:257-307, SampleStructs.h:577-613)
+    def SetupKinematics(self, event_offset, sample_id, kin):
+        kin = np.ascontiguousarray(kin, np.float64)
+        if kin.ndim == 1:
+            kin = kin.reshape(-1, 1)
+        sid = np.ascontiguousarray(sample_id, np.int32) if sample_id is not None else None
+        self.eng._chk(self.eng.lib.m3hip_upload_kinematics(self.eng.h, event_offset, kin.shape[0],
+                                                           _ptr(sid, np.int32) if sid is not None else None,
+                                                           _ptr(kin, np.float64), kin.shape[1]))
+
+    def ComputeBins(self):
+        self.eng._chk(self.eng.lib.m3hip_compute_bins(self.eng.h))
+
+    def AddKinShift(self, sample, dim, kind, param_index):
+        self.eng._chk(self.eng.lib.m3hip_add_kin_shift(self.eng.h, int(sample), int(dim), int(kind), int(param_index)))
+
+    def ClearKinShifts(self):
+        self.eng._chk(self.eng.lib.m3hip_clear_kin_shifts(self.eng.h))
+
+    def GetEventBins(self, off, n):
+        out = np.empty(n, np.int32)
+        self.eng._chk(self.eng.lib.m3hip_get_event_bins(self.eng.h, _ptr(out, np.int32), off, n))
+        return out
 
     def SetOscillationWeights(self, table):
         t = np.ascontiguousarray(table, np.float32)

@@ -661,7 +661,19 @@ struct EventInfo_o {
   int NominalSample = -999;
 };
 
+// closed-form stand-ins for the experiment's functional-parameter callbacks
+// (ref: Samples/SampleHandlerFD.cpp:545-564 ApplyShifts; funcParsGrid holds std::function objects)
+struct FuncShift_o {
+  int sample;  // -1: every sample
+  int dim;
+  int kind;    // 1: x *= (1 + theta)   2: x += theta
+  const double* valuePtr;
+};
+
 struct m3o_sample {
+  std::vector<double> kin_nominal, kin_shifted;  // KinVar pointers alias kin_shifted
+  int kin_stride = 1;
+  std::vector<FuncShift_o> shifts;
   const m3o_binning* Binning = nullptr;
   m3o_monolith* SplineHandler = nullptr;
   std::vector<EventInfo_o> MCSamples;
@@ -680,6 +692,9 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
   s->Binning = b;
   s->SplineHandler = mono;
   s->MCSamples.resize(n_events);
+  s->kin_stride = kin_stride;
+  s->kin_nominal.assign(kin, kin + n_events * uint64_t(kin_stride));
+  s->kin_shifted = s->kin_nominal;
   for (uint64_t e = 0; e < n_events; ++e) {
     EventInfo_o& ev = s->MCSamples[e];
     ev.NominalSample = sample_id ? sample_id[e] : 0;
@@ -687,7 +702,7 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
     ev.KinVar.resize(ndim);
     ev.NomBin.resize(ndim);
     for (int d = 0; d < ndim; ++d) {
-      ev.KinVar[d] = &kin[e * kin_stride + d];
+      ev.KinVar[d] = &s->kin_shifted[e * kin_stride + d];
       // ref: SampleHandlerFD.cpp:757-887 FindNominalBinAndEdges -> BinningHandler::FindNominalBin
       ev.NomBin[d] = b->FindNominalBin(ev.NominalSample, d, *ev.KinVar[d]);
     }
@@ -735,6 +750,27 @@ static m3_float_t CalcWeightTotal(const EventInfo_o* MCEvent) {
   return TotalWeight;
 }
 
+// ref: Samples/SampleHandlerFD.cpp:545-564
+static void ApplyShifts(m3o_sample* s, uint64_t iEvent) {
+  const size_t nShifts = s->shifts.size();
+  if (nShifts == 0) return;  // :550
+  EventInfo_o& ev = s->MCSamples[iEvent];
+  const int ndim = int(ev.KinVar.size());
+  // ResetShifts: back to the nominal values
+  for (int d = 0; d < ndim; ++d) s->kin_shifted[iEvent * s->kin_stride + d] = s->kin_nominal[iEvent * s->kin_stride + d];
+  for (size_t i = 0; i < nShifts; ++i) {
+    const FuncShift_o& fp = s->shifts[i];
+    if (fp.dim >= ndim || (fp.sample >= 0 && fp.sample != ev.NominalSample)) continue;
+    double& x = s->kin_shifted[iEvent * s->kin_stride + fp.dim];
+    const double th = *fp.valuePtr;
+    x = fp.kind == 1 ? x * (1.0 + th) : x + th;
+  }
+}
+
+void m3o_sample_add_shift(m3o_sample* s, int sample, int dim, int kind, const double* value_ptr) {
+  s->shifts.push_back({sample, dim, kind, value_ptr});
+}
+
 // ref: Samples/SampleHandlerFD.cpp:454-463
 static void ResetHistograms(m3o_sample* s) {
   const int nBins = s->Binning->TotalNumberOfBins;
@@ -755,6 +791,7 @@ static void FillArray(m3o_sample* s) {
 #pragma omp parallel for reduction(+ : MC_Array_for_reduction[:TotalBins], W2_array_for_reduction[:TotalBins])
 #endif
   for (uint64_t iEvent = 0; iEvent < NumberOfEvents; ++iEvent) {
+    ApplyShifts(s, iEvent);  // ref: :419, before the selection and the weight
     const EventInfo_o* MCEvent = &s->MCSamples[iEvent];
     const m3_float_t totalweight = CalcWeightTotal(MCEvent);
     if (totalweight <= 0.) continue;  // ref: :432
@@ -816,6 +853,7 @@ void m3o_sample_event_weights(const m3o_sample* s, float* out) {
 }
 void m3o_sample_event_bins(const m3o_sample* s, int32_t* out) {
   for (size_t e = 0; e < s->MCSamples.size(); ++e) {
+    ApplyShifts(const_cast<m3o_sample*>(s), e);
     const EventInfo_o& ev = s->MCSamples[e];
     out[e] = s->Binning->FindGlobalBin(ev.NominalSample, ev.KinVar, ev.NomBin);
   }

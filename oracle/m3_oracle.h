@@ -130,6 +130,9 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
                               const int32_t* osc_idx, const float* osc_table,
                               m3o_monolith* mono);
 void m3o_sample_destroy(m3o_sample* s);
+/* a functional-parameter shift of binning axis `dim` (ApplyShifts, SampleHandlerFD.cpp:545-564):
+ * kind 1: x *= (1 + *value_ptr), kind 2: x += *value_ptr; sample -1 = every sample */
+void m3o_sample_add_shift(m3o_sample* s, int sample, int dim, int kind, const double* value_ptr);
 void m3o_sample_set_test_statistic(m3o_sample* s, int kind, int update_w2);
 void m3o_sample_add_data(m3o_sample* s, const double* data); /* AddData for all bins */
 void m3o_sample_reweight(m3o_sample* s);                     /* Reweight() */

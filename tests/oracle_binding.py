@@ -46,6 +46,7 @@ def load(variant="serial"):
     lib.m3o_binning_find_global_bin.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_find_global_bin.restype = i32
     lib.m3o_sample_create.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp, vp, vp, vp]; lib.m3o_sample_create.restype = vp
     lib.m3o_sample_destroy.argtypes = [vp]; lib.m3o_sample_destroy.restype = None
+    lib.m3o_sample_add_shift.argtypes = [vp, i32, i32, i32, vp]; lib.m3o_sample_add_shift.restype = None
     lib.m3o_sample_set_test_statistic.argtypes = [vp, i32, i32]; lib.m3o_sample_set_test_statistic.restype = None
     lib.m3o_sample_add_data.argtypes = [vp, vp]; lib.m3o_sample_add_data.restype = None
     lib.m3o_sample_reweight.argtypes = [vp]; lib.m3o_sample_reweight.restype = None
@@ -178,6 +179,9 @@ class OracleSample:
             norm_idx.ctypes.data if norm_idx is not None else None, par.ctypes.data,
             osc_idx.ctypes.data if osc_idx is not None else None,
             osc_table.ctypes.data if osc_table is not None else None, mono.h if mono is not None else None)
+
+    def add_shift(self, sample, dim, kind, par, index):
+        self.lib.m3o_sample_add_shift(self.h, sample, dim, kind, par.ctypes.data + 8 * int(index))
 
     def set_test_statistic(self, kind, update_w2=False):
         self.lib.m3o_sample_set_test_statistic(self.h, int(kind), int(update_w2))

@@ -429,3 +429,101 @@ def test_in_library_rccl_allreduce_single_rank(fresh_engine):
     assert np.allclose(sh.GetMCArray(), mc_ref, rtol=1e-12)
     with pytest.raises(capi.M3HipError):
         eng.comm_init(uid, 3, 2)   # rank out of range
+
+
+def _dense_monolith(E, P, rng):
+    X7 = np.arange(-3.0, 4.0)
+    events = [[(p, "spl", natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))) for p in range(P)] for _ in range(E)]
+    return make_monolith(P, 7, {p: X7 for p in range(P)}, events)
+
+
+def test_device_side_binning_bit_exact(fresh_engine):
+    """BinningHandler::FindGlobalBin / FindNominalBin on the device, integer-exact against the oracle:
+    1-D and 2-D samples, values on edges, below the first and on/above the last edge."""
+    rng = np.random.default_rng(21)
+    E, P = 3000, 2
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    e1 = np.array([0.0, 0.5, 1.0, 1.25, 2.0, 3.5, 5.0])
+    ex, ey = np.linspace(0.0, 4.0, 11), np.array([-1.0, -0.2, 0.0, 0.3, 1.0, 2.5])
+    sample_id = rng.integers(0, 2, E).astype(np.int32)
+    kin = np.stack([rng.uniform(-0.3, 5.3, E), rng.uniform(-1.2, 2.7, E)], axis=1)
+    kin[:40, 0] = rng.choice(np.concatenate([e1, ex]), 40)        # exactly on edges
+    kin[40:60, 1] = rng.choice(ey, 20)
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    b.add_uniform([e1])
+    b.add_uniform([ex, ey])
+    par = np.zeros(P + 2)
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(par)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, None, None, par, None, None, omono)
+    exp = osamp.event_bins()
+    assert (exp == -1).any() and (exp >= 6).any()
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 2, None, par, bin_edges=[[e1], [ex, ey]])
+    assert sh.nBins == 6 + 50 and b.n_bins() == 56
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    assert np.array_equal(sh.GetEventBins(0, E), exp)
+    # the fused step on device-computed bins
+    sh.Reweight()
+    osamp.reweight()
+    assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+    osamp.close()
+    omono.close()
+
+
+def test_functional_shifts_rebin_every_step(fresh_engine):
+    """Kinematic shifts driven by parameters (the reference's ApplyShifts + FindBin with the cached
+    nominal bin: nominal hit, +-1 neighbour, binary search, migration out of range)."""
+    rng = np.random.default_rng(22)
+    E, P = 4000, 3
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    ex, ey = np.linspace(0.0, 5.0, 41), np.linspace(-1.0, 1.0, 9)
+    sample_id = rng.integers(0, 2, E).astype(np.int32)
+    kin = np.stack([rng.gamma(3.0, 0.45, E), rng.uniform(-1.05, 1.05, E)], axis=1)
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    b.add_uniform([ex, ey])
+    b.add_uniform([ex, ey])
+    par = np.zeros(P + 2)     # [splines..., energy scale, y offset]
+    opar = par.copy()
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, None, None, opar, None, None, omono)
+    osamp.add_shift(-1, 0, 1, opar, P)        # x *= 1 + theta_P, all samples
+    osamp.add_shift(1, 1, 2, opar, P + 1)     # y += theta_{P+1}, sample 1 only
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 2, None, par, bin_edges=[[ex, ey], [ex, ey]])
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    nominal_bins = sh.GetEventBins(0, E)
+    sh.AddKinShift(-1, 0, 1, P)
+    sh.AddKinShift(1, 1, 2, P + 1)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    moved = 0
+    for scale, off in [(0.0, 0.0), (0.01, 0.0), (-0.02, 0.05), (0.3, -0.4), (-0.5, 0.9), (1.5, 3.0), (0.0, 0.0)]:
+        par[:P] = rng.uniform(-1, 1, P)
+        par[P], par[P + 1] = scale, off
+        opar[:] = par
+        sh.Reweight()
+        llh = sh.GetLikelihood()
+        osamp.reweight()
+        got, exp = sh.GetEventBins(0, E), osamp.event_bins()
+        assert np.array_equal(got, exp), (scale, off)
+        moved += int((got != nominal_bins).sum())
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    assert moved > E  # the shifts really migrated events
+    assert np.array_equal(sh.GetEventBins(0, E), nominal_bins)
+    sh.ClearKinShifts()
+    assert np.array_equal(sh.GetEventBins(0, E), nominal_bins)
+    osamp.close()
+    omono.close()
