@@ -151,6 +151,27 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n,
                         const uint64_t* norm_off, const int16_t* norm_idx);
 
 /*
+ * Binned splines: the per-step part of BinnedSplineHandler
+ * (Splines/BinnedSplineHandler.cpp:295-341) -- FindSplineSegment over the handler's unique spline
+ * parameters, then weight = max(0, cubic) per non-flat bin-spline -- plus the per-event gather of
+ * those weights (SampleHandlerFD::SetSplinePointers, Samples/SampleHandlerFD.cpp:1196-1243, puts
+ * pointers into weightvec_Monolith on every event's total_weight_pointers).  float_t = float build.
+ * Arrays are the handler's own members: coeffindexvec[M], uniquesplinevec_Monolith[M],
+ * uniquecoeffindices[U], xcoeff_arr[C], manycoeff_arr[4C] (BinnedSplineHandler.h:116-140); xpts/npts are
+ * SplineInfoArray (knots of each unique parameter).  A sample uses EITHER this OR the event-by-event
+ * monolith (m3hip_upload_monolith), as in the reference.  Then: m3hip_set_spline_param_map,
+ * m3hip_set_binning..., m3hip_upload_events (bins, osc, norms) and m3hip_binned_upload_events
+ * (per event the CSR of indices into weightvec_Monolith, in pointer order).
+ */
+int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts,
+                        const int16_t* npts, int monolith_size, const int32_t* coeffindexvec,
+                        const int32_t* uniquesplinevec, int n_unique, const int32_t* uniquecoeffindices,
+                        int n_coeff, const float* xcoeff, const float* manycoeff);
+int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const uint64_t* w_off,
+                               const int32_t* w_idx);
+int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size);
+
+/*
  * Device-side binning: instead of precomputed bin_idx, hand over the
  * binning and the nominal kinematic variables and let the device run
  * BinningHandler::FindGlobalBin / SampleBinningInfo::FindBin (Samples/BinningHandler.cpp:257-307,

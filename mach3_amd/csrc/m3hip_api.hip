@@ -118,6 +118,17 @@ struct m3hip_ctx {
   float* d_osc_table = nullptr;
   uint64_t n_osc = 0;
 
+  // binned spline handler (optional)
+  int b_M = 0, b_U = 0, b_C = 0;
+  int32_t* d_b_cidx = nullptr;
+  int32_t* d_b_usv = nullptr;
+  int32_t* d_b_uniq = nullptr;
+  float* d_b_xcoeff = nullptr;
+  float4* d_b_many = nullptr;
+  float* d_b_w = nullptr;
+  int32_t* d_bwidx = nullptr;
+  uint32_t Kb = 0;
+
   // device-side binning (optional): axes, nominal kinematics, shifts
   BinSample* d_bin_samples = nullptr;
   BinAxis* d_bin_axes = nullptr;
@@ -259,6 +270,15 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_osc); h->d_osc = nullptr;
   dev_free(h->d_nidx); h->d_nidx = nullptr;
   dev_free(h->d_spline_w); h->d_spline_w = nullptr;
+  dev_free(h->d_b_cidx); h->d_b_cidx = nullptr;
+  dev_free(h->d_b_usv); h->d_b_usv = nullptr;
+  dev_free(h->d_b_uniq); h->d_b_uniq = nullptr;
+  dev_free(h->d_b_xcoeff); h->d_b_xcoeff = nullptr;
+  dev_free(h->d_b_many); h->d_b_many = nullptr;
+  dev_free(h->d_b_w); h->d_b_w = nullptr;
+  dev_free(h->d_bwidx); h->d_bwidx = nullptr;
+  h->b_M = h->b_U = h->b_C = 0;
+  h->Kb = 0;
   dev_free(h->d_sample_id); h->d_sample_id = nullptr;
   dev_free(h->d_kin); h->d_kin = nullptr;
   dev_free(h->d_nom_bin); h->d_nom_bin = nullptr;
@@ -306,6 +326,9 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.nidx = h->d_nidx;
   a.params = h->d_params;
   a.osc_table = h->d_osc_table;
+  a.bwidx = h->d_bwidx;
+  a.bw = h->d_b_w;
+  a.n_bw_slots = h->Kb;
   a.hist = h->d_hist;
   a.hist_rep = h->hist_rep;
   a.e_pad = h->E_pad;
@@ -734,6 +757,96 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   return M3HIP_OK;
 }
 
+int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
+                        int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
+                        const int32_t* uniquecoeffindices, int n_coeff, const float* xcoeff, const float* manycoeff) {
+  if (!h) return M3HIP_EINVAL;
+  if (n_events == 0 || monolith_size <= 0 || n_unique < 0 || n_coeff < 0 || !coeffindexvec || !uniquesplinevec ||
+      (n_unique && (!uniquecoeffindices || !xcoeff || !manycoeff)))
+    return fail(h, M3HIP_EINVAL, "binned_upload: empty / NULL arguments");
+  for (int u = 0; u < n_unique; ++u) {
+    const int i = uniquecoeffindices[u];
+    if (i < 0 || i >= monolith_size) return fail(h, M3HIP_EINVAL, "binned_upload: uniquecoeffindices entry out of range");
+    const int p = uniquesplinevec[i];
+    if (p < 0 || p >= n_params) return fail(h, M3HIP_EINVAL, "binned_upload: unique spline parameter out of range");
+    const int np = npts[p];
+    if (np < 2 || coeffindexvec[i] < 0 || coeffindexvec[i] + np > n_coeff)
+      return fail(h, M3HIP_EINVAL, "binned_upload: bin-spline " + std::to_string(i) + " exceeds the coefficient arrays");
+  }
+  // an event space without event-by-event responses: every event is an empty uniform slot list
+  int rc = m3hip_monolith_begin(h, n_params, max_knots, xpts, npts);
+  if (rc) return rc;
+  const uint64_t step = 1u << 20;
+  std::vector<unsigned int> zeros(2 * size_t(std::min<uint64_t>(n_events, step)), 0u);
+  for (uint64_t e0 = 0; e0 < n_events; e0 += step) {
+    const uint64_t n = std::min<uint64_t>(step, n_events - e0);
+    rc = m3hip_monolith_append(h, n, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, zeros.data(), zeros.data());
+    if (rc) return rc;
+  }
+  if ((rc = m3hip_monolith_end(h))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_cidx, size_t(monolith_size)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_usv, size_t(monolith_size)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_uniq, size_t(n_unique)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_xcoeff, size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_many, size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_w, size_t(monolith_size)))) return rc;
+  HIPCHK(h, hipMemcpy(h->d_b_cidx, coeffindexvec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_b_usv, uniquesplinevec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
+  if (n_unique) HIPCHK(h, hipMemcpy(h->d_b_uniq, uniquecoeffindices, sizeof(int32_t) * n_unique, hipMemcpyHostToDevice));
+  if (n_coeff) {
+    HIPCHK(h, hipMemcpy(h->d_b_xcoeff, xcoeff, sizeof(float) * n_coeff, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_b_many, manycoeff, sizeof(float) * 4 * size_t(n_coeff), hipMemcpyHostToDevice));
+  }
+  std::vector<float> ones(size_t(monolith_size), 1.0f);  // flat bin-splines keep weight 1 (BinnedSplineHandler.cpp:236)
+  HIPCHK(h, hipMemcpy(h->d_b_w, ones.data(), sizeof(float) * monolith_size, hipMemcpyHostToDevice));
+  h->b_M = monolith_size;
+  h->b_U = n_unique;
+  h->b_C = n_coeff;
+  return M3HIP_OK;
+}
+
+int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const uint64_t* w_off, const int32_t* w_idx) {
+  if (!h) return M3HIP_EINVAL;
+  if (h->b_M == 0) return fail(h, M3HIP_ESTATE, "binned_upload_events before binned_upload");
+  if (event_offset + n > h->E || !w_off) return fail(h, M3HIP_EINVAL, "binned_upload_events: bad range / NULL");
+  if (n == 0) return M3HIP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  uint32_t mx = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t c = w_off[i + 1] - w_off[i];
+    if (c > 1024) return fail(h, M3HIP_EINVAL, "binned_upload_events: implausible number of bin-splines for one event");
+    if (c > mx) mx = uint32_t(c);
+    for (uint64_t k = w_off[i]; k < w_off[i + 1]; ++k)
+      if (w_idx[k] < 0 || w_idx[k] >= h->b_M) return fail(h, M3HIP_EINVAL, "binned_upload_events: weight index out of range");
+  }
+  if (mx > h->Kb) {
+    int32_t* nn = nullptr;
+    int rc = dev_alloc(h, &nn, size_t(mx) * h->E_pad);
+    if (rc) return rc;
+    HIPCHK(h, hipMemset(nn, 0xFF, sizeof(int32_t) * size_t(mx) * h->E_pad));
+    if (h->Kb) HIPCHK(h, hipMemcpy(nn, h->d_bwidx, sizeof(int32_t) * size_t(h->Kb) * h->E_pad, hipMemcpyDeviceToDevice));
+    dev_free(h->d_bwidx);
+    h->d_bwidx = nn;
+    h->Kb = mx;
+  }
+  std::vector<int32_t> plane(n);
+  for (uint32_t k = 0; k < h->Kb; ++k) {
+    for (uint64_t i = 0; i < n; ++i) plane[i] = (k < w_off[i + 1] - w_off[i]) ? w_idx[w_off[i] + k] : -1;
+    HIPCHK(h, hipMemcpy(h->d_bwidx + size_t(k) * h->E_pad + event_offset, plane.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  }
+  return M3HIP_OK;
+}
+
+int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (monolith_size != h->b_M || h->b_M == 0) return fail(h, M3HIP_EINVAL, "get_binned_weights: size mismatch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_b_w, sizeof(float) * monolith_size, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
 int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) {
   if (!h) return M3HIP_EINVAL;
   if (n_samples <= 0 || !n_dim || !n_edges || !edges) return fail(h, M3HIP_EINVAL, "set_binning_edges: NULL / empty arguments");
@@ -946,6 +1059,19 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   h->host_abs[0] = t_b;
   launch_prep(p, h->stream);
   if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
+  if (h->b_U > 0) {  // BinnedSplineHandler::CalcSplineWeights
+    BinnedArgs ba;
+    ba.uniquecoeffindices = h->d_b_uniq;
+    ba.uniquesplinevec = h->d_b_usv;
+    ba.coeffindexvec = h->d_b_cidx;
+    ba.xcoeff = h->d_b_xcoeff;
+    ba.manycoeff = h->d_b_many;
+    ba.ptab = h->d_ptab;
+    ba.pval = h->d_pval;
+    ba.weightvec = h->d_b_w;
+    ba.n_unique = h->b_U;
+    launch_binned_weights(ba, h->stream);
+  }
   if (!h->h_shifts.empty()) {  // functional shifts: re-bin every event from its shifted kinematics
     if (!h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
     BinArgs b = make_bin_args(h);

@@ -63,6 +63,9 @@ struct ReweightArgs {
   const int32_t* osc;        // [E_pad]
   const int16_t* nidx;       // [M][E_pad] ELL of global parameter indices, padded with n_par (-> 1.0)
   const double* params;      // [n_par + 1], last entry 1.0
+  const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
+  const float* bw;           // weightvec_Monolith of the binned spline handler
+  uint32_t n_bw_slots;
   const float* osc_table;
   double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
   int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
@@ -142,6 +145,20 @@ struct BinArgs {
   uint64_t n_events;
 };
 void launch_find_bins(const BinArgs& a, hipStream_t s);
+
+// ---- binned splines (ref: Splines/BinnedSplineHandler.cpp:295-341)
+struct BinnedArgs {
+  const int32_t* uniquecoeffindices;  // [n_unique]
+  const int32_t* uniquesplinevec;     // [M]
+  const int32_t* coeffindexvec;       // [M]
+  const float* xcoeff;                // [C]
+  const float4* manycoeff;            // [C] {y,b,c,d}
+  const PTab* ptab;
+  const float* pval;
+  float* weightvec;                   // [M]
+  int32_t n_unique;
+};
+void launch_binned_weights(const BinnedArgs& a, hipStream_t s);
 
 struct LlhArgs {
   const double* data;

@@ -230,6 +230,10 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     }
     const int oi = a.osc[ev];
     if (oi >= 0) tw *= a.osc_table[oi];
+    for (uint32_t k = 0; k < a.n_bw_slots; ++k) {  // bin-spline weights, in SetSplinePointers order
+      const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
+      if (bi >= 0) tw *= a.bw[bi];
+    }
     tw *= w;
     if (MODE & kModeEventW) a.event_w[ev] = tw;
     if (MODE & kModeFill) {
@@ -417,6 +421,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
       }
       const int oi = a.osc[ev];
       if (oi >= 0) tw *= a.osc_table[oi];
+      for (uint32_t k = 0; k < a.n_bw_slots; ++k) {
+        const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
+        if (bi >= 0) tw *= a.bw[bi];
+      }
       tw *= w[q];
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
@@ -521,6 +529,29 @@ __global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
 void launch_find_bins(const BinArgs& a, hipStream_t s) {
   if (a.n_events == 0) return;
   hipLaunchKernelGGL(k_find_bins, dim3((unsigned)((a.n_events + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------
+// k_binned_weights: BinnedSplineHandler::CalcSplineWeights (Splines/BinnedSplineHandler.cpp:305-341):
+// one lane per non-flat bin-spline; weight = max(0, cubic).  A few 1e5-1e6 splines: small next to
+// the event loop, so the reference's AoS coefficient layout is read as it is (one float4 per lane).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_binned_weights(BinnedArgs a) {
+  const int iCoeff = blockIdx.x * 256 + threadIdx.x;
+  if (iCoeff >= a.n_unique) return;
+  const int iSpline = a.uniquecoeffindices[iCoeff];
+  const int uniqueIndex = a.uniquesplinevec[iSpline];
+  const PTab pt = a.ptab[uniqueIndex];
+  const int segCoeff = a.coeffindexvec[iSpline] + pt.seg;
+  const float4 c = a.manycoeff[segCoeff];
+  const float dx = a.pval[uniqueIndex] - a.xcoeff[segCoeff];  // :327-329 (float_t = float)
+  float weight = fmaf(dx, fmaf(dx, fmaf(dx, c.w, c.z), c.y), c.x);
+  if (weight < 0) weight = 0.f;  // :337
+  a.weightvec[iSpline] = weight;
+}
+
+void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
+  if (a.n_unique > 0) hipLaunchKernelGGL(k_binned_weights, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------

@@ -185,6 +185,46 @@ class SMonolith:
         return self.cpu_total_weights[event:event + 1]
 
 
+class BinnedSplineHandler:
+    """Bin-by-bin splines on the GPU: the per-step part of BinnedSplineHandler
+    (ref: Splines/BinnedSplineHandler.cpp:295-341).  `bs` holds the handler's flat members
+    (coeffindexvec, uniquesplinevec, uniquecoeffindices, xcoeff, manycoeff, xpts, npts)."""
+
+    def __init__(self, engine: Engine, n_events: int, bs: dict):
+        self.eng = engine
+        self.bs = bs
+        self.nParams = int(bs["n_params"])
+        self.MonolithSize = int(bs["monolith_size"])
+        engine._chk(engine.lib.m3hip_binned_upload(
+            engine.h, n_events, self.nParams, bs["max_knots"], _ptr(bs["xpts"], np.float32), _ptr(bs["npts"], np.int16),
+            self.MonolithSize, _ptr(bs["coeffindexvec"], np.int32), _ptr(bs["uniquesplinevec"], np.int32),
+            len(bs["uniquecoeffindices"]), _ptr(bs["uniquecoeffindices"], np.int32), len(bs["xcoeff"]),
+            _ptr(bs["xcoeff"], np.float32), _ptr(bs["manycoeff"], np.float32)))
+
+    def GetName(self):
+        return "BinnedSplineHandler"
+
+    def GetNParams(self):
+        return self.nParams
+
+    def setSplinePointers(self, par_vector, index=None):
+        idx = np.arange(self.nParams) if index is None else np.asarray(index)
+        gi = np.ascontiguousarray(idx, np.int32)
+        self.eng._chk(self.eng.lib.m3hip_set_spline_param_map(self.eng.h, _ptr(gi, np.int32), self.nParams))
+
+    def SetEventSplines(self, event_offset, w_off, w_idx):
+        """per event the indices into weightvec_Monolith, in total_weight_pointers order
+        (ref: Samples/SampleHandlerFD.cpp:1196-1243)"""
+        wo = np.ascontiguousarray(w_off, np.uint64)
+        wi = np.ascontiguousarray(w_idx, np.int32)
+        self.eng._chk(self.eng.lib.m3hip_binned_upload_events(self.eng.h, event_offset, len(wo) - 1, _ptr(wo, np.uint64), _ptr(wi, np.int32)))
+
+    def GetWeights(self):
+        out = np.empty(self.MonolithSize, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_get_binned_weights(self.eng.h, _ptr(out, np.float32), self.MonolithSize))
+        return out
+
+
 class SampleHandlerFD:
     """The fused sample operator: SampleHandlerBase::Reweight / GetLikelihood on the GPU
     (ref: Samples/SampleHandlerFD.cpp:316-463, 1262-1300).  Built from flat per-event

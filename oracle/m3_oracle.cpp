@@ -387,6 +387,105 @@ int16_t* m3o_monolith_curr_segment_state(m3o_monolith* m) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* Binned spline handler                                                      */
+/* ------------------------------------------------------------------------- */
+
+// ref: Splines/BinnedSplineHandler.h:11-165 (the per-step members only)
+struct m3o_binned {
+  short nParams = 0;
+  int MonolithSize = 0;
+  const int* coeffindexvec = nullptr;             // [MonolithSize] first knot of the bin-spline
+  const int* uniquesplinevec_Monolith = nullptr;  // [MonolithSize] unique spline parameter
+  int nUnique = 0;
+  const int* uniquecoeffindices = nullptr;        // [nUnique] the non-flat bin-splines
+  const m3_float_t* xcoeff_arr = nullptr;         // [CoeffIndex]
+  const m3_float_t* manycoeff_arr = nullptr;      // [CoeffIndex * 4]
+  std::vector<FastSplineInfo_o> SplineInfoArray;
+  std::vector<short> SplineSegments;
+  std::vector<float> ParamValues;
+  std::vector<m3_float_t> weightvec_Monolith;
+};
+
+m3o_binned* m3o_binned_create(int n_params, int max_knots, const float* xpts, const int16_t* npts, int monolith_size,
+                              const int* coeffindexvec, const int* uniquesplinevec, int n_unique,
+                              const int* uniquecoeffindices, const float* xcoeff, const float* manycoeff) {
+  m3o_binned* b = new m3o_binned();
+  b->nParams = short(n_params);
+  b->MonolithSize = monolith_size;
+  b->coeffindexvec = coeffindexvec;
+  b->uniquesplinevec_Monolith = uniquesplinevec;
+  b->nUnique = n_unique;
+  b->uniquecoeffindices = uniquecoeffindices;
+  b->xcoeff_arr = xcoeff;
+  b->manycoeff_arr = manycoeff;
+  b->SplineInfoArray.resize(n_params);
+  for (int i = 0; i < n_params; ++i)
+    if (npts[i] > 0) {
+      b->SplineInfoArray[i].nPts = npts[i];
+      b->SplineInfoArray[i].xPts.assign(xpts + size_t(i) * max_knots, xpts + size_t(i) * max_knots + npts[i]);
+    }
+  b->SplineSegments.assign(n_params, 0);
+  b->ParamValues.assign(n_params, -999.f);
+  b->weightvec_Monolith.assign(monolith_size, 1.0f);  // ref: BinnedSplineHandler.cpp:236 (flat splines stay 1)
+  return b;
+}
+void m3o_binned_destroy(m3o_binned* b) { delete b; }
+void m3o_binned_set_spline_pointers(m3o_binned* b, const double* const* ptrs) {
+  for (int i = 0; i < b->nParams; ++i) b->SplineInfoArray[i].splineParsPointer = ptrs[i];
+}
+
+// ref: Splines/BinnedSplineHandler.cpp:295-341 (Evaluate = FindSplineSegment + CalcSplineWeights)
+void m3o_binned_evaluate(m3o_binned* b) {
+  // FindSplineSegment: the SplineBase routine over this handler's unique parameters
+  for (m3_int_t i = 0; i < b->nParams; ++i) {
+    FastSplineInfo_o& info = b->SplineInfoArray[i];
+    const m3_int_t nPoints = info.nPts;
+    const std::vector<m3_float_t>& xArray = info.xPts;
+    const float xvar = float(*info.splineParsPointer);
+    b->ParamValues[i] = xvar;
+    if (xArray.size() == 0) continue;
+    m3_int_t segment = 0;
+    m3_int_t kHigh = m3_int_t(nPoints - 1);
+    const m3_int_t PreviousSegment = info.CurrSegment;
+    if (xvar <= xArray[0]) segment = 0;
+    else if (xvar >= xArray[nPoints - 1]) segment = kHigh;
+    else if (xArray[PreviousSegment + 1] > xvar && xvar >= xArray[PreviousSegment]) segment = PreviousSegment;
+    else {
+      while (kHigh - segment > 1) {
+        const m3_int_t kHalf = m3_int_t((segment + kHigh) / 2);
+        if (xvar > xArray[kHalf]) segment = kHalf;
+        else kHigh = kHalf;
+      }
+    }
+    if (segment >= nPoints - 1 && nPoints > 1) segment = m3_int_t(nPoints - 2);
+    info.CurrSegment = segment;
+    b->SplineSegments[i] = short(segment);
+  }
+  const size_t n = size_t(b->nUnique);
+#ifdef MULTITHREAD
+#pragma omp parallel for simd
+#endif
+  for (size_t iCoeff = 0; iCoeff < n; ++iCoeff) {
+    const int iSpline = b->uniquecoeffindices[iCoeff];
+    const short uniqueIndex = short(b->uniquesplinevec_Monolith[iSpline]);
+    const short currentsegment = short(b->SplineSegments[uniqueIndex]);
+    const int segCoeff = b->coeffindexvec[iSpline] + currentsegment;
+    const int coeffOffset = segCoeff * 4;
+    const m3_float_t y = b->manycoeff_arr[coeffOffset + 0];
+    const m3_float_t bb = b->manycoeff_arr[coeffOffset + 1];
+    const m3_float_t c = b->manycoeff_arr[coeffOffset + 2];
+    const m3_float_t d = b->manycoeff_arr[coeffOffset + 3];
+    const m3_float_t xvar = m3_float_t(*b->SplineInfoArray[uniqueIndex].splineParsPointer);  // ref: :327
+    const m3_float_t dx = xvar - b->xcoeff_arr[segCoeff];
+    m3_float_t weight = fmaf(dx, fmaf(dx, fmaf(dx, d, c), bb), y);  // M3::fmaf_t, float build
+    if (weight < 0) weight = 0.;  // ref: :337
+    b->weightvec_Monolith[iSpline] = weight;
+  }
+}
+const float* m3o_binned_weights(const m3o_binned* b) { return b->weightvec_Monolith.data(); }
+const int16_t* m3o_binned_segments(const m3o_binned* b) { return b->SplineSegments.data(); }
+
+/* ------------------------------------------------------------------------- */
 /* Binning                                                                    */
 /* ------------------------------------------------------------------------- */
 
@@ -676,6 +775,7 @@ struct m3o_sample {
   std::vector<FuncShift_o> shifts;
   const m3o_binning* Binning = nullptr;
   m3o_monolith* SplineHandler = nullptr;
+  m3o_binned* BinnedHandler = nullptr;
   std::vector<EventInfo_o> MCSamples;
   std::vector<double> SampleHandlerFD_array, SampleHandlerFD_array_w2, SampleHandlerFD_data;
   int fTestStatistic = M3O_kPoisson;
@@ -803,12 +903,22 @@ static void FillArray(m3o_sample* s) {
   }
 }
 
+// ref: Samples/SampleHandlerFD.cpp:1196-1243 (SetSplinePointers, BinnedSplineHandler branch): the
+// event's bin-spline weights are appended to total_weight_pointers, after the osc pointer
+void m3o_sample_set_binned(m3o_sample* s, m3o_binned* b, const uint64_t* w_off, const int32_t* w_idx) {
+  s->BinnedHandler = b;
+  for (size_t e = 0; e < s->MCSamples.size(); ++e)
+    for (uint64_t k = w_off[e]; k < w_off[e + 1]; ++k)
+      s->MCSamples[e].total_weight_pointers.push_back(&b->weightvec_Monolith[w_idx[k]]);
+}
+
 // ref: Samples/SampleHandlerFD.cpp:316-343
 void m3o_sample_reweight(m3o_sample* s) {
   ResetHistograms(s);
   // Oscillator->Evaluate(): probabilities are pre-staged in osc_table (BASELINE configs)
   const double t0 = now_s();
   if (s->SplineHandler) m3o_monolith_evaluate(s->SplineHandler);
+  if (s->BinnedHandler) m3o_binned_evaluate(s->BinnedHandler);
   const double t1 = now_s();
   FillArray(s);
   const double t2 = now_s();

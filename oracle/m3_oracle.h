@@ -92,6 +92,21 @@ const int16_t* m3o_monolith_segments(const m3o_monolith* m);     /* SplineSegmen
 const float* m3o_monolith_param_values(const m3o_monolith* m);   /* ParamValues[P] */
 int16_t* m3o_monolith_curr_segment_state(m3o_monolith* m);       /* FastSplineInfo.CurrSegment[P] */
 
+/* ---- binned spline handler: Splines/BinnedSplineHandler.cpp:295-341 (float_t = float build) ----
+ * Arrays BORROWED, in the reference's members' layout: coeffindexvec[M] (first knot of each
+ * bin-spline), uniquesplinevec_Monolith[M] (its unique spline parameter), uniquecoeffindices[U]
+ * (the non-flat ones), xcoeff_arr[C], manycoeff_arr[4C]; xpts/npts give SplineInfoArray. */
+typedef struct m3o_binned m3o_binned;
+m3o_binned* m3o_binned_create(int n_params, int max_knots, const float* xpts, const int16_t* npts,
+                              int monolith_size, const int* coeffindexvec, const int* uniquesplinevec,
+                              int n_unique, const int* uniquecoeffindices, const float* xcoeff,
+                              const float* manycoeff);
+void m3o_binned_destroy(m3o_binned* b);
+void m3o_binned_set_spline_pointers(m3o_binned* b, const double* const* ptrs);
+void m3o_binned_evaluate(m3o_binned* b);
+const float* m3o_binned_weights(const m3o_binned* b);   /* weightvec_Monolith[M] */
+const int16_t* m3o_binned_segments(const m3o_binned* b);
+
 /* ---- binning: Samples/SampleStructs.h:172-676, Samples/BinningHandler.cpp:257-355 ---- */
 typedef struct m3o_binning m3o_binning;
 m3o_binning* m3o_binning_create(void);
@@ -130,6 +145,9 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
                               const int32_t* osc_idx, const float* osc_table,
                               m3o_monolith* mono);
 void m3o_sample_destroy(m3o_sample* s);
+/* SetSplinePointers with a BinnedSplineHandler (SampleHandlerFD.cpp:1196-1243): per event the CSR
+ * w_off/w_idx of indices into weightvec_Monolith */
+void m3o_sample_set_binned(m3o_sample* s, m3o_binned* b, const uint64_t* w_off, const int32_t* w_idx);
 /* a functional-parameter shift of binning axis `dim` (ApplyShifts, SampleHandlerFD.cpp:545-564):
  * kind 1: x *= (1 + *value_ptr), kind 2: x += *value_ptr; sample -1 = every sample */
 void m3o_sample_add_shift(m3o_sample* s, int sample, int dim, int kind, const double* value_ptr);

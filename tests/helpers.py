@@ -95,3 +95,51 @@ def debug_layout(n_params, max_knots, npts, ch):
                                 desc.ctypes.data, bdesc.ctypes.data, words.ctypes.data)
     return rc, "", dict(n_tiles=nt, spl=spl.reshape(-1, 4), tf1=tf1.reshape(-1, 2), meta=meta, desc=desc[:nt],
                         n_bricks=nbr, bdesc=bdesc[:nbr], words=words[:nw])
+
+
+def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_frac=0.1):
+    """Synthetic BinnedSplineHandler members (ref: Splines/BinnedSplineHandler.h:116-140): one
+    bin-spline per (cell, parameter); a fraction is flat (no coefficients, weight stays 1), some dip
+    below zero (exercising the weight < 0 -> 0 clamp, BinnedSplineHandler.cpp:337).  Parameters have
+    different knot counts."""
+    knots = {p: np.linspace(-3, 3, [7, 5, 3][p % 3]) for p in range(n_params)}
+    xpts = np.full((n_params, max_knots), -999.0, np.float32)
+    npts = np.zeros(n_params, np.int16)
+    for p, xs in knots.items():
+        xpts[p, :len(xs)] = xs
+        npts[p] = len(xs)
+    coeffindexvec, usv, uniq, xcoeff, many = [], [], [], [], []
+    ci = 0
+    for cell in range(n_cells):
+        for p in range(n_params):
+            i = cell * n_params + p
+            coeffindexvec.append(ci)
+            usv.append(p)
+            if rng.random() < flat_frac:
+                continue  # flat: CoeffIndex does not advance (BinnedSplineHandler.cpp:1023-1036)
+            xs = knots[p]
+            y = 1 + 0.15 * rng.standard_normal(len(xs))
+            if rng.random() < negative_frac:
+                y[rng.integers(0, len(xs))] = -0.4
+            c = natural_cubic(xs, y)
+            uniq.append(i)
+            xcoeff.append(np.asarray(xs, np.float32))
+            many.append(c.reshape(-1))
+            ci += len(xs)
+    return dict(n_params=n_params, max_knots=max_knots, monolith_size=n_cells * n_params,
+                xpts=np.ascontiguousarray(xpts.reshape(-1)), npts=npts,
+                coeffindexvec=np.asarray(coeffindexvec, np.int32), uniquesplinevec=np.asarray(usv, np.int32),
+                uniquecoeffindices=np.asarray(uniq, np.int32),
+                xcoeff=np.concatenate(xcoeff).astype(np.float32), manycoeff=np.concatenate(many).astype(np.float32))
+
+
+def make_binned_events(n_events, n_params, n_cells, rng):
+    """per event: its cell's bin-splines for a random subset of the parameters, ascending"""
+    w_off, w_idx = [0], []
+    for _ in range(n_events):
+        cell = int(rng.integers(0, n_cells))
+        for p in range(n_params):
+            if rng.random() < 0.6:
+                w_idx.append(cell * n_params + p)
+        w_off.append(len(w_idx))
+    return np.asarray(w_off, np.uint64), np.asarray(w_idx, np.int32)

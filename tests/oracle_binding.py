@@ -33,6 +33,13 @@ def load(variant="serial"):
     for n in ("m3o_monolith_total_weights", "m3o_monolith_spline_weights", "m3o_monolith_tf1_weights",
               "m3o_monolith_segments", "m3o_monolith_param_values", "m3o_monolith_curr_segment_state"):
         getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = vp
+    lib.m3o_binned_create.argtypes = [i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]; lib.m3o_binned_create.restype = vp
+    lib.m3o_binned_destroy.argtypes = [vp]; lib.m3o_binned_destroy.restype = None
+    lib.m3o_binned_set_spline_pointers.argtypes = [vp, vp]; lib.m3o_binned_set_spline_pointers.restype = None
+    lib.m3o_binned_evaluate.argtypes = [vp]; lib.m3o_binned_evaluate.restype = None
+    lib.m3o_binned_weights.argtypes = [vp]; lib.m3o_binned_weights.restype = vp
+    lib.m3o_binned_segments.argtypes = [vp]; lib.m3o_binned_segments.restype = vp
+    lib.m3o_sample_set_binned.argtypes = [vp, vp, vp, vp]; lib.m3o_sample_set_binned.restype = None
     lib.m3o_binning_create.argtypes = []; lib.m3o_binning_create.restype = vp
     lib.m3o_binning_destroy.argtypes = [vp]; lib.m3o_binning_destroy.restype = None
     lib.m3o_binning_add_uniform.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_add_uniform.restype = i32
@@ -129,6 +136,41 @@ class OracleMonolith:
             self.h = None
 
 
+class OracleBinned:
+    """BinnedSplineHandler per-step path over borrowed arrays (dict `bs`, see helpers.make_binned)."""
+
+    def __init__(self, lib, bs: dict):
+        self.lib = lib
+        self.bs = bs
+        self.P, self.M = bs["n_params"], bs["monolith_size"]
+        self.h = lib.m3o_binned_create(self.P, bs["max_knots"], bs["xpts"].ctypes.data, bs["npts"].ctypes.data, self.M,
+                                       bs["coeffindexvec"].ctypes.data, bs["uniquesplinevec"].ctypes.data,
+                                       len(bs["uniquecoeffindices"]), bs["uniquecoeffindices"].ctypes.data,
+                                       bs["xcoeff"].ctypes.data, bs["manycoeff"].ctypes.data)
+
+    def set_spline_pointers(self, par, index=None):
+        idx = np.arange(self.P) if index is None else np.asarray(index)
+        self._par = par
+        self._ptrs = (C.c_void_p * self.P)(*[par.ctypes.data + 8 * int(i) for i in idx])
+        self.lib.m3o_binned_set_spline_pointers(self.h, self._ptrs)
+
+    def evaluate(self):
+        self.lib.m3o_binned_evaluate(self.h)
+
+    @property
+    def weights(self):
+        return _view(self.lib.m3o_binned_weights(self.h), self.M, np.float32)
+
+    @property
+    def segments(self):
+        return _view(self.lib.m3o_binned_segments(self.h), self.P, np.int16)
+
+    def close(self):
+        if self.h:
+            self.lib.m3o_binned_destroy(self.h)
+            self.h = None
+
+
 class OracleBinning:
     def __init__(self, lib):
         self.lib = lib
@@ -179,6 +221,10 @@ class OracleSample:
             norm_idx.ctypes.data if norm_idx is not None else None, par.ctypes.data,
             osc_idx.ctypes.data if osc_idx is not None else None,
             osc_table.ctypes.data if osc_table is not None else None, mono.h if mono is not None else None)
+
+    def set_binned(self, binned: OracleBinned, w_off, w_idx):
+        self.keep = self.keep + (binned, w_off, w_idx)
+        self.lib.m3o_sample_set_binned(self.h, binned.h, w_off.ctypes.data, w_idx.ctypes.data)
 
     def add_shift(self, sample, dim, kind, par, index):
         self.lib.m3o_sample_add_shift(self.h, sample, dim, kind, par.ctypes.data + 8 * int(index))

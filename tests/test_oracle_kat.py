@@ -283,3 +283,29 @@ def test_fill_semantics(lib):
     assert s.get_sample_likelihood(0) == 0.0
     s.close()
     mono.close()
+
+
+def test_binned_spline_kat(lib):
+    """ref: Splines/BinnedSplineHandler.cpp:305-341: flat bin-splines keep weight 1, weight = y at a knot,
+    negative cubic values are clamped to 0."""
+    xs = np.array([-1.0, 0.0, 1.0])
+    c_pos = natural_cubic(xs, [0.8, 1.0, 1.3])
+    c_neg = natural_cubic(xs, [0.5, -0.4, 0.6])
+    bs = dict(n_params=1, max_knots=3, monolith_size=3, xpts=xs.astype(np.float32), npts=np.array([3], np.int16),
+              coeffindexvec=np.array([0, 3, 3], np.int32), uniquesplinevec=np.array([0, 0, 0], np.int32),
+              uniquecoeffindices=np.array([0, 2], np.int32),        # entry 1 is flat
+              xcoeff=np.concatenate([xs, xs]).astype(np.float32),
+              manycoeff=np.concatenate([c_pos.reshape(-1), c_neg.reshape(-1)]).astype(np.float32))
+    b = ob.OracleBinned(lib, bs)
+    par = np.array([0.5])
+    b.set_spline_pointers(par)
+    b.evaluate()
+    par[0] = 0.0                      # shortcut keeps segment 1 (x[1] = 0): dx = 0 -> weight = y[1]
+    b.evaluate()
+    assert b.segments[0] == 1
+    w = b.weights
+    assert w[0] == np.float32(1.0) and w[1] == 1.0 and w[2] == 0.0   # y[1] = -0.4 clamped
+    par[0] = -1.0
+    b.evaluate()
+    assert b.weights[0] == np.float32(0.8) and b.weights[2] == np.float32(0.5)
+    b.close()
