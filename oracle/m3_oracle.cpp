@@ -163,6 +163,233 @@ double m3o_tspline3_eval(const float* xpos, const float* yresp, const float* par
 double m3o_tf1_eval(const float* par, double var) { return par[1] + par[0] * var; }
 
 /* ------------------------------------------------------------------------- */
+/* TSpline3_red coefficient builders (set-up time)                            */
+/* ------------------------------------------------------------------------- */
+
+// ROOT's TSpline3 (no end-condition options) is the `spline` routine of Forsythe, Malcolm & Moler,
+// "Computer Methods for Mathematical Computations" (1977): end conditions from the cubics through
+// the first / last four points.  ROOT is not part of the reference tree (third-party, parity
+// unpinned); this restates the published algorithm in double, as ROOT runs it.
+void m3o_root_tspline3_coeffs(int n, const double* x, const double* y, double* b, double* c, double* d) {
+  if (n < 2) { if (n == 1) { b[0] = c[0] = d[0] = 0; } return; }
+  const int nm1 = n - 1;
+  if (n < 3) {
+    b[0] = (y[1] - y[0]) / (x[1] - x[0]);
+    c[0] = 0.; d[0] = 0.;
+    b[1] = b[0]; c[1] = 0.; d[1] = 0.;
+    return;
+  }
+  d[0] = x[1] - x[0];
+  c[1] = (y[1] - y[0]) / d[0];
+  for (int i = 1; i < nm1; ++i) {
+    d[i] = x[i + 1] - x[i];
+    b[i] = 2. * (d[i - 1] + d[i]);
+    c[i + 1] = (y[i + 1] - y[i]) / d[i];
+    c[i] = c[i + 1] - c[i];
+  }
+  b[0] = -d[0];
+  b[nm1] = -d[n - 2];
+  c[0] = 0.;
+  c[nm1] = 0.;
+  if (n != 3) {
+    c[0] = c[2] / (x[3] - x[1]) - c[1] / (x[2] - x[0]);
+    c[nm1] = c[n - 2] / (x[nm1] - x[n - 3]) - c[n - 3] / (x[n - 2] - x[n - 4]);
+    c[0] = c[0] * d[0] * d[0] / (x[3] - x[0]);
+    c[nm1] = -c[nm1] * d[n - 2] * d[n - 2] / (x[nm1] - x[n - 4]);
+  }
+  for (int i = 1; i < n; ++i) {
+    const double t = d[i - 1] / b[i - 1];
+    b[i] = b[i] - t * d[i - 1];
+    c[i] = c[i] - t * c[i - 1];
+  }
+  c[nm1] = c[nm1] / b[nm1];
+  for (int ib = 1; ib < n; ++ib) {
+    const int i = n - 1 - ib;
+    c[i] = (c[i] - d[i] * c[i + 1]) / b[i];
+  }
+  b[nm1] = (y[nm1] - y[n - 2]) / d[n - 2] + d[n - 2] * (c[n - 2] + 2. * c[nm1]);
+  for (int i = 0; i < nm1; ++i) {
+    b[i] = (y[i + 1] - y[i]) / d[i] - d[i] * (c[i + 1] + 2. * c[i]);
+    d[i] = (c[i + 1] - c[i]) / d[i];
+    c[i] = 3. * c[i];
+  }
+  c[nm1] = 3. * c[nm1];
+  d[nm1] = d[n - 2];
+}
+
+// ref: Splines/SplineStructs.h:311-652 (TSpline3_red::SetFunc).  `spline` = the ROOT TSpline3 the
+// reference is handed: knots x,y (double) and ROOT's own b,c,d (root_bcd[n][3]).  Output per knot
+// {x, y, b, c, d} as M3::float_t.  interpolation: 0 kTSpline3, 1 kLinear, 2 kMonotonic, 3 kAkima,
+// 4 kKochanekBartels, 5 kLinearFunc.  Returns 0, or -1 for an unsupported type (reference throws).
+int m3o_build_tspline3_red(int InterPolation, int nPoints, const double* sx, const double* sy, const double* root_bcd,
+                           float* out /*[nPoints][5]*/) {
+  std::vector<m3_float_t> XPos(nPoints), YResp(nPoints);
+  std::vector<std::array<m3_float_t, 3>> Par(nPoints, {0.f, 0.f, 0.f});
+  if (InterPolation == 0) {  // kTSpline3 :331-345
+    for (int i = 0; i < nPoints; ++i) {
+      XPos[i] = m3_float_t(sx[i]);
+      YResp[i] = m3_float_t(sy[i]);
+      Par[i][0] = m3_float_t(root_bcd[3 * i]);
+      Par[i][1] = m3_float_t(root_bcd[3 * i + 1]);
+      Par[i][2] = m3_float_t(root_bcd[3 * i + 2]);
+    }
+  } else if (InterPolation == 1 || InterPolation == 5) {  // kLinear / kLinearFunc :351-373
+    for (int k = 0; k < nPoints; ++k) {
+      const double x1 = sx[k], y1 = sy[k];
+      double tempb = 0;
+      if (k == nPoints - 1) {
+        tempb = Par[k - 1][0];
+      } else {
+        const double x2 = sx[k + 1], y2 = sy[k + 1];
+        tempb = (y2 - y1) / (x2 - x1);
+      }
+      XPos[k] = m3_float_t(x1);
+      YResp[k] = m3_float_t(y1);
+      Par[k][0] = m3_float_t(tempb);
+      Par[k][1] = m3_float_t(0);
+      Par[k][2] = m3_float_t(0);
+    }
+  } else if (InterPolation == 3) {  // kAkima :376-447
+    for (int i = 0; i < nPoints; ++i) {
+      XPos[i] = m3_float_t(sx[i]);
+      YResp[i] = m3_float_t(sy[i]);
+    }
+    std::vector<m3_float_t> mvals(nPoints + 3), svals(nPoints + 1);
+    for (int i = -2; i <= nPoints; ++i) {
+      if (i == -2) {
+        mvals[i + 2] = m3_float_t(3.0 * (YResp[1] - YResp[0]) / (XPos[1] - XPos[0]) - 2.0 * (YResp[2] - YResp[1]) / (XPos[2] - XPos[1]));
+      } else if (i == -1) {
+        mvals[i + 2] = m3_float_t(2.0 * (YResp[1] - YResp[0]) / (XPos[1] - XPos[0]) - (YResp[2] - YResp[1]) / (XPos[2] - XPos[1]));
+      } else if (i == nPoints) {
+        mvals[i + 2] = m3_float_t(3.0 * (YResp[nPoints - 1] - YResp[nPoints - 2]) / (XPos[nPoints - 1] - XPos[nPoints - 2]) -
+                                  2.0 * (YResp[nPoints - 2] - YResp[nPoints - 3]) / (XPos[nPoints - 2] - XPos[nPoints - 3]));
+      } else if (i == nPoints - 1) {
+        mvals[i + 2] = m3_float_t(2.0 * (YResp[nPoints - 1] - YResp[nPoints - 2]) / (XPos[nPoints - 1] - XPos[nPoints - 2]) -
+                                  (YResp[nPoints - 2] - YResp[nPoints - 3]) / (XPos[nPoints - 2] - XPos[nPoints - 3]));
+      } else {
+        mvals[i + 2] = (YResp[i + 1] - YResp[i]) / (XPos[i + 1] - XPos[i]);
+      }
+    }
+    // the reference's loop runs i = 2 .. nPoints+2 and reads mvals[i+1] one past its nPoints+3
+    // entries on the last pass (svals[nPoints] of that pass is only used for the last knot's
+    // unused coefficients); the out-of-bounds element is taken as 0 here.
+    auto mv = [&](int k) -> m3_float_t { return k < nPoints + 3 ? mvals[k] : m3_float_t(0); };
+    for (int i = 2; i <= nPoints + 2; i++) {
+      if (i - 2 > nPoints) break;
+      if (std::abs(mv(i + 1) - mv(i)) + std::abs(mv(i - 1) - mv(i - 2)) != 0.0) {
+        svals[i - 2] = (std::abs(mv(i + 1) - mv(i)) * mv(i - 1) + std::abs(mv(i - 1) - mv(i - 2)) * mv(i)) /
+                       (std::abs(mv(i + 1) - mv(i)) + std::abs(mv(i - 1) - mv(i - 2)));
+      } else {
+        svals[i - 2] = mv(i);
+      }
+    }
+    for (int i = 0; i < nPoints - 1; i++) {  // the reference also runs i = nPoints-1 (reads past the knots); that quad is never evaluated
+      m3_float_t b, c, d;
+      b = svals[i];
+      c = m3_float_t(3.0 * (YResp[i + 1] - YResp[i]) / (XPos[i + 1] - XPos[i]) - 2.0 * svals[i] - svals[i + 1]) / (XPos[i + 1] - XPos[i]);
+      d = m3_float_t((svals[i + 1] + svals[i]) - 2.0 * (YResp[i + 1] - YResp[i]) / (XPos[i + 1] - XPos[i])) /
+          ((XPos[i + 1] - XPos[i]) * (XPos[i + 1] - XPos[i]));
+      Par[i][0] = b; Par[i][1] = c; Par[i][2] = d;
+    }
+    for (int i = 0; i < nPoints - 1; i++) {  // :434-444 keep segments the input spline has as straight lines
+      const double b = root_bcd[3 * i], c = root_bcd[3 * i + 1], d = root_bcd[3 * i + 2];
+      if (c == 0.0 && d == 0.0) {
+        Par[i][0] = m3_float_t(b); Par[i][1] = m3_float_t(0.0); Par[i][2] = m3_float_t(0.0);
+      }
+    }
+  } else if (InterPolation == 2) {  // kMonotonic :450-566
+    std::vector<m3_float_t> Secants(nPoints > 1 ? nPoints - 1 : 1), Tangents(nPoints);
+    for (int i = 0; i < nPoints; ++i) {
+      XPos[i] = m3_float_t(sx[i]);
+      YResp[i] = m3_float_t(sy[i]);
+      Tangents[i] = 0.0;
+    }
+    if (nPoints == 2) {
+      Par[0][0] = (YResp[1] - YResp[0]) / (XPos[1] - XPos[0]);
+      Par[0][1] = 0.0; Par[0][2] = 0.0; Par[1][1] = 0.0; Par[1][2] = 0.0;
+    } else {
+      for (int i = 0; i < nPoints - 1; ++i) Secants[i] = (YResp[i + 1] - YResp[i]) / (XPos[i + 1] - XPos[i]);
+      Tangents[0] = Secants[0];
+      Tangents[nPoints - 1] = Secants[nPoints - 2];
+      m3_float_t alpha, beta;
+      for (int i = 1; i < nPoints - 1; ++i) {
+        if ((Secants[i - 1] >= 0.0 && Secants[i] >= 0.0) | (Secants[i - 1] < 0.0 && Secants[i] < 0.0)) {
+          Tangents[i] = m3_float_t((Secants[i - 1] + Secants[i]) / 2.0);
+        }
+      }
+      for (int i = 0; i < nPoints - 1; ++i) {
+        if (Secants[i] == 0.0) {
+          Tangents[i] = 0.0;
+          Tangents[i + 1] = 0.0;
+        } else {
+          alpha = Tangents[i] / Secants[i];
+          beta = Tangents[i + 1] / Secants[i];
+          if (alpha < 0.0) Tangents[i] = 0.0;
+          if (beta < 0.0) Tangents[i + 1] = 0.0;
+          if (alpha * alpha + beta * beta > 9.0) {
+            m3_float_t tau = m3_float_t(3.0 / std::sqrt(alpha * alpha + beta * beta));
+            Tangents[i] = tau * alpha * Secants[i];
+            Tangents[i + 1] = tau * beta * Secants[i];
+          }
+        }
+      }
+      m3_float_t dx;
+      for (int i = 0; i < nPoints - 1; i++) {
+        m3_float_t b, c, d;
+        dx = XPos[i + 1] - XPos[i];
+        b = Tangents[i] * dx;
+        c = m3_float_t(3.0 * (YResp[i + 1] - YResp[i]) - 2.0 * dx * Tangents[i] - dx * Tangents[i + 1]);
+        d = m3_float_t(2.0 * (YResp[i] - YResp[i + 1]) + dx * (Tangents[i] + Tangents[i + 1]));
+        Par[i][0] = b / dx;
+        Par[i][1] = c / (dx * dx);
+        Par[i][2] = d / (dx * dx * dx);
+      }
+      Par[nPoints - 1][0] = 0.0; Par[nPoints - 1][1] = 0.0; Par[nPoints - 1][2] = 0.0;
+      for (int i = 0; i < nPoints - 1; i++) {  // :552-562
+        const double b = root_bcd[3 * i], c = root_bcd[3 * i + 1], d = root_bcd[3 * i + 2];
+        if (c == 0.0 && d == 0.0) {
+          Par[i][0] = m3_float_t(b); Par[i][1] = 0.0; Par[i][2] = 0.0;
+        }
+      }
+    }
+  } else if (InterPolation == 4) {  // kKochanekBartels :568-643, T = C = B = 0 (Catmull-Rom)
+    std::vector<m3_float_t> Tangents(nPoints);
+    for (int i = 0; i < nPoints; ++i) {
+      XPos[i] = m3_float_t(sx[i]);
+      YResp[i] = m3_float_t(sy[i]);
+      Tangents[i] = 0.0;
+    }
+    constexpr m3_float_t T = 0.0, Cc = 0.0, B = 0.0;
+    for (int i = 1; i < nPoints - 1; ++i) {
+      m3_float_t d0 = (YResp[i] - YResp[i - 1]) / (XPos[i] - XPos[i - 1]);
+      m3_float_t d1 = (YResp[i + 1] - YResp[i]) / (XPos[i + 1] - XPos[i]);
+      m3_float_t term1 = (1.0 - T) * (1.0 + B) * (1.0 + Cc) * 0.5 * d0;
+      m3_float_t term2 = (1.0 - T) * (1.0 - B) * (1.0 - Cc) * 0.5 * d1;
+      Tangents[i] = term1 + term2;
+    }
+    Tangents[0] = (YResp[1] - YResp[0]) / (XPos[1] - XPos[0]);
+    Tangents[nPoints - 1] = (YResp[nPoints - 1] - YResp[nPoints - 2]) / (XPos[nPoints - 1] - XPos[nPoints - 2]);
+    for (int i = 0; i < nPoints - 1; ++i) {
+      m3_float_t dx = XPos[i + 1] - XPos[i];
+      m3_float_t dy = YResp[i + 1] - YResp[i];
+      m3_float_t m0 = Tangents[i];
+      m3_float_t m1 = Tangents[i + 1];
+      Par[i][0] = m0;
+      Par[i][1] = (3 * dy / (dx * dx)) - (2 * m0 + m1) / dx;
+      Par[i][2] = (m0 + m1 - 2 * dy / dx) / (dx * dx);
+    }
+    Par[nPoints - 1][0] = 0.0; Par[nPoints - 1][1] = 0.0; Par[nPoints - 1][2] = 0.0;
+  } else {
+    return -1;
+  }
+  for (int i = 0; i < nPoints; ++i) {
+    out[5 * i] = XPos[i]; out[5 * i + 1] = YResp[i];
+    out[5 * i + 2] = Par[i][0]; out[5 * i + 3] = Par[i][1]; out[5 * i + 4] = Par[i][2];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Spline monolith                                                            */
 /* ------------------------------------------------------------------------- */
 

@@ -53,6 +53,15 @@ double m3o_tspline3_eval(const float* xpos, const float* yresp, const float* par
 /* TF1_red::Eval: Par[1] + Par[0]*var (SplineStructs.h:192-193) */
 double m3o_tf1_eval(const float* par, double var);
 
+/* ---- set-up: TSpline3_red coefficient builders, Splines/SplineStructs.h:311-652 ----
+ * m3o_root_tspline3_coeffs: ROOT's TSpline3 (third party, not in the reference tree) = the FMM
+ * `spline` routine; restated from the published algorithm, PARITY UNPINNED.
+ * m3o_build_tspline3_red: TSpline3_red::SetFunc for kTSpline3 / kLinear / kMonotonic / kAkima /
+ * kKochanekBartels / kLinearFunc given the knots and ROOT's coefficients; out[n][5] = {x,y,b,c,d}. */
+void m3o_root_tspline3_coeffs(int n, const double* x, const double* y, double* b, double* c, double* d);
+int m3o_build_tspline3_red(int interpolation, int n, const double* x, const double* y, const double* root_bcd,
+                           float* out);
+
 /* ---- spline monolith: Splines/SplineBase.cpp:44-109, SplineMonolith.cpp:712-830 ---- */
 typedef struct m3o_monolith m3o_monolith;
 

@@ -23,6 +23,8 @@ def load(variant="serial"):
     lib.m3o_tspline3_find_x.argtypes = [vp, i32, dbl]; lib.m3o_tspline3_find_x.restype = i32
     lib.m3o_tspline3_eval.argtypes = [vp, vp, vp, i32, dbl]; lib.m3o_tspline3_eval.restype = dbl
     lib.m3o_tf1_eval.argtypes = [vp, dbl]; lib.m3o_tf1_eval.restype = dbl
+    lib.m3o_root_tspline3_coeffs.argtypes = [i32, vp, vp, vp, vp, vp]; lib.m3o_root_tspline3_coeffs.restype = None
+    lib.m3o_build_tspline3_red.argtypes = [i32, i32, vp, vp, vp, vp]; lib.m3o_build_tspline3_red.restype = i32
     lib.m3o_monolith_create.argtypes = [u64, i32, i32, vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]
     lib.m3o_monolith_create.restype = vp
     for n in ("m3o_monolith_destroy", "m3o_monolith_evaluate", "m3o_monolith_find_spline_segment",

@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "build", "mr2t2_dragrace")
 
 def test_facade_headers_compile():
     """Syntax-check the facade headers on their own (no GPU, no link)."""
-    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h"):
+    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h", "SplineBuilders.h"):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                             "-x", "c++", os.path.join(ROOT, "include", "mach3_amd", h)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
