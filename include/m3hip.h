@@ -195,6 +195,10 @@ int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, c
 int m3hip_compute_bins(m3hip_handle h);
 int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index);
 int m3hip_clear_kin_shifts(m3hip_handle h);
+/* SampleHandlerFD::IsEventSelected (Samples/SampleHandlerFD.cpp:281-294): an event is kept while
+ * lower <= x < upper for every cut of its sample; `column` addresses the kinematics array (binning
+ * axes first, further columns may hold cut-only variables).  Evaluated on the shifted values. */
+int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, double upper);
 int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, uint64_t n);
 
 /* Pre-staged oscillation weights (what OscillationHandler::Evaluate leaves behind the

@@ -141,6 +141,8 @@ struct m3hip_ctx {
   bool bins_computed = false;
   std::vector<KinShift> h_shifts;
   KinShift* d_shifts = nullptr;
+  std::vector<KinCut> h_cuts;
+  KinCut* d_cuts = nullptr;
 
   // bins
   int n_bins = 0, n_samples = 0;
@@ -306,6 +308,8 @@ BinArgs make_bin_args(m3hip_handle h) {
   b.bin = h->d_bin;
   b.shifts = h->d_shifts;
   b.n_shifts = int32_t(h->h_shifts.size());
+  b.cuts = h->d_cuts;
+  b.n_cuts = int32_t(h->h_cuts.size());
   b.params = h->d_params;
   b.kin_stride = h->kin_stride;
   b.n_events = h->E;
@@ -384,6 +388,7 @@ int m3hip_destroy(m3hip_handle h) {
   dev_free(h->d_bin_axes);
   dev_free(h->d_edges);
   dev_free(h->d_shifts);
+  dev_free(h->d_cuts);
   dev_free(h->d_sample_off);
   dev_free(h->d_data);
   dev_free(h->d_hist);
@@ -947,10 +952,28 @@ int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param
   k.sample = sample; k.dim = dim; k.kind = kind; k.param = param_index;
   h->h_shifts.push_back(k);
   dev_free(h->d_shifts);
+  dev_free(h->d_cuts);
   h->d_shifts = nullptr;
   int rc = dev_alloc(h, &h->d_shifts, h->h_shifts.size());
   if (rc) return rc;
   HIPCHK(h, hipMemcpy(h->d_shifts, h->h_shifts.data(), sizeof(KinShift) * h->h_shifts.size(), hipMemcpyHostToDevice));
+  return M3HIP_OK;
+}
+
+int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, double upper) {
+  if (!h) return M3HIP_EINVAL;
+  if (column < 0 || column >= M3_MAX_DIM || sample < -1 || !(lower <= upper)) return fail(h, M3HIP_EINVAL, "add_kin_cut: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  KinCut c;
+  c.sample = sample; c.column = column; c.lo = lower; c.hi = upper;
+  h->h_cuts.push_back(c);
+  dev_free(h->d_cuts);
+  h->d_cuts = nullptr;
+  int rc = dev_alloc(h, &h->d_cuts, h->h_cuts.size());
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpy(h->d_cuts, h->h_cuts.data(), sizeof(KinCut) * h->h_cuts.size(), hipMemcpyHostToDevice));
+  if (h->bins_computed) return m3hip_compute_bins(h);  // the selection changes which events fill
   return M3HIP_OK;
 }
 

@@ -129,6 +129,11 @@ struct KinShift {      // closed set of functional-parameter shifts (stand-ins f
   int32_t kind;        // 1: x *= (1 + theta)   2: x += theta
   int32_t param;       // index into the global parameter vector
 };
+struct KinCut {        // SampleHandlerFD::IsEventSelected (SampleHandlerFD.cpp:281-294): keep lo <= x < hi
+  int32_t sample;      // -1 = every sample
+  int32_t column;      // column of the kinematics array (binning axes first, extra cut variables after)
+  double lo, hi;
+};
 struct BinArgs {
   const BinSample* samples;
   const BinAxis* axes;
@@ -139,6 +144,8 @@ struct BinArgs {
   int32_t* bin;              // [E_pad] out: global bin
   const KinShift* shifts;
   int32_t n_shifts;
+  const KinCut* cuts;
+  int32_t n_cuts;
   const double* params;      // device parameter vector (needed when n_shifts > 0)
   int32_t kin_stride;
   int32_t compute_nominal;   // 1: set-up pass, fill nom_bin with upper_bound; 0: per-step pass using nom_bin

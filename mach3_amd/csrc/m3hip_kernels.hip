@@ -498,27 +498,40 @@ __device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin
 __global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
   const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (ev >= a.n_events) return;
-  const BinSample sm = a.samples[a.sample_id[ev]];
-  int global = 0;
+  const int sid = a.sample_id[ev];
+  const BinSample sm = a.samples[sid];
+  // ApplyShifts (SampleHandlerFD.cpp:545-564): nominal values, then every registered shift in order
+  double x[M3_MAX_DIM];
+  for (int c = 0; c < a.kin_stride; ++c) x[c] = a.kin[ev * a.kin_stride + c];
+  if (!a.compute_nominal) {
+    for (int s = 0; s < a.n_shifts; ++s) {
+      const KinShift sh = a.shifts[s];
+      if (sh.dim < a.kin_stride && (sh.sample < 0 || sh.sample == sid)) {
+        const double th = a.params[sh.param];
+        x[sh.dim] = sh.kind == 1 ? x[sh.dim] * (1.0 + th) : x[sh.dim] + th;
+      }
+    }
+  }
+  // IsEventSelected (SampleHandlerFD.cpp:281-294), on the shifted values
   bool out = false;
+  for (int c = 0; c < a.n_cuts; ++c) {
+    const KinCut ct = a.cuts[c];
+    if (ct.column < a.kin_stride && (ct.sample < 0 || ct.sample == sid)) {
+      const double v = x[ct.column];
+      if ((v < ct.lo) || (v >= ct.hi)) out = true;
+    }
+  }
+  int global = 0;
   for (int d = 0; d < sm.n_dim; ++d) {
     const BinAxis ax = a.axes[sm.axis_off + d];
     const double* e = a.edges + ax.edge_off;
-    double x = a.kin[ev * a.kin_stride + d];
     int b;
     if (a.compute_nominal) {
       // BinningHandler::FindNominalBin (BinningHandler.cpp:294-307)
-      b = (x < e[0] || x >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x);
+      b = (x[d] < e[0] || x[d] >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x[d]);
       a.nom_bin[ev * a.kin_stride + d] = b;
     } else {
-      for (int s = 0; s < a.n_shifts; ++s) {  // ApplyShifts: nominal value, then every shift in order
-        const KinShift sh = a.shifts[s];
-        if (sh.dim == d && (sh.sample < 0 || sh.sample == a.sample_id[ev])) {
-          const double th = a.params[sh.param];
-          x = sh.kind == 1 ? x * (1.0 + th) : x + th;
-        }
-      }
-      b = d_find_bin(e, ax.n_bins, x, a.nom_bin[ev * a.kin_stride + d]);
+      b = d_find_bin(e, ax.n_bins, x[d], a.nom_bin[ev * a.kin_stride + d]);
     }
     if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
     global += b * ax.stride;

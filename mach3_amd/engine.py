@@ -287,6 +287,9 @@ class SampleHandlerFD:
     def AddKinShift(self, sample, dim, kind, param_index):
         self.eng._chk(self.eng.lib.m3hip_add_kin_shift(self.eng.h, int(sample), int(dim), int(kind), int(param_index)))
 
+    def AddKinCut(self, sample, column, lower, upper):
+        self.eng._chk(self.eng.lib.m3hip_add_kin_cut(self.eng.h, int(sample), int(column), float(lower), float(upper)))
+
     def ClearKinShifts(self):
         self.eng._chk(self.eng.lib.m3hip_clear_kin_shifts(self.eng.h))
 

@@ -996,7 +996,15 @@ struct FuncShift_o {
   const double* valuePtr;
 };
 
+// ref: Samples/SampleStructs.h KinematicCut {ParamToCutOnIt, LowerBound, UpperBound}
+struct KinematicCut_o {
+  int sample;  // -1: every sample
+  int column;
+  double LowerBound, UpperBound;
+};
+
 struct m3o_sample {
+  std::vector<KinematicCut_o> Selection;
   std::vector<double> kin_nominal, kin_shifted;  // KinVar pointers alias kin_shifted
   int kin_stride = 1;
   std::vector<FuncShift_o> shifts;
@@ -1082,16 +1090,30 @@ static void ApplyShifts(m3o_sample* s, uint64_t iEvent) {
   const size_t nShifts = s->shifts.size();
   if (nShifts == 0) return;  // :550
   EventInfo_o& ev = s->MCSamples[iEvent];
-  const int ndim = int(ev.KinVar.size());
   // ResetShifts: back to the nominal values
-  for (int d = 0; d < ndim; ++d) s->kin_shifted[iEvent * s->kin_stride + d] = s->kin_nominal[iEvent * s->kin_stride + d];
+  for (int d = 0; d < s->kin_stride; ++d) s->kin_shifted[iEvent * s->kin_stride + d] = s->kin_nominal[iEvent * s->kin_stride + d];
   for (size_t i = 0; i < nShifts; ++i) {
     const FuncShift_o& fp = s->shifts[i];
-    if (fp.dim >= ndim || (fp.sample >= 0 && fp.sample != ev.NominalSample)) continue;
+    if (fp.dim >= s->kin_stride || (fp.sample >= 0 && fp.sample != ev.NominalSample)) continue;
     double& x = s->kin_shifted[iEvent * s->kin_stride + fp.dim];
     const double th = *fp.valuePtr;
     x = fp.kind == 1 ? x * (1.0 + th) : x + th;
   }
+}
+
+// ref: Samples/SampleHandlerFD.cpp:281-294
+static bool IsEventSelected(const m3o_sample* s, int iSample, uint64_t iEvent) {
+  for (const KinematicCut_o& Cut : s->Selection) {
+    if (Cut.sample >= 0 && Cut.sample != iSample) continue;
+    if (Cut.column >= s->kin_stride) continue;
+    const double Val = s->kin_shifted[iEvent * s->kin_stride + Cut.column];  // ReturnKinematicParameter
+    if ((Val < Cut.LowerBound) || (Val >= Cut.UpperBound)) return false;
+  }
+  return true;
+}
+
+void m3o_sample_add_cut(m3o_sample* s, int sample, int column, double lower, double upper) {
+  s->Selection.push_back({sample, column, lower, upper});
 }
 
 void m3o_sample_add_shift(m3o_sample* s, int sample, int dim, int kind, const double* value_ptr) {
@@ -1120,6 +1142,7 @@ static void FillArray(m3o_sample* s) {
   for (uint64_t iEvent = 0; iEvent < NumberOfEvents; ++iEvent) {
     ApplyShifts(s, iEvent);  // ref: :419, before the selection and the weight
     const EventInfo_o* MCEvent = &s->MCSamples[iEvent];
+    if (!IsEventSelected(s, MCEvent->NominalSample, iEvent)) continue;  // ref: :423
     const m3_float_t totalweight = CalcWeightTotal(MCEvent);
     if (totalweight <= 0.) continue;  // ref: :432
     const int GlobalBin = s->Binning->FindGlobalBin(MCEvent->NominalSample, MCEvent->KinVar, MCEvent->NomBin);
@@ -1191,6 +1214,7 @@ void m3o_sample_event_weights(const m3o_sample* s, float* out) {
 void m3o_sample_event_bins(const m3o_sample* s, int32_t* out) {
   for (size_t e = 0; e < s->MCSamples.size(); ++e) {
     ApplyShifts(const_cast<m3o_sample*>(s), e);
+    if (!IsEventSelected(s, s->MCSamples[e].NominalSample, e)) { out[e] = M3O_UNDER_OVERFLOW_BIN; continue; }
     const EventInfo_o& ev = s->MCSamples[e];
     out[e] = s->Binning->FindGlobalBin(ev.NominalSample, ev.KinVar, ev.NomBin);
   }

@@ -55,6 +55,7 @@ def load(variant="serial"):
     lib.m3o_binning_find_global_bin.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_find_global_bin.restype = i32
     lib.m3o_sample_create.argtypes = [vp, u64, vp, i32, vp, vp, vp, vp, vp, vp, vp]; lib.m3o_sample_create.restype = vp
     lib.m3o_sample_destroy.argtypes = [vp]; lib.m3o_sample_destroy.restype = None
+    lib.m3o_sample_add_cut.argtypes = [vp, i32, i32, dbl, dbl]; lib.m3o_sample_add_cut.restype = None
     lib.m3o_sample_add_shift.argtypes = [vp, i32, i32, i32, vp]; lib.m3o_sample_add_shift.restype = None
     lib.m3o_sample_set_test_statistic.argtypes = [vp, i32, i32]; lib.m3o_sample_set_test_statistic.restype = None
     lib.m3o_sample_add_data.argtypes = [vp, vp]; lib.m3o_sample_add_data.restype = None
@@ -227,6 +228,9 @@ class OracleSample:
     def set_binned(self, binned: OracleBinned, w_off, w_idx):
         self.keep = self.keep + (binned, w_off, w_idx)
         self.lib.m3o_sample_set_binned(self.h, binned.h, w_off.ctypes.data, w_idx.ctypes.data)
+
+    def add_cut(self, sample, column, lower, upper):
+        self.lib.m3o_sample_add_cut(self.h, sample, column, float(lower), float(upper))
 
     def add_shift(self, sample, dim, kind, par, index):
         self.lib.m3o_sample_add_shift(self.h, sample, dim, kind, par.ctypes.data + 8 * int(index))

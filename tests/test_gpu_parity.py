@@ -592,3 +592,49 @@ def test_binned_splines_match_oracle(fresh_engine):
     assert clamped > 0   # the weight < 0 -> 0 clamp was exercised
     osamp.close()
     ob_binned.close()
+
+
+def test_kinematic_cuts_on_shifted_variables(fresh_engine):
+    """SampleHandlerFD::IsEventSelected (ref: Samples/SampleHandlerFD.cpp:281-294): cuts lo <= x < hi on
+    a binning axis and on a cut-only column, evaluated after the functional shifts."""
+    rng = np.random.default_rng(23)
+    E, P = 3000, 2
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    ex = np.linspace(0.0, 5.0, 26)
+    sample_id = rng.integers(0, 2, E).astype(np.int32)
+    kin = np.stack([rng.gamma(3.0, 0.45, E), rng.uniform(0.0, 10.0, E)], axis=1)   # column 1: cut-only variable
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    b.add_uniform([ex])
+    b.add_uniform([ex])
+    par = np.zeros(P + 1)
+    opar = par.copy()
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, None, None, opar, None, None, omono)
+    osamp.add_shift(-1, 1, 2, opar, P)      # the cut variable moves with a parameter
+    osamp.add_cut(-1, 0, 0.5, 3.0)          # axis 0: [0.5, 3.0)
+    osamp.add_cut(1, 1, 2.0, 7.5)           # sample 1 only, on the cut-only column
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 2, None, par, bin_edges=[[ex], [ex]])
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    sh.AddKinShift(-1, 1, 2, P)
+    sh.AddKinCut(-1, 0, 0.5, 3.0)
+    sh.AddKinCut(1, 1, 2.0, 7.5)
+    n_sel = []
+    for off in (0.0, 1.5, -2.5, 0.0):
+        par[:P] = rng.uniform(-1, 1, P)
+        par[P] = off
+        opar[:] = par
+        sh.Reweight()
+        osamp.reweight()
+        got, exp = sh.GetEventBins(0, E), osamp.event_bins()
+        assert np.array_equal(got, exp), off
+        n_sel.append(int((got >= 0).sum()))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+    assert 0 < min(n_sel) < max(n_sel) < E and n_sel[0] == n_sel[-1]
+    osamp.close()
+    omono.close()
