@@ -14,6 +14,8 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -63,6 +65,52 @@ class BinningHandler {
     Samples.push_back(std::move(s));
     return int(Samples.size()) - 1;
   }
+  /// Non-uniform binning: every bin is an N-dimensional box {lo, hi} per axis, a point belongs to it
+  /// when lo < x <= hi on every axis (ref: Samples/SampleStructs.h:186-220).  Bins are found through
+  /// a coarse 10-cells-per-axis grid over their bounding box whose cells list the boxes they overlap
+  /// (SampleStructs.h:397-530); the grid itself is searched like uniform bins, [lo, hi).
+  int AddNonUniformSample(const std::vector<std::vector<std::array<double, 2>>>& boxes) {
+    if (boxes.empty() || boxes[0].size() < 2) throw MaCh3Exception(__FILE__, __LINE__, "non-uniform binning needs >= 2 dimensions");
+    const size_t dim = boxes[0].size();
+    Sample s;
+    s.Uniform = false;
+    s.Boxes = boxes;
+    constexpr int kCells = 10;
+    for (size_t d = 0; d < dim; ++d) {
+      double lo = std::numeric_limits<double>::max(), hi = std::numeric_limits<double>::lowest();
+      for (const auto& b : boxes) {
+        if (b.size() != dim) throw MaCh3Exception(__FILE__, __LINE__, "bins of different dimension");
+        lo = std::min(lo, b[d][0]);
+        hi = std::max(hi, b[d][1]);
+      }
+      std::vector<double> e(kCells + 1);
+      const double w = (hi - lo) / double(kCells);
+      for (int i = 0; i <= kCells; ++i) e[size_t(i)] = lo + double(i) * w;
+      s.Edges.push_back(e);
+    }
+    int stride = 1;
+    for (size_t d = 0; d < dim; ++d) {
+      s.Strides.push_back(stride);
+      stride *= kCells;
+    }
+    s.CellBoxes.assign(size_t(stride), {});
+    std::vector<int> idx(dim, 0);
+    for (int cell = 0; cell < stride; ++cell) {  // cell = sum idx[d] * 10^d
+      int r = cell;
+      for (size_t d = 0; d < dim; ++d) { idx[d] = r % kCells; r /= kCells; }
+      for (size_t ib = 0; ib < boxes.size(); ++ib) {
+        bool overlap = true;
+        for (size_t d = 0; d < dim && overlap; ++d)
+          overlap = boxes[ib][d][1] > s.Edges[d][size_t(idx[d])] && boxes[ib][d][0] < s.Edges[d][size_t(idx[d]) + 1];
+        if (overlap) s.CellBoxes[size_t(cell)].push_back(int(ib));
+      }
+    }
+    s.nBins = int(boxes.size());
+    s.GlobalOffset = TotalBins;
+    TotalBins += s.nBins;
+    Samples.push_back(std::move(s));
+    return int(Samples.size()) - 1;
+  }
   int GetNBins() const { return TotalBins; }
   int GetNBins(int Sample) const { return Samples[Sample].nBins; }
   int GetNSamples() const { return int(Samples.size()); }
@@ -94,7 +142,13 @@ class BinningHandler {
       }
       Global += b * s.Strides[d];
     }
-    return Global + s.GlobalOffset;
+    if (s.Uniform) return Global + s.GlobalOffset;
+    for (int ib : s.CellBoxes[size_t(Global)]) {  // ref: Samples/BinningHandler.cpp:277-289
+      bool inside = true;
+      for (size_t d = 0; d < KinVar.size(); ++d) inside &= (*KinVar[d] > s.Boxes[size_t(ib)][d][0]) & (*KinVar[d] <= s.Boxes[size_t(ib)][d][1]);
+      if (inside) return ib + s.GlobalOffset;
+    }
+    return M3::UnderOverFlowBin;
   }
   std::vector<int32_t> SampleBinOffsets() const {
     std::vector<int32_t> off;
@@ -108,6 +162,9 @@ class BinningHandler {
     std::vector<std::vector<double>> Edges;
     std::vector<int> Strides;
     int nBins = 0, GlobalOffset = 0;
+    bool Uniform = true;
+    std::vector<std::vector<std::array<double, 2>>> Boxes;  // non-uniform bins
+    std::vector<std::vector<int>> CellBoxes;                // grid cell -> candidate bins
   };
   std::vector<Sample> Samples;
   int TotalBins = 0;

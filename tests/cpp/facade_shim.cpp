@@ -36,7 +36,17 @@ double facade_spline_eval(int n, const float* x, const float* y, const float* bc
   return s.Eval(var);
 }
 
-// BinningHandler of the facade: global bin of one event (uniform N-D), for integer parity
+// BinningHandler of the facade: global bin of one event, for integer parity with the oracle
+static int find_bin(const BinningHandler& b, int sample, const double* kin, const int* nom_bin) {
+  std::vector<const double*> kv;
+  std::vector<int> nb;
+  for (int d = 0; d < b.GetNDim(sample); ++d) {
+    kv.push_back(&kin[d]);
+    nb.push_back(nom_bin ? nom_bin[d] : b.FindNominalBin(sample, d, kin[d]));
+  }
+  return b.FindGlobalBin(sample, kv, nb);
+}
+
 int facade_find_global_bin(int n_samples, const int* n_dim, const int* n_edges, const double* edges, int sample, const double* kin,
                            const int* nom_bin) {
   BinningHandler b;
@@ -50,12 +60,17 @@ int facade_find_global_bin(int n_samples, const int* n_dim, const int* n_edges, 
     }
     b.AddUniformSample(ed);
   }
-  std::vector<const double*> kv;
-  std::vector<int> nb;
-  for (int d = 0; d < b.GetNDim(sample); ++d) {
-    kv.push_back(&kin[d]);
-    nb.push_back(nom_bin ? nom_bin[d] : b.FindNominalBin(sample, d, kin[d]));
-  }
-  return b.FindGlobalBin(sample, kv, nb);
+  return find_bin(b, sample, kin, nom_bin);
+}
+
+// non-uniform sample: boxes[n_boxes][n_dim][2]
+int facade_find_nonuniform_bin(int n_boxes, int n_dim, const double* boxes, const double* kin, const int* nom_bin) {
+  BinningHandler b;
+  const std::vector<std::array<double, 2>> one_box(static_cast<size_t>(n_dim));
+  std::vector<std::vector<std::array<double, 2>>> bx(static_cast<size_t>(n_boxes), one_box);
+  for (int i = 0; i < n_boxes; ++i)
+    for (int d = 0; d < n_dim; ++d) bx[size_t(i)][size_t(d)] = {boxes[(size_t(i) * n_dim + d) * 2], boxes[(size_t(i) * n_dim + d) * 2 + 1]};
+  const int sample = b.AddNonUniformSample(bx);
+  return find_bin(b, sample, kin, nom_bin);
 }
 }

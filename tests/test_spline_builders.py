@@ -152,3 +152,26 @@ def test_facade_binning_handler_matches_oracle(shim):
         exp = b.find_global_bin(s, kin[:ndim], nom_a[:ndim])
         got = shim.facade_find_global_bin(2, n_dim.ctypes.data, n_edges.ctypes.data, edges.ctypes.data, s, kin.ctypes.data, nom_a.ctypes.data)
         assert got == exp, (s, kin, nom, got, exp)
+
+
+def test_facade_nonuniform_binning_matches_oracle(shim):
+    """non-uniform (box) bins through the 10x10 mega-bin grid: facade == oracle, including points on box
+    edges (the reference's (lo,hi] boxes looked up through a [lo,hi) grid)"""
+    shim.facade_find_nonuniform_bin.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    olib = ob.load("serial")
+    # an irregular tiling of [0,4] x [0,3]
+    boxes = np.array([[[0, 1], [0, 1]], [[1, 2.5], [0, 1]], [[2.5, 4], [0, 1.5]], [[0, 2.5], [1, 3]], [[2.5, 4], [1.5, 3]]], np.float64)
+    b = ob.OracleBinning(olib)
+    assert b.add_nonuniform(boxes) == 0
+    rng = np.random.default_rng(4)
+    pts = np.stack([rng.uniform(-0.2, 4.2, 4000), rng.uniform(-0.2, 3.2, 4000)], axis=1)
+    pts[:300, 0] = rng.choice([0, 1, 2.5, 4, 0.4, 0.8, 1.2, 1.6, 2.0, 2.4, 2.8], 300)   # box and grid edges
+    pts[300:600, 1] = rng.choice([0, 1, 1.5, 3, 0.3, 0.6, 0.9, 1.2, 2.1], 300)
+    hits = set()
+    for k in pts:
+        nom = np.array([b.find_nominal_bin(0, 0, k[0]), b.find_nominal_bin(0, 1, k[1])], np.int32)
+        exp = b.find_global_bin(0, k, nom)
+        got = shim.facade_find_nonuniform_bin(len(boxes), 2, boxes.ctypes.data, np.ascontiguousarray(k).ctypes.data, nom.ctypes.data)
+        assert got == exp, (k, got, exp)
+        hits.add(got)
+    assert hits == {-1, 0, 1, 2, 3, 4}
