@@ -155,6 +155,49 @@ __device__ __forceinline__ float2 stream_load(const float2* p) {
   return *p;
 }
 
+// Per-event gathers of the fused epilogue, batched so that several independent loads are in
+// flight per lane (a plain loop over a run-time slot count serialises index load -> gather).
+// Multiplication order is the slot order, as CalcWeightTotal walks its pointer vectors.
+__device__ __forceinline__ float mul_binned_weights(float tw, const ReweightArgs& a, uint64_t ev) {
+  uint32_t k = 0;
+  for (; k + 4 <= a.n_bw_slots; k += 4) {
+    int bi[4];
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bi[u] = a.bwidx[(uint64_t)(k + u) * a.e_pad + ev];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = bi[u] >= 0 ? a.bw[bi[u]] : 1.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (bi[u] >= 0) tw *= wv[u];
+  }
+  for (; k < a.n_bw_slots; ++k) {
+    const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
+    if (bi >= 0) tw *= a.bw[bi];
+  }
+  return tw;
+}
+
+__device__ __forceinline__ float mul_norm_weights(float tw, const ReweightArgs& a, uint64_t ev) {
+  uint32_t m = 0;
+  for (; m + 4 <= a.n_norm_slots; m += 4) {
+    int idx[4];
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) idx[u] = a.nidx[(uint64_t)(m + u) * a.e_pad + ev];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = idx[u] >= 0 ? a.params[idx[u]] : 1.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (idx[u] >= 0) tw *= static_cast<float>(v[u]);  // double -> float cast per pointer (SampleHandlerFD.cpp:580)
+  }
+  for (; m < a.n_norm_slots; ++m) {
+    const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
+    if (idx >= 0) tw *= static_cast<float>(a.params[idx]);
+  }
+  return tw;
+}
+
 template <int MODE, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 (kModeFill only)
@@ -223,17 +266,10 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   if (MODE & (kModeFill | kModeEventW)) {
     // ---- kernel (ii): CalcWeightTotal (SampleHandlerFD.cpp:568-594): norm pointers first
     // (double -> float cast each), then total_weight_pointers = {osc, spline total weight}.
-    float tw = 1.0f;
-    for (uint32_t m = 0; m < a.n_norm_slots; ++m) {
-      const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
-      if (idx >= 0) tw *= static_cast<float>(a.params[idx]);  // -1: empty ELL slot
-    }
+    float tw = mul_norm_weights(1.0f, a, ev);  // -1: empty ELL slot
     const int oi = a.osc[ev];
     if (oi >= 0) tw *= a.osc_table[oi];
-    for (uint32_t k = 0; k < a.n_bw_slots; ++k) {  // bin-spline weights, in SetSplinePointers order
-      const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
-      if (bi >= 0) tw *= a.bw[bi];
-    }
+    tw = mul_binned_weights(tw, a, ev);  // bin-spline weights, in SetSplinePointers order
     tw *= w;
     if (MODE & kModeEventW) a.event_w[ev] = tw;
     if (MODE & kModeFill) {
@@ -414,17 +450,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
     const uint64_t ev = (uint64_t)bd.first_event + e;
     if (MODE & kModeEval) a.spline_w[ev] = w[q];
     if (MODE & (kModeFill | kModeEventW)) {
-      float tw = 1.0f;  // CalcWeightTotal, as in k_reweight_uniform
-      for (uint32_t mm = 0; mm < a.n_norm_slots; ++mm) {
-        const int idx = a.nidx[(uint64_t)mm * a.e_pad + ev];
-        if (idx >= 0) tw *= static_cast<float>(a.params[idx]);
-      }
+      float tw = mul_norm_weights(1.0f, a, ev);  // CalcWeightTotal, as in k_reweight_uniform
       const int oi = a.osc[ev];
       if (oi >= 0) tw *= a.osc_table[oi];
-      for (uint32_t k = 0; k < a.n_bw_slots; ++k) {
-        const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
-        if (bi >= 0) tw *= a.bw[bi];
-      }
+      tw = mul_binned_weights(tw, a, ev);
       tw *= w[q];
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {

@@ -1,0 +1,64 @@
+"""Timings of the widened rows (binned splines, device binning with shifts, seam-2 eval path).
+Numbers go into DESIGN.md section 8; not part of bench.py's contract."""
+import sys, os, time
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
+import numpy as np
+from mach3_amd import synth, capi
+from mach3_amd.engine import Engine, SMonolith, SampleHandlerFD, BinnedSplineHandler, build_from_synth
+from helpers import make_binned
+
+def timeit(fn, n=200, spin=0.7):
+    t=time.perf_counter()
+    while time.perf_counter()-t<spin: fn()
+    t=time.perf_counter()
+    for _ in range(n): fn()
+    return (time.perf_counter()-t)/n*1e6
+
+rng=np.random.default_rng(5)
+# ---- binned splines: 1e6 events, 50 unique parameters, 1e6 bin-splines, ~30 weights per event
+P, cells, E = 50, 20000, 1_000_000
+bs = make_binned(P, cells, rng)
+cell = rng.integers(0, cells, E)
+mask = rng.random((E, P)) < 0.6
+cnt = mask.sum(1)
+w_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+w_idx = (cell[:, None] * P + np.arange(P)[None, :])[mask].astype(np.int32)
+par = np.zeros(P + 4); par[P:] = 1
+eng = Engine(0)
+h = BinnedSplineHandler(eng, E, bs); h.setSplinePointers(par)
+edges = np.linspace(0, 5, 201); kin = rng.gamma(3.0, 0.35, E); sid = np.zeros(E, np.int32)
+sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kBarlowBeeston)
+sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sid, 200), rng.integers(-1, 4000, E).astype(np.int32), None, None)
+h.SetEventSplines(0, w_off, w_idx); sh.SetOscillationWeights(rng.random(4000).astype(np.float32))
+sh.Reweight(); sh.AddData(sh.GetMCArray())
+def step():
+    par[:P] = rng.uniform(-2, 2, P); return sh.Step()
+eng.timing_enable(True); us = timeit(step); k_ms,_ = eng.timing_read(0)
+print(f"binned: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: step {us:.1f} us, event kernel {k_ms*1e3:.1f} us "
+      f"({(w_idx.nbytes + 8*E)/k_ms/1e6:.0f} GB/s of index+bin/osc bytes)")
+eng.close()
+
+# ---- device binning + one energy-scale shift on config 2 at 1e6 events
+spec = synth.CONFIGS["c2"].scaled(1_000_000, n_params=16)
+eng, mono, sh0, par = build_from_synth(spec)
+ev = synth.events_chunk(spec, 0, spec.n_events)
+par2 = np.concatenate([par, [0.0]])
+sh = SampleHandlerFD(eng, 1, None, par2, bin_edges=[[synth.bin_edges(spec)]])
+sh.SetupKinematics(0, ev["sample_id"], ev["erec"]); sh.ComputeBins()
+sh.SetupEvents(0, sh.GetEventBins(0, spec.n_events), ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+sh.SetOscillationWeights(synth.osc_table(spec))
+sh.Reweight(); sh.AddData(sh.GetMCArray())
+def step2():
+    par2[:spec.n_par] = synth.params(spec, int(rng.integers(1, 60))); par2[-1] = 0.02*rng.standard_normal(); return sh.Step()
+a = timeit(step2)
+sh.AddKinShift(-1, 0, 1, spec.n_par)
+b = timeit(step2)
+print(f"device re-binning: E=1e6, 1-D 200 bins, one scale shift: step {a:.1f} us without, {b:.1f} us with shifts (+{b-a:.1f} us for k_find_bins)")
+# ---- seam 2: SMonolith::Evaluate + SynchroniseMemTransfer incl. the 4 MB device-to-host copy
+mono.setSplinePointers(par)
+def step3():
+    par[:] = synth.params(spec, int(rng.integers(1, 60))); mono.Evaluate(); mono.SynchroniseMemTransfer()
+c = timeit(step3, n=100)
+print(f"seam 2 (Evaluate + sync, E=1e6 x 16 splines, 4 MB of weights D2H per step): {c:.1f} us/step")
+eng.close()
