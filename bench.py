@@ -171,7 +171,7 @@ def main():
             ok = torch.zeros(1, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) > 0:
-            comm_mode = "rccl-allreduce(f64[32 x n_bins]) in-library"
+            comm_mode = "rccl-allreduce(f64[n_bins]) in-library, one per step"
         else:
             comm_mode = "torch.distributed all_reduce of the bin vector (fallback)"
     elif world > 1:

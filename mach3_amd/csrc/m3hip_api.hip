@@ -1121,8 +1121,14 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   }
   HIPCHK(h, hipGetLastError());
   if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
-    const size_t count = size_t(h->n_bins) * h->hist_rep * (h->first_w2 ? 2 : 1);
-    int r = g_rccl.AllReduce(h->d_hist, h->d_hist, count, /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    // fold the 32 flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins), and w2
+    // only travels while it is still being accumulated
+    launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, h->first_w2 ? 1 : 0, h->stream);
+    int r = g_rccl.AllReduce(h->d_hist, h->d_hist, size_t(h->n_bins), /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
+    if (r == 0 && h->first_w2) {
+      double* w2 = h->d_hist + size_t(h->hist_rep) * h->n_bins;
+      r = g_rccl.AllReduce(w2, w2, size_t(h->n_bins), 8, 0, h->comm, h->stream);
+    }
     if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
   }
   if (!h->update_w2) h->first_w2 = false;  // SampleHandlerFD.cpp:342

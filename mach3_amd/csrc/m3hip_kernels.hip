@@ -703,6 +703,28 @@ __device__ double block_sum_256(double v, double* scratch /*[4]*/) {
   return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
+// fold the flush replicas into replica 0 (same fixed order as k_llh), so that the multi-GPU
+// all-reduce moves n_bins doubles instead of hist_rep * n_bins
+__global__ __launch_bounds__(256) void k_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2) {
+  for (int i = threadIdx.x; i < n_bins * (with_w2 ? 2 : 1); i += 256) {
+    double* base = hist + (i < n_bins ? i : (size_t)hist_rep * n_bins + (i - n_bins));
+    double m = 0.0;
+    for (int r0 = 0; r0 < hist_rep; r0 += 8) {
+      double am[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m += am[u];
+    }
+    base[0] = m;
+    for (int r = 1; r < hist_rep; ++r) base[(size_t)r * n_bins] = 0.0;
+  }
+}
+
+void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s) {
+  hipLaunchKernelGGL(k_fold_hist, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins, with_w2);
+}
+
 __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   __shared__ double scratch[4];
   // fold the flush replicas (fixed order) into the first one; afterwards mc / w2 are plain vectors
