@@ -337,8 +337,10 @@ struct RRun {      // per-step resolved run: address = base + r, dx of the run's
   float dx;
 };
 
-// Latency structure per stage: {run entries, response words, event words} are independent global
-// loads issued together; the only dependent global access is the coefficient load itself.
+// Latency structure: the kernel is software-pipelined over stages.  While stage s waits for its
+// coefficient loads, the independent loads of stage s+1 (event slices, response words, run
+// entries -> resolved run table in the other LDS buffer) are already in flight, so per stage only
+// ONE dependent HBM round trip (the coefficient load itself) sits on the critical path.
 template <int MODE, bool NT>
 __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
@@ -362,20 +364,27 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
   for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
 
   const uint32_t n_stages = lds_hdr[0];
-  for (uint32_t s = 0; s < n_stages; ++s) {
+  // what a stage needs before its coefficient loads can be issued
+  uint32_t ec_n[kBrickEvPerLane];
+  uint32_t m_n[kBrickRespPerLane];
+
+  auto prefetch = [&](uint32_t s) {
     const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
     const uint32_t kind = h[0], n_resp = h[1];
-    // event slices of this stage (used in phase B; issued now so the miss overlaps phase A)
-    uint32_t ec[kBrickEvPerLane];
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
       const uint32_t e = lane * kBrickEvPerLane + q;
-      ec[q] = e < bd.n_events ? words[h[5] + e] : 0u;
+      ec_n[q] = e < bd.n_events ? words[h[5] + e] : 0u;
     }
     if (kind == 0) {
+      const uint32_t* __restrict__ resp = words + h[4];
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        m_n[u] = r < n_resp ? resp[r] : 0u;
+      }
       RRun* runs_s = lds_runs[s & 1];
       const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
-      const uint32_t* __restrict__ resp = words + h[4];
       const uint32_t n_runs = h[2];
       for (uint32_t r = lane; r < n_runs; r += kBrickThreads) {  // resolve the stage's runs for this step
         const uint4 rt = runs[r];  // {coef_off, n_run, start_r, param}
@@ -385,14 +394,23 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
         rr.dx = pt.dx;
         runs_s[r] = rr;
       }
-      // every response word of the lane for this stage, issued together with the run entries
-      uint32_t m[kBrickRespPerLane];
+    }
+  };
+
+  if (n_stages > 0) prefetch(0);
+  for (uint32_t s = 0; s < n_stages; ++s) {
+    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
+    const uint32_t kind = h[0], n_resp = h[1];
+    uint32_t ec[kBrickEvPerLane];
+    uint32_t m[kBrickRespPerLane];
 #pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        m[u] = r < n_resp ? resp[r] : 0u;
-      }
-      __syncthreads();
+    for (int q = 0; q < kBrickEvPerLane; ++q) ec[q] = ec_n[q];
+#pragma unroll
+    for (int u = 0; u < kBrickRespPerLane; ++u) m[u] = m_n[u];
+    // stage s's run table is complete, and phase B of stage s-1 no longer reads stage_w
+    __syncthreads();
+    if (kind == 0) {
+      const RRun* runs_s = lds_runs[s & 1];
 #pragma unroll
       for (int b0 = 0; b0 < kBrickRespPerLane; b0 += kBrickBatch) {
         if ((uint32_t)(b0 * kBrickThreads) < n_resp) {  // wave-uniform
@@ -402,10 +420,11 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
           for (int u = 0; u < kBrickBatch; ++u) {
             const uint32_t r = lane + (b0 + u) * kBrickThreads;
             const RRun rr = runs_s[m[b0 + u] & 0xFFFFu];
-            // lanes past the end read the stage's first quad (in range) and discard it
-            c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(r < n_resp ? rr.base + (int32_t)r : rr.base + (int32_t)0)]);
+            // lanes past the end read an in-range quad and discard it
+            c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(r < n_resp ? rr.base + (int32_t)r : rr.base)]);
             dx[u] = rr.dx;
           }
+          if (b0 == 0 && s + 1 < n_stages) prefetch(s + 1);  // rides under the coefficient loads
 #pragma unroll
           for (int u = 0; u < kBrickBatch; ++u) {
             const uint32_t r = lane + (b0 + u) * kBrickThreads;
@@ -416,21 +435,24 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
     } else {
       const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
       const float2* __restrict__ tp = bd.tf1 + h[6];
-      for (uint32_t r0 = 0; r0 < n_resp; r0 += kBrickBatch * kBrickThreads) {
-        float2 c[kBrickBatch];
-        uint32_t p[kBrickBatch];
 #pragma unroll
-        for (int u = 0; u < kBrickBatch; ++u) {
-          const uint32_t r = r0 + lane + u * kBrickThreads;
-          if (r < n_resp) {
-            p[u] = par[r];
-            c[u] = stream_load<NT>(&tp[r]);
+      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += 8) {
+        if ((uint32_t)(b0 * kBrickThreads) < n_resp) {
+          float2 c[8];
+          uint32_t p[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t r = lane + (b0 + u) * kBrickThreads;
+            const uint32_t rr = r < n_resp ? r : 0u;
+            p[u] = par[rr];
+            c[u] = stream_load<NT>(&tp[rr]);
           }
-        }
+          if (b0 == 0 && s + 1 < n_stages) prefetch(s + 1);
 #pragma unroll
-        for (int u = 0; u < kBrickBatch; ++u) {
-          const uint32_t r = r0 + lane + u * kBrickThreads;
-          if (r < n_resp) stage_w[r] = fmaf(c[u].x, a.pval[p[u]], c[u].y);  // SplineMonolith.cpp:779
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t r = lane + (b0 + u) * kBrickThreads;
+            if (r < n_resp) stage_w[r] = fmaf(c[u].x, a.pval[p[u]], c[u].y);  // SplineMonolith.cpp:779
+          }
         }
       }
     }
@@ -441,8 +463,8 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
       const uint32_t start = ec[q] & 0xFFFFu, cnt = ec[q] >> 16;
       for (uint32_t i = 0; i < cnt; ++i) w[q] *= stage_w[start + i];
     }
-    __syncthreads();
   }
+  __syncthreads();  // last phase B / lds_hist zeroing complete
 
 #pragma unroll
   for (int q = 0; q < kBrickEvPerLane; ++q) {
