@@ -3,9 +3,10 @@
 //      (the reference's constructor signature, Splines/SplineMonolith.h:18-26);
 //   2. FitterBase::DragRace: times Reweight() and GetLikelihood() over NLaps
 //      (ref: Fitters/FitterBase.cpp:461-520);
-//   3. a short Metropolis chain in MR2T2::ProposeStep order: propose -> prior / bounds ->
-//      skip reweight when out of bounds -> Reweight -> GetLikelihood -> accept/reject
-//      (ref: Fitters/MR2T2.cpp:25-115, Fitters/MCMCBase.cpp:188-216).
+//   3. Markov chains with the facade's ROOT-free fitters (include/mach3_amd/Fitters.h): MR2T2
+//      (propose -> prior / bounds -> skip reweight when out of bounds -> Reweight -> GetLikelihood ->
+//      accept/reject; ref: Fitters/MR2T2.cpp:25-115), the same with the adaptive proposal
+//      (Parameters/AdaptiveMCMCHandler.cpp:332-397) and DelayedMR2T2 (Fitters/DelayedMR2T2.cpp:95-235).
 // Synthetic MC comes from libm3synth (same generator as the tests and bench.py).
 //
 //   usage: mr2t2_dragrace [n_events=50000] [n_params=32] [n_laps=100] [n_steps=2000]
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <random>
 
+#include "../include/mach3_amd/Fitters.h"
 #include "../include/mach3_amd/SampleHandlerFD.h"
 #include "../mach3_amd/synth/m3synth.h"
 
@@ -75,25 +77,29 @@ int main(int argc, char** argv) {
     }
     std::vector<float>().swap(coeff_many);
 
-    std::vector<double> par(nPar), nominal(nPar), sigma(nPar), lo(nPar), hi(nPar);
-    m3synth_params(&cfg, 0, par.data());
-    nominal = par;
+    std::vector<double> nominal(nPar), sigma(nPar), lo(nPar), hi(nPar), cov(size_t(nPar) * nPar, 0.0);
+    m3synth_params(&cfg, 0, nominal.data());
     for (int i = 0; i < nPar; ++i) {
       sigma[i] = i < P ? 1.0 : 0.1;
       lo[i] = i < P ? -5.0 : 0.0;
       hi[i] = i < P ? 5.0 : 2.0;
+      cov[size_t(i) * nPar + i] = sigma[i] * sigma[i];
     }
+    // the parameter handler owns the proposed values; splines and the sample read them through pointers
+    ParameterHandlerBase ph("synthetic_systematics", nominal, cov, lo, hi, {}, 4242);
+    auto setpar = [&](int i, double v) { ph.SetParCurrProp(i, v); };
 
     double t0 = now_s();
     auto splines = std::make_unique<SMonolith>(MasterSpline, SplineType);
     std::vector<const double*> ptrs(P);
-    for (int p = 0; p < P; ++p) ptrs[p] = &par[p];
+    for (int p = 0; p < P; ++p) ptrs[p] = ph.RetPointer(p);
     splines->setSplinePointers(ptrs);
     std::printf("SMonolith: %llu events, %d parameters, %llu TSpline3 + %llu TF1 responses, upload %.2f s\n",
                 (unsigned long long)E, P, (unsigned long long)S, (unsigned long long)T, now_s() - t0);
 
     // seam 1 check: SMonolith::Evaluate against TSpline3_red::Eval / TF1_red::Eval in double
-    for (int p = 0; p < P; ++p) par[p] = 0.37 * ((p % 5) - 2);
+    for (int p = 0; p < P; ++p) setpar(p, 0.37 * ((p % 5) - 2));
+    const std::vector<double> par = ph.GetParPropVec();
     splines->Evaluate();
     splines->SynchroniseMemTransfer();
     {
@@ -110,13 +116,13 @@ int main(int argc, char** argv) {
       }
       std::printf("Evaluate(): event weights agree with TSpline3_red::Eval (double) to 2e-5\n");
     }
-    par = nominal;
+    for (int i = 0; i < nPar; ++i) setpar(i, nominal[i]);
 
     auto bins = std::make_unique<BinningHandler>();
     std::vector<double> edges(cfg.n_bins + 1);
     m3synth_bin_edges(&cfg, edges.data());
     for (int s = 0; s < cfg.n_samples; ++s) bins->AddUniformSample({edges});
-    SampleHandlerFD sample("SyntheticFD", std::move(splines), std::move(bins), par.data(), nPar);
+    SampleHandlerFD sample("SyntheticFD", std::move(splines), std::move(bins), ph.RetPointer(0), nPar);
     sample.SetTestStatistic(kBarlowBeeston);
     {
       std::vector<int32_t> sid(E), osc(E);
@@ -138,69 +144,43 @@ int main(int argc, char** argv) {
     const double llh0 = sample.GetLikelihood();
     if (std::fabs(llh0) > 1e-9) throw MaCh3Exception(__FILE__, __LINE__, "Asimov likelihood is not zero");
 
-    // ---- DragRace
-    std::mt19937_64 rng(1234);
-    std::normal_distribution<double> gaus(0.0, 1.0);
+    // ---- DragRace (ref: Fitters/FitterBase.cpp:461-520)
+    MR2T2 fitter(1234);
+    fitter.AddSampleHandler(&sample);
+    fitter.AddSystObj(&ph);
+    ph.SetStepScale(0.5 / std::sqrt(double(nPar)));
     double t_rw = 0, t_llh = 0;
-    // spin-up: a fresh process shows one-off 50-100 ms stalls in its first second of GPU work
-    for (const double t_s = now_s(); now_s() - t_s < 1.0;) {
-      for (int i = 0; i < nPar; ++i) par[i] = nominal[i] + 0.3 * sigma[i] * gaus(rng);
-      sample.Reweight();
-      (void)sample.GetLikelihood();
-    }
-    for (int lap = 0; lap < NLaps + 10; ++lap) {
-      for (int i = 0; i < nPar; ++i) par[i] = nominal[i] + 0.3 * sigma[i] * gaus(rng);
-      const double a = now_s();
-      sample.Reweight();
-      const double b = now_s();
-      const double llh = sample.GetLikelihood();
-      const double c = now_s();
-      (void)llh;
-      if (lap >= 10) { t_rw += b - a; t_llh += c - b; }
-    }
+    fitter.DragRace(std::max(NLaps, 2000), &t_rw, &t_llh);  // also the spin-up: a fresh process shows one-off 50-100 ms stalls
+    fitter.DragRace(NLaps, &t_rw, &t_llh);
     std::printf("DragRace: %d laps, Reweight() launch %.1f us/lap, GetLikelihood() (incl. wait) %.1f us/lap -> %.0f steps/s\n", NLaps,
-                1e6 * t_rw / NLaps, 1e6 * t_llh / NLaps, NLaps / (t_rw + t_llh));
+                1e6 * t_rw, 1e6 * t_llh, 1.0 / (t_rw + t_llh));
 
-    // ---- Metropolis chain, MR2T2 order
-    std::uniform_real_distribution<double> unif(0.0, 1.0);
-    par = nominal;
-    std::vector<double> curr = par, prop(nPar);
-    auto prior = [&](const std::vector<double>& x) {
-      double l = 0;
-      for (int i = 0; i < nPar; ++i) {
-        if (x[i] < lo[i] || x[i] > hi[i]) return M3::_LARGE_LOGL_;  // ref: ParameterHandlerBase.cpp:859-867
-        const double d = (x[i] - nominal[i]) / sigma[i];
-        l += 0.5 * d * d;
-      }
-      return l;
-    };
-    sample.Reweight();
-    double logLCurr = prior(curr) + sample.GetLikelihood();
-    int accepted = 0, skipped = 0;
-    const double scale = 0.5 / std::sqrt(double(nPar));
-    t0 = now_s();
-    for (int step = 0; step < NSteps; ++step) {
-      for (int i = 0; i < nPar; ++i) prop[i] = curr[i] + scale * sigma[i] * gaus(rng);
-      double logLProp = prior(prop);
-      bool out_of_bounds = logLProp >= M3::_LARGE_LOGL_;
-      if (!out_of_bounds) {  // ref: MR2T2.cpp:51-76: out-of-bounds proposals never reach Reweight()
-        std::copy(prop.begin(), prop.end(), par.begin());
-        sample.Reweight();
-        logLProp += sample.GetLikelihood();
-      } else {
-        ++skipped;
-      }
-      const double accProb = out_of_bounds ? 0.0 : std::min(1.0, std::exp(logLCurr - logLProp));  // ref: MR2T2.cpp:103-115
-      if (unif(rng) <= accProb) {
-        curr = prop;
-        logLCurr = logLProp;
-        ++accepted;
-      }
-    }
-    const double el = now_s() - t0;
-    std::printf("MCMC: %d steps in %.3f s = %.0f steps/s, acceptance %.3f, %d out-of-bounds proposals skipped, final -logL %.4f\n", NSteps,
-                el, NSteps / el, double(accepted) / NSteps, skipped, logLCurr);
-    if (accepted == 0 || accepted == NSteps) throw MaCh3Exception(__FILE__, __LINE__, "degenerate acceptance rate");
+    // ---- MR2T2 chain
+    double t0c = now_s();
+    fitter.RunMCMC(NSteps);
+    double el = now_s() - t0c;
+    const double acc_plain = double(fitter.GetAccCount()) / fitter.GetStepCount();
+    std::printf("MCMC: %d steps in %.3f s = %.0f steps/s, acceptance %.3f, %d out-of-bounds proposals skipped, final -logL %.4f\n", NSteps, el,
+                NSteps / el, acc_plain, fitter.GetOutOfBoundsCount(), fitter.GetLogLCurr());
+    if (fitter.GetAccCount() == 0 || fitter.GetAccCount() == NSteps) throw MaCh3Exception(__FILE__, __LINE__, "degenerate acceptance rate");
+
+    // ---- adaptive proposal: the throw matrix follows the chain's own covariance
+    ph.InitialiseAdaption(0, 100 * NSteps, NSteps / 4, std::max(50, NSteps / 10));
+    t0c = now_s();
+    fitter.RunMCMC(NSteps);
+    el = now_s() - t0c;
+    std::printf("MCMC + adaptive proposal: %d more steps, %.0f steps/s, cumulative acceptance %.3f\n", NSteps, NSteps / el,
+                double(fitter.GetAccCount()) / fitter.GetStepCount());
+
+    // ---- delayed rejection on the same sample and parameters
+    DelayedMR2T2 delayed(99, 1.0, 0.5, 2, 0.1);
+    delayed.AddSampleHandler(&sample);
+    delayed.AddSystObj(&ph);
+    t0c = now_s();
+    delayed.RunMCMC(NSteps / 2);
+    el = now_s() - t0c;
+    std::printf("DelayedMR2T2: %d steps, %.0f steps/s, acceptance %.3f (%d accepted at a delayed stage)\n", NSteps / 2, (NSteps / 2) / el,
+                double(delayed.GetAccCount()) / delayed.GetStepCount(), delayed.GetDelayedAcceptCount());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
     return 1;

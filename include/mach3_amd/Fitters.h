@@ -1,0 +1,385 @@
+// Fitters.h -- a ROOT-free step driver for the engine: the callers of the hot
+// path, reduced to what a Markov chain needs.  Host-only, O(nPar^2) per step.
+//
+//   ParameterHandlerBase   Parameters/ParameterHandlerBase.{h,cpp}: ProposeStep (:652-664) =
+//                          Randomize (:690-707) + CorrelateSteps (:726-745), AcceptStep (:748-761),
+//                          CalcLikelihood (:816-841), CheckBounds / GetLikelihood (:844-867),
+//                          UpdateAdaptiveCovariance (:1306-1345) with the Haario update of
+//                          Parameters/AdaptiveMCMCHandler.cpp:332-397
+//   MCMCBase / MR2T2       Fitters/MCMCBase.cpp:32-216, Fitters/MR2T2.cpp:11-115
+//   DelayedMR2T2           Fitters/DelayedMR2T2.cpp:95-235 (delayed rejection, DRAM acceptance)
+//
+// Not here: YAML configuration, ROOT output trees (steps are kept in memory), PCA, parameter
+// flips / circular bounds, tunes, Robbins-Monro scaling, block-wise adaption, multi-chain tools.
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "Core.h"
+#include "SampleHandlerFD.h"
+
+class ParameterHandlerBase {
+ public:
+  /// prior central values, prior covariance (row-major nPar x nPar), bounds; flat_prior[i] drops
+  /// parameter i from the prior term (ref: ParameterHandlerBase.cpp:816-841)
+  ParameterHandlerBase(std::string name, const std::vector<double>& prefit, const std::vector<double>& covariance, const std::vector<double>& low,
+                       const std::vector<double>& up, const std::vector<bool>& flat_prior = {}, uint64_t seed = 0)
+      : matrixName(std::move(name)), _fNumPar(int(prefit.size())), _fPreFitValue(prefit), _fCurrVal(prefit), _fPropVal(prefit), _fLowBound(low),
+        _fUpBound(up), _fFlatPrior(flat_prior.empty() ? std::vector<bool>(prefit.size(), false) : flat_prior), _fIndivStepScale(prefit.size(), 1.0),
+        randParams(prefit.size(), 0.0), corr_throw(prefit.size(), 0.0), covMatrix(covariance), rng(seed ? seed : 0x5EEDull) {
+    if (int(covariance.size()) != _fNumPar * _fNumPar || int(low.size()) != _fNumPar || int(up.size()) != _fNumPar)
+      throw MaCh3Exception(__FILE__, __LINE__, "ParameterHandlerBase: inconsistent sizes");
+    InvertCovMatrix = Invert(covMatrix, _fNumPar);
+    SetThrowMatrix(covMatrix);
+    _fGlobalStepScale = 2.38 / std::sqrt(double(_fNumPar));  // the usual optimal scale for a Gaussian target
+  }
+  virtual ~ParameterHandlerBase() {}
+
+  std::string GetName() const { return matrixName; }
+  int GetNumParams() const { return _fNumPar; }
+  /// address of the PROPOSED value: what samples read at Reweight() (ref: ParameterHandlerBase.h:205)
+  const double* RetPointer(const int iParam) { return &_fPropVal[size_t(iParam)]; }
+  const std::vector<double>& GetParCurrVec() const { return _fCurrVal; }
+  const std::vector<double>& GetParPropVec() const { return _fPropVal; }
+  double GetParProp(int i) const { return _fPropVal[size_t(i)]; }
+  double GetParCurr(int i) const { return _fCurrVal[size_t(i)]; }
+  void SetParCurrProp(const int parNo, const double parVal) { _fPropVal[size_t(parNo)] = _fCurrVal[size_t(parNo)] = parVal; }
+  void SetStepScale(const double scale, bool = false) { _fGlobalStepScale = scale; }
+  double GetGlobalStepScale() const { return _fGlobalStepScale; }
+  void SetIndivStepScale(int i, double s) { _fIndivStepScale[size_t(i)] = s; }
+  bool GetDoAdaption() const { return use_adaptive; }
+
+  /// ref: ParameterHandlerBase.cpp:652-664, 690-707, 726-745
+  void ProposeStep() {
+    for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = gaus(rng);
+    for (int i = 0; i < _fNumPar; ++i) {  // corr_throw = L z, L lower triangular
+      double s = 0.0;
+      for (int j = 0; j <= i; ++j) s += throwMatrixCholDecomp[size_t(i) * _fNumPar + j] * randParams[size_t(j)];
+      corr_throw[size_t(i)] = s;
+    }
+    for (int i = 0; i < _fNumPar; ++i) _fPropVal[size_t(i)] = _fCurrVal[size_t(i)] + corr_throw[size_t(i)] * _fGlobalStepScale * _fIndivStepScale[size_t(i)];
+  }
+  void AcceptStep() { _fCurrVal = _fPropVal; }  // ref: :748-761
+
+  /// ref: :816-841 -- 0.5 * d^T V^-1 d over the parameters with a Gaussian prior
+  double CalcLikelihood() const {
+    double logL = 0.0;
+    for (int i = 0; i < _fNumPar; ++i) {
+      if (_fFlatPrior[size_t(i)]) continue;
+      const double Diff = _fPropVal[size_t(i)] - _fPreFitValue[size_t(i)];
+      for (int j = 0; j <= i; ++j) {
+        if (_fFlatPrior[size_t(j)]) continue;
+        const double scale = (i != j) ? 1. : 0.5;
+        logL += scale * Diff * (_fPropVal[size_t(j)] - _fPreFitValue[size_t(j)]) * InvertCovMatrix[size_t(i) * _fNumPar + j];
+      }
+    }
+    return logL;
+  }
+  int CheckBounds() const {  // ref: :844-856
+    int NOutside = 0;
+    for (int i = 0; i < _fNumPar; ++i)
+      if (_fPropVal[size_t(i)] > _fUpBound[size_t(i)] || _fPropVal[size_t(i)] < _fLowBound[size_t(i)]) NOutside++;
+    return NOutside;
+  }
+  double GetLikelihood() {  // ref: :859-867
+    const int NOutside = CheckBounds();
+    if (NOutside > 0) return NOutside * M3::_LARGE_LOGL_;
+    return CalcLikelihood();
+  }
+
+  /// Adaptive MCMC: between start_update and end_update every step feeds the running mean and
+  /// covariance of the chain; from start_throw on, every update_step steps the proposal's throw
+  /// matrix becomes that covariance (ref: AdaptiveMCMCHandler.cpp:398-432, ParameterHandlerBase.cpp:1306-1345)
+  void InitialiseAdaption(int start_update, int end_update, int start_throw, int update_step) {
+    use_adaptive = true;
+    start_adaptive_update = start_update;
+    end_adaptive_update = end_update;
+    start_adaptive_throw = start_throw;
+    adaptive_update_step = update_step;
+    total_steps = 0;
+    par_means.assign(size_t(_fNumPar), 0.0);
+    adaptive_covariance.assign(size_t(_fNumPar) * _fNumPar, 0.0);
+  }
+  void UpdateAdaptiveCovariance() {
+    if (total_steps > end_adaptive_update || total_steps < start_adaptive_update) {  // SkipAdaption
+      ++total_steps;
+      return;
+    }
+    // Haario update (ref: AdaptiveMCMCHandler.cpp:332-397), no blocks / skipped parameters
+    const std::vector<double> par_means_prev = par_means;
+    const int steps_post_burn = total_steps - start_adaptive_update;
+    for (int i = 0; i < _fNumPar; ++i) par_means[size_t(i)] = (_fCurrVal[size_t(i)] + par_means_prev[size_t(i)] * steps_post_burn) / (steps_post_burn + 1);
+    for (int i = 0; i < _fNumPar; ++i)
+      for (int j = 0; j <= i; ++j) {
+        const double cov_prev = adaptive_covariance[size_t(i) * _fNumPar + j];
+        double cov_updated = 0.0;
+        if (steps_post_burn > 0) {
+          const double cov_t = cov_prev * (steps_post_burn - 1) / steps_post_burn;
+          const double prev_means_t = steps_post_burn * par_means_prev[size_t(i)] * par_means_prev[size_t(j)];
+          const double curr_means_t = (steps_post_burn + 1) * par_means[size_t(i)] * par_means[size_t(j)];
+          const double curr_step_t = _fCurrVal[size_t(i)] * _fCurrVal[size_t(j)];
+          cov_updated = cov_t + (prev_means_t - curr_means_t + curr_step_t) / steps_post_burn;
+        }
+        adaptive_covariance[size_t(i) * _fNumPar + j] = adaptive_covariance[size_t(j) * _fNumPar + i] = cov_updated;
+      }
+    if (total_steps == start_adaptive_throw) std::fill(_fIndivStepScale.begin(), _fIndivStepScale.end(), 1.0);  // IndivStepScaleAdapt
+    if (total_steps >= start_adaptive_throw && (total_steps - start_adaptive_throw) % adaptive_update_step == 0) {  // UpdateMatrixAdapt
+      try {
+        SetThrowMatrix(adaptive_covariance);
+      } catch (const MaCh3Exception&) {
+        // not positive definite yet (too few distinct points): keep the previous throw matrix
+      }
+    }
+    ++total_steps;
+  }
+  const std::vector<double>& GetAdaptiveCovariance() const { return adaptive_covariance; }
+
+  /// throw matrix -> its lower Cholesky factor (ref: SetThrowMatrix / MakePosDef, ParameterHandlerBase.cpp:1140-1200)
+  void SetThrowMatrix(const std::vector<double>& cov) {
+    std::vector<double> L(size_t(_fNumPar) * _fNumPar, 0.0);
+    for (int i = 0; i < _fNumPar; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = cov[size_t(i) * _fNumPar + j];
+        for (int k = 0; k < j; ++k) s -= L[size_t(i) * _fNumPar + k] * L[size_t(j) * _fNumPar + k];
+        if (i == j) {
+          if (s <= 0.0) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
+          L[size_t(i) * _fNumPar + i] = std::sqrt(s);
+        } else {
+          L[size_t(i) * _fNumPar + j] = s / L[size_t(j) * _fNumPar + j];
+        }
+      }
+    throwMatrixCholDecomp = L;
+  }
+
+ private:
+  static std::vector<double> Invert(const std::vector<double>& a, int n) {  // Gauss-Jordan with partial pivoting
+    std::vector<double> m(a), inv(size_t(n) * n, 0.0);
+    for (int i = 0; i < n; ++i) inv[size_t(i) * n + i] = 1.0;
+    for (int c = 0; c < n; ++c) {
+      int p = c;
+      for (int r = c + 1; r < n; ++r)
+        if (std::fabs(m[size_t(r) * n + c]) > std::fabs(m[size_t(p) * n + c])) p = r;
+      if (std::fabs(m[size_t(p) * n + c]) < 1e-300) throw MaCh3Exception(__FILE__, __LINE__, "singular covariance matrix");
+      for (int k = 0; k < n; ++k) {
+        std::swap(m[size_t(c) * n + k], m[size_t(p) * n + k]);
+        std::swap(inv[size_t(c) * n + k], inv[size_t(p) * n + k]);
+      }
+      const double d = m[size_t(c) * n + c];
+      for (int k = 0; k < n; ++k) { m[size_t(c) * n + k] /= d; inv[size_t(c) * n + k] /= d; }
+      for (int r = 0; r < n; ++r) {
+        if (r == c) continue;
+        const double f = m[size_t(r) * n + c];
+        if (f == 0.0) continue;
+        for (int k = 0; k < n; ++k) { m[size_t(r) * n + k] -= f * m[size_t(c) * n + k]; inv[size_t(r) * n + k] -= f * inv[size_t(c) * n + k]; }
+      }
+    }
+    return inv;
+  }
+
+  std::string matrixName;
+  int _fNumPar;
+  std::vector<double> _fPreFitValue, _fCurrVal, _fPropVal, _fLowBound, _fUpBound;
+  std::vector<bool> _fFlatPrior;
+  std::vector<double> _fIndivStepScale;
+  double _fGlobalStepScale = 1.0;
+  std::vector<double> randParams, corr_throw, covMatrix, InvertCovMatrix, throwMatrixCholDecomp;
+  std::mt19937_64 rng;
+  std::normal_distribution<double> gaus{0.0, 1.0};
+  // adaption
+  bool use_adaptive = false;
+  int start_adaptive_update = 0, end_adaptive_update = 0, start_adaptive_throw = 0, adaptive_update_step = 1, total_steps = 0;
+  std::vector<double> par_means, adaptive_covariance;
+};
+
+/// ref: Fitters/FitterBase.h:36-61 + Fitters/MCMCBase.cpp:32-216 (chain bookkeeping kept in memory)
+class MCMCBase {
+ public:
+  explicit MCMCBase(uint64_t seed = 12345) : random(seed) {}
+  virtual ~MCMCBase() {}
+  void AddSampleHandler(SampleHandlerBase* sample) { samples.push_back(sample); }
+  void AddSystObj(ParameterHandlerBase* cov) { systematics.push_back(cov); }
+
+  /// ref: MCMCBase.cpp:32-77
+  void RunMCMC(int n_steps) {
+    syst_llh.assign(systematics.size(), 0.0);
+    sample_llh.assign(samples.size(), 0.0);
+    if (!started) {  // the chain starts from the current values: evaluate them once (FitterBase.cpp:348-410 restart logic is out of scope)
+      ProposeStepAtCurrent();
+      logLCurr = logLProp;
+      started = true;
+    }
+    for (int i = 0; i < n_steps; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      DoStep();
+      for (auto* s : systematics)
+        if (s->GetDoAdaption()) s->UpdateAdaptiveCovariance();  // MCMCBase::AdaptiveStep
+      ++step;
+      stepTime.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      LogLStore.push_back(logLCurr);
+      for (size_t k = 0; k < systematics.size(); ++k) StepStore.insert(StepStore.end(), systematics[k]->GetParCurrVec().begin(), systematics[k]->GetParCurrVec().end());
+    }
+  }
+  int GetAccCount() const { return accCount; }
+  int GetStepCount() const { return step; }
+  double GetLogLCurr() const { return logLCurr; }
+  int GetOutOfBoundsCount() const { return oobCount; }
+  const std::vector<double>& GetStepStore() const { return StepStore; }  ///< [step][all parameters of all handlers]
+  const std::vector<double>& GetLogLStore() const { return LogLStore; }
+  const std::vector<double>& GetStepTimes() const { return stepTime; }
+
+  /// ref: Fitters/FitterBase.cpp:461-520
+  void DragRace(int NLaps, double* reweight_s_per_lap, double* llh_s_per_lap) {
+    double tr = 0, tl = 0;
+    for (int lap = 0; lap < NLaps; ++lap) {
+      for (auto* s : systematics) s->ProposeStep();
+      const auto a = std::chrono::steady_clock::now();
+      for (auto* s : samples) s->Reweight();
+      const auto b = std::chrono::steady_clock::now();
+      for (auto* s : samples) (void)s->GetLikelihood();
+      const auto c = std::chrono::steady_clock::now();
+      tr += std::chrono::duration<double>(b - a).count();
+      tl += std::chrono::duration<double>(c - b).count();
+    }
+    *reweight_s_per_lap = tr / NLaps;
+    *llh_s_per_lap = tl / NLaps;
+    for (auto* s : systematics)  // back to the current point
+      for (int i = 0; i < s->GetNumParams(); ++i) s->SetParCurrProp(i, s->GetParCurr(i));
+  }
+
+ protected:
+  virtual void DoStep() = 0;
+  bool IsStepAccepted(const double acc_prob) { return !(unif(random) > acc_prob); }  // ref: MCMCBase.cpp:188-203
+  void AcceptStep() {                                                                  // ref: :206-216
+    ++accCount;
+    logLCurr = logLProp;
+    for (auto* s : systematics) s->AcceptStep();
+  }
+  /// everything MR2T2::ProposeStep does after the proposal itself (ref: MR2T2.cpp:33-98)
+  void EvaluateProposal() {
+    out_of_bounds = false;
+    double llh = 0.0;
+    for (size_t s = 0; s < systematics.size(); ++s) {
+      syst_llh[s] = systematics[s]->GetLikelihood();
+      llh += syst_llh[s];
+    }
+    if (llh >= M3::_LARGE_LOGL_) out_of_bounds = true;
+    if (!out_of_bounds) {
+      for (auto* s : samples) s->Reweight();
+      for (size_t i = 0; i < samples.size(); ++i) {
+        sample_llh[i] = samples[i]->GetLikelihood();
+        llh += sample_llh[i];
+      }
+    } else {
+      ++oobCount;
+      for (size_t i = 0; i < samples.size(); ++i) sample_llh[i] = M3::_LARGE_LOGL_;
+    }
+    logLProp = llh;
+  }
+  void ProposeStepAtCurrent() {
+    for (auto* s : systematics)
+      for (int i = 0; i < s->GetNumParams(); ++i) s->SetParCurrProp(i, s->GetParCurr(i));
+    EvaluateProposal();
+  }
+
+  std::vector<SampleHandlerBase*> samples;
+  std::vector<ParameterHandlerBase*> systematics;
+  std::vector<double> syst_llh, sample_llh;
+  double logLCurr = 0.0, logLProp = 0.0;
+  bool out_of_bounds = false, started = false;
+  int step = 0, accCount = 0, oobCount = 0;
+  std::mt19937_64 random;
+  std::uniform_real_distribution<double> unif{0.0, 1.0};
+  std::vector<double> StepStore, LogLStore, stepTime;
+};
+
+/// ref: Fitters/MR2T2.cpp:11-115
+class MR2T2 : public MCMCBase {
+ public:
+  using MCMCBase::MCMCBase;
+
+ protected:
+  void DoStep() override {  // :11-21
+    ProposeStep();
+    accProb = AcceptanceProbability();
+    if (IsStepAccepted(accProb) && !out_of_bounds) AcceptStep();
+  }
+  void ProposeStep() {  // :25-99
+    for (auto* s : systematics) s->ProposeStep();
+    EvaluateProposal();
+  }
+  double AcceptanceProbability() const { return std::min(1., std::exp(logLCurr - logLProp)); }  // :103-115 (no annealing)
+  double accProb = 0.0;
+};
+
+/// Delayed rejection: after a rejection, retry from the same point with a shrunken proposal
+/// (ref: Fitters/DelayedMR2T2.cpp:95-235; acceptance of the later tries per arXiv:2010.04190)
+class DelayedMR2T2 : public MR2T2 {
+ public:
+  /// delay_probability follows the reference literally: after a rejected try the loop STOPS when
+  /// Rndm() <= delay_probability (DelayedMR2T2.cpp:148-150, 167-171), so small values delay often and
+  /// 1 never delays; <= 0 switches delayed rejection off (DelayedMR2T2.cpp:24-29).
+  DelayedMR2T2(uint64_t seed, double initial_scale_, double decay_rate_, int max_rejections_, double delay_probability_,
+               bool delay_on_oob_only_ = false)
+      : MR2T2(seed), initial_scale(initial_scale_), decay_rate(decay_rate_), max_rejections(max_rejections_),
+        delay_probability(std::min(1.0, std::max(0.0, delay_probability_))), delay_on_oob_only(delay_on_oob_only_) {
+    if (delay_probability <= 0.0) max_rejections = 0;
+  }
+  int GetDelayedAcceptCount() const { return delayedAccCount; }
+
+ protected:
+  void DoStep() override {  // :95-165
+    std::vector<std::vector<double>> current_step_vals;
+    std::vector<double> start_step_scale;
+    for (auto* s : systematics) {  // StoreCurrentStep
+      current_step_vals.push_back(s->GetParCurrVec());
+      start_step_scale.push_back(s->GetGlobalStepScale());
+    }
+    for (auto* s : systematics) s->SetStepScale(initial_scale * s->GetGlobalStepScale());
+    bool accepted = false, delay = false;
+    MinLogLikelihood = M3::_LARGE_LOGL_;
+    for (int i = 0; i <= max_rejections; ++i) {
+      ProposeStep();
+      for (auto* s : systematics) s->AcceptStep();  // "leapfrog": the next try starts from this proposal
+      if (out_of_bounds || logLProp > MinLogLikelihood) continue;
+      if (i == 0) {
+        accProb = MR2T2::AcceptanceProbability();
+      } else {
+        accProb = DelayedAcceptanceProbability();
+        delay = true;
+      }
+      if (IsStepAccepted(accProb)) {
+        AcceptStep();
+        accepted = true;
+        if (delay) ++delayedAccCount;
+        break;
+      }
+      if (!out_of_bounds && delay_on_oob_only) break;
+      if (!(unif(random) > delay_probability)) break;  // `if (not ProbabilisticDelay()) break;`
+      for (auto* s : systematics) s->SetStepScale(decay_rate * s->GetGlobalStepScale());
+      MinLogLikelihood = logLProp;
+    }
+    if (!accepted)
+      for (size_t k = 0; k < systematics.size(); ++k)
+        for (int j = 0; j < systematics[k]->GetNumParams(); ++j) systematics[k]->SetParCurrProp(j, current_step_vals[k][size_t(j)]);
+    for (size_t k = 0; k < systematics.size(); ++k) systematics[k]->SetStepScale(start_step_scale[k]);
+  }
+  double DelayedAcceptanceProbability() const {  // :176-190
+    const double numerator = std::max(0.0, std::exp(MinLogLikelihood - logLProp) - 1.0);
+    const double denominator = std::exp(MinLogLikelihood - logLCurr) - 1.0;
+    if (denominator <= 0.0) return 1.0;
+    if (std::isinf(numerator) || std::isinf(denominator)) return MR2T2::AcceptanceProbability();
+    return std::min(numerator / denominator, 1.0);
+  }
+
+  double initial_scale, decay_rate;
+  int max_rejections;
+  double delay_probability;
+  bool delay_on_oob_only;
+  double MinLogLikelihood = M3::_LARGE_LOGL_;
+  int delayedAccCount = 0;
+};

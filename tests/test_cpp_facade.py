@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "build", "mr2t2_dragrace")
 
 def test_facade_headers_compile():
     """Syntax-check the facade headers on their own (no GPU, no link)."""
-    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h", "SplineBuilders.h"):
+    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h", "SplineBuilders.h", "Fitters.h"):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                             "-x", "c++", os.path.join(ROOT, "include", "mach3_amd", h)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
@@ -28,3 +28,4 @@ def test_cpp_driver_runs_a_chain():
     assert "agree with TSpline3_red::Eval" in out and "DragRace" in out and out.strip().endswith("OK")
     acc = float(out.split("acceptance ")[1].split(",")[0])
     assert 0.02 < acc < 0.98
+    assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out
