@@ -42,7 +42,8 @@ int main(int argc, char** argv) {
   cfg.bin_lo = 0.0;
   cfg.bin_hi = 5.0;
   cfg.nc_fraction = 0.1;
-  const int nPar = P + cfg.n_norm;
+  const int nPar = P + cfg.n_norm + 1;  // spline parameters, normalisations, one energy-scale functional parameter
+  const int iEScale = nPar - 1;
 
   try {
     // ---- reference-layout arrays from the generator, turned back into response-function objects
@@ -78,13 +79,15 @@ int main(int argc, char** argv) {
     std::vector<float>().swap(coeff_many);
 
     std::vector<double> nominal(nPar), sigma(nPar), lo(nPar), hi(nPar), cov(size_t(nPar) * nPar, 0.0);
-    m3synth_params(&cfg, 0, nominal.data());
+    m3synth_params(&cfg, 0, nominal.data());  // fills the first nPar - 1
     for (int i = 0; i < nPar; ++i) {
       sigma[i] = i < P ? 1.0 : 0.1;
       lo[i] = i < P ? -5.0 : 0.0;
       hi[i] = i < P ? 5.0 : 2.0;
       cov[size_t(i) * nPar + i] = sigma[i] * sigma[i];
     }
+    nominal[iEScale] = 0.0; sigma[iEScale] = 0.02; lo[iEScale] = -0.2; hi[iEScale] = 0.2;
+    cov[size_t(iEScale) * nPar + iEScale] = sigma[iEScale] * sigma[iEScale];
     // the parameter handler owns the proposed values; splines and the sample read them through pointers
     ParameterHandlerBase ph("synthetic_systematics", nominal, cov, lo, hi, {}, 4242);
     auto setpar = [&](int i, double v) { ph.SetParCurrProp(i, v); };
@@ -181,6 +184,18 @@ int main(int argc, char** argv) {
     el = now_s() - t0c;
     std::printf("DelayedMR2T2: %d steps, %.0f steps/s, acceptance %.3f (%d accepted at a delayed stage)\n", NSteps / 2, (NSteps / 2) / el,
                 double(delayed.GetAccCount()) / delayed.GetStepCount(), delayed.GetDelayedAcceptCount());
+
+    // ---- functional parameter: E_rec *= 1 + theta, events re-binned on the device every step
+    sample.EnableDeviceBinning();  // also checks device FindGlobalBin == host FindGlobalBin for every event
+    sample.RegisterFunctionalParameter(-1, 0, 1, iEScale);
+    MR2T2 fitter_fp(777);  // a fresh chain from the current point
+    fitter_fp.AddSampleHandler(&sample);
+    fitter_fp.AddSystObj(&ph);
+    t0c = now_s();
+    fitter_fp.RunMCMC(NSteps / 2);
+    const double el_fp = now_s() - t0c;
+    std::printf("MCMC + energy-scale functional parameter (device re-binning): %d steps, %.0f steps/s, acceptance %.3f\n", NSteps / 2,
+                (NSteps / 2) / el_fp, double(fitter_fp.GetAccCount()) / fitter_fp.GetStepCount());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAILED: %s\n", e.what());
     return 1;

@@ -187,9 +187,23 @@ int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size);
  *                            arbitrary std::function callbacks per event (SampleHandlerFD.cpp:545-564);
  *                            the device supports this closed set.  With shifts registered, every
  *                            m3hip_reweight re-bins all events (nominal bin, +-1 neighbour, binary search).
+ *   m3hip_binning_begin / _add_uniform / _add_nonuniform / _end
+ *                            the same, sample by sample (BinningHandler::SetupSampleBinning,
+ *                            Samples/BinningHandler.cpp:15-60), and the only way to declare a NON-UNIFORM
+ *                            sample: n_boxes bins given as extents[n_boxes][n_dim][2] = {lo, hi} per axis
+ *                            (SampleBinningInfo::InitNonUniform, Samples/SampleStructs.h:465-530; 2..4
+ *                            dimensions as there).  The library builds the reference's 10-per-axis
+ *                            mega-bin grid and its BinGridMapping (SampleStructs.h:397-462); an event lands
+ *                            in the first candidate box with lo < x <= hi on every axis
+ *                            (BinInfo::IsEventInside, SampleStructs.h:186-220), global bin = box number +
+ *                            the sample's offset.  Samples get their global offsets in the order added.
  */
 int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges,
                             const double* edges);
+int m3hip_binning_begin(m3hip_handle h);
+int m3hip_binning_add_uniform(m3hip_handle h, int n_dim, const int32_t* n_edges, const double* edges);
+int m3hip_binning_add_nonuniform(m3hip_handle h, int n_boxes, int n_dim, const double* extents);
+int m3hip_binning_end(m3hip_handle h);
 int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id,
                             const double* kin, int kin_stride);
 int m3hip_compute_bins(m3hip_handle h);

@@ -5,9 +5,11 @@
 //                      FindNominalBin, Samples/BinningHandler.cpp:257-355, SampleStructs.h:577-613)
 //   SampleHandlerFD    Samples/SampleHandlerFD.h:21-413 -- only the per-step surface: Reweight,
 //                      GetLikelihood, GetSampleLikelihood, GetMCArray / GetW2Array / GetDataArray,
-//                      AddData, SetTestStatistic.  Configuration (YAML), ROOT I/O, plotting
-//                      projections and functional-parameter callbacks are out of scope; events
-//                      are registered through AddEvent*/FinaliseEvents instead of SetupExperimentMC.
+//                      AddData, SetTestStatistic.  Configuration (YAML), ROOT I/O and plotting
+//                      projections are out of scope; events are registered through
+//                      AddEvent/FinaliseEvents instead of SetupExperimentMC.  Functional parameters
+//                      (SampleHandlerFD.cpp:545-564) and selection cuts (:281-294) are available
+//                      from a closed set once EnableDeviceBinning() moved FindGlobalBin to the device.
 //
 // Reweight() runs spline evaluation, weight product, bin fill and (on GetLikelihood) the bin
 // likelihood on the device; per step only the proposed parameter values cross PCIe.
@@ -150,6 +152,28 @@ class BinningHandler {
     }
     return M3::UnderOverFlowBin;
   }
+  /// hand the binning to the device (m3hip_binning_*): defines the global bin space there and lets
+  /// the device run FindGlobalBin itself once kinematics are uploaded
+  void UploadTo(m3hip_handle h) const {
+    M3HIP_CALL(h, m3hip_binning_begin(h));
+    for (const Sample& s : Samples) {
+      if (s.Uniform) {
+        std::vector<int32_t> ne;
+        std::vector<double> flat;
+        for (const auto& e : s.Edges) {
+          ne.push_back(int32_t(e.size()));
+          flat.insert(flat.end(), e.begin(), e.end());
+        }
+        M3HIP_CALL(h, m3hip_binning_add_uniform(h, int(s.Edges.size()), ne.data(), flat.data()));
+      } else {
+        std::vector<double> ext;
+        for (const auto& b : s.Boxes)
+          for (const auto& lohi : b) { ext.push_back(lohi[0]); ext.push_back(lohi[1]); }
+        M3HIP_CALL(h, m3hip_binning_add_nonuniform(h, int(s.Boxes.size()), int(s.Boxes[0].size()), ext.data()));
+      }
+    }
+    M3HIP_CALL(h, m3hip_binning_end(h));
+  }
   std::vector<int32_t> SampleBinOffsets() const {
     std::vector<int32_t> off;
     for (const auto& s : Samples) off.push_back(s.GlobalOffset);
@@ -181,8 +205,7 @@ class SampleHandlerFD : public SampleHandlerBase {
     h = SplineHandler->Handle();
     nSamples = M3::int_t(Binning->GetNSamples());
     nEvents = SplineHandler->GetNEvents();
-    const std::vector<int32_t> off = Binning->SampleBinOffsets();
-    M3HIP_CALL(h, m3hip_set_binning(h, nSamples, off.data()));
+    Binning->UploadTo(h);
     M3HIP_CALL(h, m3hip_set_test_statistic(h, int(fTestStatistic), UpdateW2 ? 1 : 0));
     bin_idx.assign(nEvents, M3::UnderOverFlowBin);
     osc_idx.assign(nEvents, -1);
@@ -205,6 +228,9 @@ class SampleHandlerFD : public SampleHandlerBase {
       nom.push_back(Binning->FindNominalBin(Sample, int(d), KinVars[d]));
     }
     bin_idx[iEvent] = Binning->FindGlobalBin(Sample, kv, nom);
+    if (KinVars.size() > size_t(kKinStride)) throw MaCh3Exception(__FILE__, __LINE__, "at most 4 kinematic columns per event");
+    sample_id.push_back(Sample);
+    for (int d = 0; d < kKinStride; ++d) kin.push_back(size_t(d) < KinVars.size() ? KinVars[size_t(d)] : 0.0);
     osc_idx[iEvent] = OscIndex;
     norm_idx.insert(norm_idx.end(), NormParams.begin(), NormParams.end());
     norm_off[iEvent + 1] = norm_idx.size();
@@ -213,6 +239,38 @@ class SampleHandlerFD : public SampleHandlerBase {
   void FinaliseEvents() {
     if (n_added != nEvents) throw MaCh3Exception(__FILE__, __LINE__, "not every event was added");
     M3HIP_CALL(h, m3hip_upload_events(h, 0, nEvents, bin_idx.data(), osc_idx.data(), norm_off.data(), norm_idx.data()));
+  }
+  /// Move FindGlobalBin to the device: uploads the nominal kinematics, lets the device compute nominal and
+  /// global bins, and checks them against the host's (integers: must agree exactly).  Needed before
+  /// RegisterFunctionalParameter / AddSelection; KinVars beyond the sample's binning axes are cut variables.
+  void EnableDeviceBinning() {
+    if (n_added != nEvents || sample_id.size() != nEvents) throw MaCh3Exception(__FILE__, __LINE__, "EnableDeviceBinning: call after FinaliseEvents, before CleanMemoryBeforeFit");
+    M3HIP_CALL(h, m3hip_upload_kinematics(h, 0, nEvents, sample_id.data(), kin.data(), kKinStride));
+    M3HIP_CALL(h, m3hip_compute_bins(h));
+    std::vector<int32_t> dev(nEvents);
+    M3HIP_CALL(h, m3hip_get_event_bins(h, dev.data(), 0, nEvents));
+    for (unsigned int i = 0; i < nEvents; ++i)
+      if (dev[i] != bin_idx[i]) throw MaCh3Exception(__FILE__, __LINE__, "device and host FindGlobalBin disagree for event " + std::to_string(i));
+    device_binning = true;
+  }
+  /// Functional parameter from the closed set the device supports (the reference registers arbitrary
+  /// std::function callbacks, SampleHandlerFD.cpp:545-564): Kind 1: x *= 1 + theta, Kind 2: x += theta, where x
+  /// is kinematic column `Column` and theta = ParameterValues[ParameterIndex].  Sample -1 = every sample.
+  /// With one registered, every Reweight() re-bins all events.
+  void RegisterFunctionalParameter(int Sample, int Column, int Kind, int ParameterIndex) {
+    if (!device_binning) throw MaCh3Exception(__FILE__, __LINE__, "RegisterFunctionalParameter needs EnableDeviceBinning()");
+    M3HIP_CALL(h, m3hip_add_kin_shift(h, Sample, Column, Kind, ParameterIndex));
+  }
+  /// Selection lo <= x < hi on kinematic column `Column`, evaluated on the shifted values
+  /// (SampleHandlerFD::IsEventSelected, SampleHandlerFD.cpp:281-294)
+  void AddSelection(int Sample, int Column, double Lo, double Hi) {
+    if (!device_binning) throw MaCh3Exception(__FILE__, __LINE__, "AddSelection needs EnableDeviceBinning()");
+    M3HIP_CALL(h, m3hip_add_kin_cut(h, Sample, Column, Lo, Hi));
+  }
+  std::vector<int32_t> GetEventBins() const {
+    std::vector<int32_t> dev(nEvents);
+    M3HIP_CALL(h, m3hip_get_event_bins(h, dev.data(), 0, nEvents));
+    return dev;
   }
   /// weights OscillationHandler::Evaluate would have left behind the event pointers
   void SetOscillationWeights(const std::vector<float>& w) { M3HIP_CALL(h, m3hip_set_osc_table(h, w.data(), w.size())); }
@@ -250,6 +308,8 @@ class SampleHandlerFD : public SampleHandlerBase {
     std::vector<int32_t>().swap(osc_idx);
     std::vector<uint64_t>().swap(norm_off);
     std::vector<int16_t>().swap(norm_idx);
+    std::vector<int32_t>().swap(sample_id);
+    std::vector<double>().swap(kin);
   }
   void PrintRates(const bool DataOnly = false) override {
     const std::vector<double> mc = Bins(true);
@@ -287,7 +347,10 @@ class SampleHandlerFD : public SampleHandlerBase {
   int nPar;
   bool UpdateW2;
   m3hip_handle h = nullptr;
-  std::vector<int32_t> bin_idx, osc_idx;
+  static constexpr int kKinStride = 4;
+  std::vector<int32_t> bin_idx, osc_idx, sample_id;
+  std::vector<double> kin;  // [event][kKinStride]
+  bool device_binning = false;
   std::vector<uint64_t> norm_off;
   std::vector<int16_t> norm_idx;
   std::vector<double> data;

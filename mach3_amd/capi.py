@@ -21,6 +21,7 @@ M3HIP_SYMBOLS = [
     "m3hip_binned_upload", "m3hip_binned_upload_events", "m3hip_get_binned_weights",
     "m3hip_set_binning_edges", "m3hip_upload_kinematics", "m3hip_compute_bins", "m3hip_add_kin_shift",
     "m3hip_clear_kin_shifts", "m3hip_add_kin_cut", "m3hip_get_event_bins",
+    "m3hip_binning_begin", "m3hip_binning_add_uniform", "m3hip_binning_add_nonuniform", "m3hip_binning_end",
     "m3hip_reweight", "m3hip_get_likelihood", "m3hip_step",
     "m3hip_get_bins", "m3hip_get_spline_weights", "m3hip_record_event_weights", "m3hip_get_event_weights",
     "m3hip_get_segments",
@@ -107,6 +108,10 @@ def load_m3hip():
         "m3hip_upload_events": [vp, u64, u64, vp, vp, vp, vp],
         "m3hip_set_osc_table": [vp, vp, u64],
         "m3hip_set_binning_edges": [vp, i32, vp, vp, vp],
+        "m3hip_binning_begin": [vp],
+        "m3hip_binning_add_uniform": [vp, i32, vp, vp],
+        "m3hip_binning_add_nonuniform": [vp, i32, i32, vp],
+        "m3hip_binning_end": [vp],
         "m3hip_binned_upload": [vp, u64, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp],
         "m3hip_binned_upload_events": [vp, u64, u64, vp, vp],
         "m3hip_get_binned_weights": [vp, vp, i32],

@@ -3,9 +3,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <vector>
@@ -133,7 +135,16 @@ struct m3hip_ctx {
   BinSample* d_bin_samples = nullptr;
   BinAxis* d_bin_axes = nullptr;
   double* d_edges = nullptr;
+  int32_t* d_grid_off = nullptr;
+  int32_t* d_grid_list = nullptr;
+  double* d_boxes = nullptr;
   std::vector<int> h_sample_ndim;
+  // m3hip_binning_begin .. _end builder state
+  bool binning_open = false;
+  std::vector<BinSample> bb_samples;
+  std::vector<BinAxis> bb_axes;
+  std::vector<double> bb_edges, bb_boxes;
+  std::vector<int32_t> bb_grid_off, bb_grid_list, bb_nbins;
   int32_t* d_sample_id = nullptr;
   double* d_kin = nullptr;
   int32_t* d_nom_bin = nullptr;
@@ -302,6 +313,9 @@ BinArgs make_bin_args(m3hip_handle h) {
   b.samples = h->d_bin_samples;
   b.axes = h->d_bin_axes;
   b.edges = h->d_edges;
+  b.grid_off = h->d_grid_off;
+  b.grid_list = h->d_grid_list;
+  b.boxes = h->d_boxes;
   b.sample_id = h->d_sample_id;
   b.kin = h->d_kin;
   b.nom_bin = h->d_nom_bin;
@@ -387,6 +401,9 @@ int m3hip_destroy(m3hip_handle h) {
   dev_free(h->d_bin_samples);
   dev_free(h->d_bin_axes);
   dev_free(h->d_edges);
+  dev_free(h->d_grid_off);
+  dev_free(h->d_grid_list);
+  dev_free(h->d_boxes);
   dev_free(h->d_shifts);
   dev_free(h->d_cuts);
   dev_free(h->d_sample_off);
@@ -852,49 +869,164 @@ int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) {
   return M3HIP_OK;
 }
 
-int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) {
+int m3hip_binning_begin(m3hip_handle h) {
   if (!h) return M3HIP_EINVAL;
-  if (n_samples <= 0 || !n_dim || !n_edges || !edges) return fail(h, M3HIP_EINVAL, "set_binning_edges: NULL / empty arguments");
-  std::vector<BinSample> bs(n_samples);
-  std::vector<BinAxis> ax;
-  std::vector<int32_t> off(size_t(n_samples) + 1, 0);
-  int e_off = 0, k = 0;
-  for (int s = 0; s < n_samples; ++s) {
-    if (n_dim[s] < 1 || n_dim[s] > M3_MAX_DIM) return fail(h, M3HIP_EINVAL, "set_binning_edges: 1..4 dimensions per sample");
-    bs[s].n_dim = n_dim[s];
-    bs[s].axis_off = int32_t(ax.size());
-    bs[s].global_offset = off[s];
-    bs[s].pad_ = 0;
-    int stride = 1;
-    for (int d = 0; d < n_dim[s]; ++d, ++k) {
-      const int ne = n_edges[k];
-      if (ne < 2) return fail(h, M3HIP_EINVAL, "set_binning_edges: an axis needs at least two edges");
-      for (int i = 1; i < ne; ++i)
-        if (edges[e_off + i] < edges[e_off + i - 1]) return fail(h, M3HIP_EINVAL, "set_binning_edges: bin edges must be increasing");  // SampleStructs.h:259-263
-      BinAxis a;
-      a.edge_off = e_off;
-      a.n_bins = ne - 1;
-      a.stride = stride;  // SampleStructs.h:648-659
-      a.pad_ = 0;
-      ax.push_back(a);
-      stride *= ne - 1;
-      e_off += ne;
+  h->bb_samples.clear(); h->bb_axes.clear(); h->bb_edges.clear(); h->bb_boxes.clear();
+  h->bb_grid_off.clear(); h->bb_grid_list.clear(); h->bb_nbins.clear();
+  h->binning_open = true;
+  return M3HIP_OK;
+}
+
+// one axis of a sample: edges appended to the shared table, stride = product of the earlier axes' bins
+// (SampleBinningInfo::InitialiseStrides, SampleStructs.h:648-659)
+static void push_axis(m3hip_handle h, const double* e, int ne, int& stride) {
+  BinAxis a;
+  a.edge_off = int32_t(h->bb_edges.size());
+  a.n_bins = ne - 1;
+  a.stride = stride;
+  a.pad_ = 0;
+  h->bb_axes.push_back(a);
+  h->bb_edges.insert(h->bb_edges.end(), e, e + ne);
+  stride *= ne - 1;
+}
+
+int m3hip_binning_add_uniform(m3hip_handle h, int n_dim, const int32_t* n_edges, const double* edges) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_add_uniform outside binning_begin/end");
+  if (!n_edges || !edges) return fail(h, M3HIP_EINVAL, "binning_add_uniform: NULL arguments");
+  if (n_dim < 1 || n_dim > M3_MAX_DIM) return fail(h, M3HIP_EINVAL, "binning_add_uniform: 1..4 dimensions per sample");
+  int e_off = 0;
+  for (int d = 0; d < n_dim; ++d) {
+    const int ne = n_edges[d];
+    if (ne < 2) return fail(h, M3HIP_EINVAL, "binning_add_uniform: an axis needs at least two edges");
+    for (int i = 1; i < ne; ++i)
+      if (edges[e_off + i] < edges[e_off + i - 1]) return fail(h, M3HIP_EINVAL, "binning_add_uniform: bin edges must be increasing");  // SampleStructs.h:259-263
+    e_off += ne;
+  }
+  BinSample bs;
+  bs.n_dim = n_dim;
+  bs.axis_off = int32_t(h->bb_axes.size());
+  bs.global_offset = 0;
+  bs.uniform = 1;
+  bs.map_off = bs.box_off = 0;
+  int stride = 1;
+  e_off = 0;
+  for (int d = 0; d < n_dim; ++d) {
+    push_axis(h, edges + e_off, n_edges[d], stride);
+    e_off += n_edges[d];
+  }
+  h->bb_samples.push_back(bs);
+  h->bb_nbins.push_back(stride);
+  return M3HIP_OK;
+}
+
+int m3hip_binning_add_nonuniform(m3hip_handle h, int n_boxes, int n_dim, const double* extents) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_add_nonuniform outside binning_begin/end");
+  if (!extents) return fail(h, M3HIP_EINVAL, "binning_add_nonuniform: NULL arguments");
+  if (n_dim <= 1 || n_dim > M3_MAX_DIM || n_boxes <= 0)  // SampleStructs.h:471-474: 1-D non-uniform binning is refused
+    return fail(h, M3HIP_EINVAL, "binning_add_nonuniform: needs 2..4 dimensions and at least one bin");
+  for (int64_t i = 0; i < int64_t(n_boxes) * n_dim; ++i)
+    if (!(extents[2 * i] < extents[2 * i + 1])) return fail(h, M3HIP_EINVAL, "binning_add_nonuniform: a bin extent needs lo < hi");
+  BinSample bs;
+  bs.n_dim = n_dim;
+  bs.axis_off = int32_t(h->bb_axes.size());
+  bs.global_offset = 0;
+  bs.uniform = 0;
+  bs.map_off = int32_t(h->bb_grid_off.size());
+  bs.box_off = int32_t(h->bb_boxes.size() / (2 * size_t(n_dim)));
+  if (h->bb_boxes.size() % (2 * size_t(n_dim)) != 0) {  // keep box_off exact when samples of different dimension mix
+    h->bb_boxes.resize((h->bb_boxes.size() / (2 * size_t(n_dim)) + 1) * 2 * size_t(n_dim), 0.0);
+    bs.box_off = int32_t(h->bb_boxes.size() / (2 * size_t(n_dim)));
+  }
+  // the mega-bin grid: 10 equal bins per axis over the boxes' bounding range (SampleStructs.h:499-517)
+  constexpr int BinsPerDimension = 10;
+  int stride = 1;
+  std::vector<std::vector<double>> grid(static_cast<size_t>(n_dim), std::vector<double>(BinsPerDimension + 1));
+  for (int d = 0; d < n_dim; ++d) {
+    double MinVal = std::numeric_limits<double>::max(), MaxVal = std::numeric_limits<double>::lowest();
+    for (int b = 0; b < n_boxes; ++b) {
+      MinVal = std::min(MinVal, extents[(size_t(b) * n_dim + d) * 2]);
+      MaxVal = std::max(MaxVal, extents[(size_t(b) * n_dim + d) * 2 + 1]);
     }
-    off[s + 1] = off[s] + stride;
+    const double BinWidth = (MaxVal - MinVal) / double(BinsPerDimension);
+    for (int i = 0; i <= BinsPerDimension; ++i) grid[size_t(d)][size_t(i)] = MinVal + double(i) * BinWidth;
+    push_axis(h, grid[size_t(d)].data(), BinsPerDimension + 1, stride);
+  }
+  // BinGridMapping (SampleStructs.h:397-462): boxes overlapping each mega-bin, in box order
+  const int n_cells = stride;
+  std::vector<int> mi(static_cast<size_t>(n_dim));
+  for (int cell = 0; cell < n_cells; ++cell) {
+    int rem = cell;
+    for (int d = 0; d < n_dim; ++d) { mi[size_t(d)] = rem % BinsPerDimension; rem /= BinsPerDimension; }  // first axis fastest
+    h->bb_grid_off.push_back(int32_t(h->bb_grid_list.size()));
+    for (int b = 0; b < n_boxes; ++b) {
+      bool overlap = true;
+      for (int d = 0; d < n_dim && overlap; ++d) {
+        const double a_lo = extents[(size_t(b) * n_dim + d) * 2], a_hi = extents[(size_t(b) * n_dim + d) * 2 + 1];
+        const double b_lo = grid[size_t(d)][size_t(mi[size_t(d)])], b_hi = grid[size_t(d)][size_t(mi[size_t(d)]) + 1];
+        if (!(a_hi > b_lo && a_lo < b_hi)) overlap = false;
+      }
+      if (overlap) h->bb_grid_list.push_back(b);
+    }
+  }
+  h->bb_grid_off.push_back(int32_t(h->bb_grid_list.size()));
+  h->bb_boxes.insert(h->bb_boxes.end(), extents, extents + size_t(n_boxes) * n_dim * 2);
+  h->bb_samples.push_back(bs);
+  h->bb_nbins.push_back(n_boxes);
+  return M3HIP_OK;
+}
+
+int m3hip_binning_end(m3hip_handle h) {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_end without binning_begin");
+  const int n_samples = int(h->bb_samples.size());
+  if (n_samples == 0) return fail(h, M3HIP_EINVAL, "binning_end: no samples added");
+  h->binning_open = false;
+  std::vector<int32_t> off(size_t(n_samples) + 1, 0);  // BinningHandler::SetGlobalBinNumbers (BinningHandler.cpp:341-355)
+  for (int s = 0; s < n_samples; ++s) {
+    h->bb_samples[size_t(s)].global_offset = off[size_t(s)];
+    off[size_t(s) + 1] = off[size_t(s)] + h->bb_nbins[size_t(s)];
   }
   int rc = m3hip_set_binning(h, n_samples, off.data());
   if (rc) return rc;
   dev_free(h->d_bin_samples); dev_free(h->d_bin_axes); dev_free(h->d_edges);
+  dev_free(h->d_grid_off); dev_free(h->d_grid_list); dev_free(h->d_boxes);
   h->d_bin_samples = nullptr; h->d_bin_axes = nullptr; h->d_edges = nullptr;
-  if ((rc = dev_alloc(h, &h->d_bin_samples, bs.size()))) return rc;
-  if ((rc = dev_alloc(h, &h->d_bin_axes, ax.size()))) return rc;
-  if ((rc = dev_alloc(h, &h->d_edges, size_t(e_off)))) return rc;
-  HIPCHK(h, hipMemcpy(h->d_bin_samples, bs.data(), sizeof(BinSample) * bs.size(), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_bin_axes, ax.data(), sizeof(BinAxis) * ax.size(), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_edges, edges, sizeof(double) * size_t(e_off), hipMemcpyHostToDevice));
-  h->h_sample_ndim.assign(n_dim, n_dim + n_samples);
+  h->d_grid_off = nullptr; h->d_grid_list = nullptr; h->d_boxes = nullptr;
+  auto up = [&](auto** dptr, const auto& v) -> int {
+    if (v.empty()) return M3HIP_OK;
+    int r = dev_alloc(h, dptr, v.size());
+    if (r) return r;
+    if (hipMemcpy(*dptr, v.data(), sizeof(v[0]) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(h, M3HIP_EHIP, "binning_end: upload failed");
+    return M3HIP_OK;
+  };
+  if ((rc = up(&h->d_bin_samples, h->bb_samples))) return rc;
+  if ((rc = up(&h->d_bin_axes, h->bb_axes))) return rc;
+  if ((rc = up(&h->d_edges, h->bb_edges))) return rc;
+  if ((rc = up(&h->d_grid_off, h->bb_grid_off))) return rc;
+  if ((rc = up(&h->d_grid_list, h->bb_grid_list))) return rc;
+  if ((rc = up(&h->d_boxes, h->bb_boxes))) return rc;
+  h->h_sample_ndim.clear();
+  for (const BinSample& s : h->bb_samples) h->h_sample_ndim.push_back(s.n_dim);
   h->bins_computed = false;
   return M3HIP_OK;
+}
+
+int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) {
+  if (!h) return M3HIP_EINVAL;
+  if (n_samples <= 0 || !n_dim || !n_edges || !edges) return fail(h, M3HIP_EINVAL, "set_binning_edges: NULL / empty arguments");
+  int rc = m3hip_binning_begin(h);
+  int k = 0;
+  size_t e_off = 0;
+  for (int s = 0; s < n_samples && !rc; ++s) {
+    if (n_dim[s] < 1 || n_dim[s] > M3_MAX_DIM) { rc = fail(h, M3HIP_EINVAL, "set_binning_edges: 1..4 dimensions per sample"); break; }
+    rc = m3hip_binning_add_uniform(h, n_dim[s], n_edges + k, edges + e_off);
+    for (int d = 0; d < n_dim[s]; ++d) e_off += size_t(std::max(n_edges[k + d], 0));
+    k += n_dim[s];
+  }
+  if (rc) { h->binning_open = false; return rc; }
+  return m3hip_binning_end(h);
 }
 
 int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id, const double* kin, int kin_stride) {

@@ -119,9 +119,11 @@ struct BinAxis {       // one axis of one sample
 };
 struct BinSample {
   int32_t n_dim;
-  int32_t axis_off;       // first BinAxis of the sample
+  int32_t axis_off;       // first BinAxis of the sample (non-uniform: the axes of the mega-bin grid)
   int32_t global_offset;  // SampleBinningInfo::GlobalOffset
-  int32_t pad_;
+  int32_t uniform;        // SampleBinningInfo::Uniform
+  int32_t map_off;        // non-uniform: first entry of this sample's BinGridMapping offsets (CSR, n_cells + 1)
+  int32_t box_off;        // non-uniform: first box of this sample in `boxes` ([box][dim][2] doubles)
 };
 struct KinShift {      // closed set of functional-parameter shifts (stand-ins for the reference's
   int32_t sample;      // std::function callbacks, SampleHandlerFD.cpp:545-564); -1 = every sample
@@ -138,6 +140,9 @@ struct BinArgs {
   const BinSample* samples;
   const BinAxis* axes;
   const double* edges;
+  const int32_t* grid_off;   // BinGridMapping as CSR: candidates of mega-bin c = grid_list[grid_off[c] .. grid_off[c+1])
+  const int32_t* grid_list;  // box numbers, ascending within a cell (the reference's scan order)
+  const double* boxes;       // BinInfo::Extent, [box][dim][2]
   const int32_t* sample_id;  // [E_pad]
   const double* kin;         // [E_pad][kin_stride] nominal kinematic variables
   int32_t* nom_bin;          // [E_pad][kin_stride] nominal bin per axis (FindNominalBin)

@@ -587,6 +587,22 @@ __global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
     if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
     global += b * ax.stride;
   }
+  if (!sm.uniform && !out) {
+    // BinningHandler.cpp:277-290: `global` is the mega-bin; scan its candidate boxes in order, first
+    // box with lo < x <= hi on every axis (BinInfo::IsEventInside, SampleStructs.h:186-220) wins
+    const int32_t* go = a.grid_off + sm.map_off + global;
+    const int c0 = go[0], c1 = go[1];
+    int found = -1;
+    for (int c = c0; c < c1 && found < 0; ++c) {
+      const int box = a.grid_list[c];
+      const double* ext = a.boxes + ((size_t)sm.box_off + box) * sm.n_dim * 2;
+      bool inside = true;
+      for (int d = 0; d < sm.n_dim; ++d) inside &= (x[d] > ext[2 * d]) & (x[d] <= ext[2 * d + 1]);
+      if (inside) found = box;
+    }
+    global = found;
+    if (found < 0) out = true;
+  }
   a.bin[ev] = out ? -1 : global + sm.global_offset;
 }
 

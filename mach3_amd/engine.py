@@ -233,18 +233,27 @@ class SampleHandlerFD:
     def __init__(self, engine: Engine, n_samples: int, sample_bin_offset, par_vector: np.ndarray,
                  test_statistic=capi.kPoisson, update_w2=False, bin_edges=None):
         """bin_edges = [[edges_dim0, edges_dim1, ...] per sample] switches to device-side binning
-        (SetupKinematics / ComputeBins / AddKinShift); otherwise global bins come precomputed
-        through SetupEvents and `sample_bin_offset` defines the global bin space."""
+        (SetupKinematics / ComputeBins / AddKinShift); a sample given as an ndarray
+        [n_boxes][n_dim][2] is NON-UNIFORM (one {lo, hi} extent per axis and bin).  Otherwise
+        global bins come precomputed through SetupEvents and `sample_bin_offset` defines the
+        global bin space."""
         self.eng = engine
         self.nSamples = int(n_samples)
         if bin_edges is not None:
             assert len(bin_edges) == n_samples
-            n_dim = np.array([len(s) for s in bin_edges], np.int32)
-            n_edges = np.array([len(e) for s in bin_edges for e in s], np.int32)
-            edges = np.ascontiguousarray(np.concatenate([np.asarray(e, np.float64) for s in bin_edges for e in s]))
-            engine._chk(engine.lib.m3hip_set_binning_edges(engine.h, n_samples, _ptr(n_dim, np.int32), _ptr(n_edges, np.int32),
-                                                           _ptr(edges, np.float64)))
-            nb = [int(np.prod([len(e) - 1 for e in s])) for s in bin_edges]
+            engine._chk(engine.lib.m3hip_binning_begin(engine.h))
+            nb = []
+            for s in bin_edges:
+                if isinstance(s, np.ndarray) and s.ndim == 3:
+                    ext = np.ascontiguousarray(s, np.float64)
+                    engine._chk(engine.lib.m3hip_binning_add_nonuniform(engine.h, ext.shape[0], ext.shape[1], _ptr(ext, np.float64)))
+                    nb.append(ext.shape[0])
+                else:
+                    n_edges = np.array([len(e) for e in s], np.int32)
+                    edges = np.ascontiguousarray(np.concatenate([np.asarray(e, np.float64) for e in s]))
+                    engine._chk(engine.lib.m3hip_binning_add_uniform(engine.h, len(s), _ptr(n_edges, np.int32), _ptr(edges, np.float64)))
+                    nb.append(int(np.prod([len(e) - 1 for e in s])))
+            engine._chk(engine.lib.m3hip_binning_end(engine.h))
             off = np.concatenate([[0], np.cumsum(nb)]).astype(np.int32)
         else:
             off = np.ascontiguousarray(sample_bin_offset, np.int32)

@@ -475,6 +475,88 @@ def test_device_side_binning_bit_exact(fresh_engine):
     omono.close()
 
 
+def _random_boxes(rng, nx, ny, x0, x1, y0, y1, drop=0):
+    """irregular rectilinear tiling of [x0,x1] x [y0,y1] with some cells merged away (gaps)"""
+    xs = np.sort(np.concatenate([[x0, x1], rng.uniform(x0, x1, nx - 1)]))
+    boxes = []
+    for i in range(nx):
+        ys = np.sort(np.concatenate([[y0, y1], rng.uniform(y0, y1, ny - 1)]))   # different y cuts per column
+        for j in range(ny):
+            boxes.append([[xs[i], xs[i + 1]], [ys[j], ys[j + 1]]])
+    boxes = np.array(boxes, np.float64)
+    keep = np.ones(len(boxes), bool)
+    keep[rng.choice(len(boxes), drop, replace=False)] = False
+    return boxes[keep], xs
+
+
+def test_device_side_nonuniform_binning_bit_exact(fresh_engine):
+    """Non-uniform (box) samples on the device: mega-bin grid -> candidate scan with the (lo, hi] test
+    (BinningHandler.cpp:277-290), mixed with a uniform sample, integer-exact against the oracle; with
+    a shift registered every step re-bins through the cached nominal mega-bins."""
+    rng = np.random.default_rng(31)
+    E, P = 6000, 2
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    boxes, xs = _random_boxes(rng, 9, 7, 0.0, 5.0, -1.0, 1.0, drop=5)
+    boxes3 = np.array([[[0, 1], [0, 1], [0, 2]], [[1, 3], [0, 1], [0, 2]], [[0, 3], [1, 2], [0, 1]], [[0, 3], [1, 2], [1, 2]]], np.float64)
+    e1 = np.linspace(0.0, 5.0, 26)
+    sample_id = rng.integers(0, 3, E).astype(np.int32)
+    kin = np.stack([rng.uniform(-0.2, 5.2, E), rng.uniform(-1.1, 1.1, E), rng.uniform(-0.1, 2.1, E)], axis=1)
+    s2 = np.flatnonzero(sample_id == 2)
+    kin[s2, 0] = rng.uniform(-0.1, 3.1, len(s2))
+    kin[s2, 1] = rng.uniform(-0.1, 2.1, len(s2))
+    kin[:200, 0] = rng.choice(np.concatenate([xs, np.linspace(0, 5, 11)]), 200)      # box edges and mega-bin edges
+    kin[200:400, 1] = rng.choice(np.concatenate([boxes[:, 1, :].ravel(), np.linspace(-1, 1, 11)]), 200)
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    assert b.add_uniform([e1]) == 0
+    assert b.add_nonuniform(boxes) == 1
+    assert b.add_nonuniform(boxes3) == 2
+    par = np.zeros(P + 1)
+    opar = par.copy()
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, None, None, opar, None, None, omono)
+    exp = osamp.event_bins()
+    nb = 25 + len(boxes) + 4
+    assert b.n_bins() == nb
+    for s, lo, hi in ((0, 0, 25), (1, 25, 25 + len(boxes)), (2, 25 + len(boxes), nb)):
+        got_s = exp[sample_id == s]
+        assert (got_s == -1).any() and ((got_s >= lo) & (got_s < hi)).sum() > 0.5 * len(got_s)
+        assert (((got_s >= lo) & (got_s < hi)) | (got_s == -1)).all()
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 3, None, par, bin_edges=[[e1], boxes, boxes3])
+    assert sh.nBins == nb
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    assert np.array_equal(sh.GetEventBins(0, E), exp)
+    sh.Reweight()
+    osamp.reweight()
+    assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+
+    # x *= 1 + theta on every sample: events migrate between boxes, mega-bins and out of range
+    osamp.add_shift(-1, 0, 1, opar, P)
+    sh.AddKinShift(-1, 0, 1, P)
+    moved = 0
+    for theta in (0.0, 0.013, -0.04, 0.11, -0.3, 0.0):
+        par[:P] = opar[:P] = rng.normal(0, 0.4, P)
+        par[P] = opar[P] = theta
+        sh.Reweight()
+        osamp.reweight()
+        got = sh.GetEventBins(0, E)
+        want = osamp.event_bins()
+        assert np.array_equal(got, want), theta
+        moved += int((want != exp).sum())
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        assert np.isclose(sh.GetLikelihood(), osamp.get_likelihood(), rtol=RTOL_LLH, atol=1e-9)
+    assert moved > 1000
+    osamp.close()
+    omono.close()
+
+
 def test_functional_shifts_rebin_every_step(fresh_engine):
     """Kinematic shifts driven by parameters (the reference's ApplyShifts + FindBin with the cached
     nominal bin: nominal hit, +-1 neighbour, binary search, migration out of range)."""
