@@ -172,6 +172,23 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
 int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size);
 
 /*
+ * The same for the reference's DEFAULT build, M3::float_t = double (Manager/Core.h:27-51; float only with
+ * MaCh3_LOW_MEMORY_STRUCTS): knots, xcoeff_arr, manycoeff_arr and weightvec_Monolith are double, the cubic
+ * uses std::fma on the parameter's own double value (BinnedSplineHandler.cpp:320-337), FindSplineSegment
+ * compares the float-cast value with the double knots (SplineBase.cpp:51-54), and the whole sample side --
+ * norm casts, oscillation weights, the weight product, w*w -- runs in double
+ * (SampleHandlerFD.cpp:568-594, 432-446).  Uploading bin-splines through this entry point switches the
+ * handle's sample epilogue to that build; oscillation weights then come from m3hip_set_osc_table_f64 (a
+ * float table is widened), per-event weights from m3hip_get_event_weights_f64.  That build has no
+ * event-by-event SMonolith (its weights are float), so the event space carries bin-splines only.
+ */
+int m3hip_binned_upload_f64(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const double* xpts,
+                            const int16_t* npts, int monolith_size, const int32_t* coeffindexvec,
+                            const int32_t* uniquesplinevec, int n_unique, const int32_t* uniquecoeffindices,
+                            int n_coeff, const double* xcoeff, const double* manycoeff);
+int m3hip_get_binned_weights_f64(m3hip_handle h, double* out, int monolith_size);
+
+/*
  * Device-side binning: instead of precomputed bin_idx, hand over the
  * binning and the nominal kinematic variables and let the device run
  * BinningHandler::FindGlobalBin / SampleBinningInfo::FindBin (Samples/BinningHandler.cpp:257-307,
@@ -218,6 +235,7 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
 /* Pre-staged oscillation weights (what OscillationHandler::Evaluate leaves behind the
  * event pointers, Samples/OscillationHandler.cpp:81-119).  May be re-uploaded per step. */
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n);
+int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n);
 
 /* SampleHandlerFD::AddData for all global bins (SampleHandlerFD.cpp:1027-1044) */
 int m3hip_set_data(m3hip_handle h, const double* data, int n_bins);
@@ -245,6 +263,7 @@ int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, 
  * default: the fused step writes nothing per event) */
 int m3hip_record_event_weights(m3hip_handle h, int enable);
 int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n);
+int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offset, uint64_t n);
 /* state written by the device-side FindSplineSegment of the last reweight */
 int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_params);
 

@@ -4,29 +4,37 @@
 // Only Evaluate() and the weight look-up exist here.  Loading splines from ROOT files, the
 // 7-dimensional indexvec and the mode / oscillation-channel bookkeeping
 // (BinnedSplineHandler.cpp:69-292, 343-1090) are set-up code outside the per-step path: the
-// caller hands over the flat members that code produces.  float_t = float build.
+// caller hands over the flat members that code produces.
+//
+// M3::float_t: BinnedSplineHandlerT<float> is the MaCh3_LOW_MEMORY_STRUCTS build (the name
+// BinnedSplineHandler), BinnedSplineHandlerT<double> the reference's default build (Manager/Core.h:27-51):
+// double tables, std::fma cubic, and a double weight product in the sample that uses it.
 #pragma once
 
+#include <type_traits>
 #include <vector>
 
 #include "../m3hip.h"
 #include "Core.h"
 #include "SplineMonolith.h"
 
-class BinnedSplineHandler : public SplineBase {
+template <class FloatT>
+class BinnedSplineHandlerT : public SplineBase {
+  static_assert(std::is_same<FloatT, float>::value || std::is_same<FloatT, double>::value, "M3::float_t is float or double");
+
  public:
   /// the handler's flat members (BinnedSplineHandler.h:116-140) + the knots of every unique
   /// spline parameter (SplineInfoArray) and the number of MC events of the sample
-  BinnedSplineHandler(unsigned int n_events, short n_unique_params, short max_knots, const std::vector<float>& xpts,
-                      const std::vector<short>& npts, const std::vector<int>& coeffindexvec_,
-                      const std::vector<int>& uniquesplinevec_Monolith_, const std::vector<int>& uniquecoeffindices_,
-                      const std::vector<float>& xcoeff_arr, const std::vector<float>& manycoeff_arr, int device_id = 0)
+  BinnedSplineHandlerT(unsigned int n_events, short n_unique_params, short max_knots, const std::vector<FloatT>& xpts,
+                       const std::vector<short>& npts, const std::vector<int>& coeffindexvec_,
+                       const std::vector<int>& uniquesplinevec_Monolith_, const std::vector<int>& uniquecoeffindices_,
+                       const std::vector<FloatT>& xcoeff_arr, const std::vector<FloatT>& manycoeff_arr, int device_id = 0)
       : gpu(new SMonolithGPU(device_id)), MonolithSize(int(coeffindexvec_.size())) {
     nParams = n_unique_params;
-    M3HIP_CALL(gpu->Handle(), m3hip_binned_upload(gpu->Handle(), n_events, nParams, max_knots, xpts.data(), npts.data(), MonolithSize,
-                                                  coeffindexvec_.data(), uniquesplinevec_Monolith_.data(), int(uniquecoeffindices_.size()),
-                                                  uniquecoeffindices_.data(), int(xcoeff_arr.size()), xcoeff_arr.data(), manycoeff_arr.data()));
-    weightvec_Monolith.assign(size_t(MonolithSize), 1.f);
+    M3HIP_CALL(gpu->Handle(), Upload(gpu->Handle(), n_events, nParams, max_knots, xpts.data(), npts.data(), MonolithSize, coeffindexvec_.data(),
+                                     uniquesplinevec_Monolith_.data(), int(uniquecoeffindices_.size()), uniquecoeffindices_.data(),
+                                     int(xcoeff_arr.size()), xcoeff_arr.data(), manycoeff_arr.data()));
+    weightvec_Monolith.assign(size_t(MonolithSize), FloatT(1));
   }
   /// In the fused sample operator the weights never leave the device; Evaluate() is what
   /// SampleHandlerFD::Reweight() triggers.  Stand-alone it refreshes the host copy.
@@ -41,14 +49,23 @@ class BinnedSplineHandler : public SplineBase {
     M3HIP_CALL(gpu->Handle(), m3hip_binned_upload_events(gpu->Handle(), 0, w_off.size() - 1, w_off.data(), w_idx.data()));
   }
   /// weightvec_Monolith after the last Reweight() (device -> host)
-  const std::vector<float>& GetWeights() {
-    M3HIP_CALL(gpu->Handle(), m3hip_get_binned_weights(gpu->Handle(), weightvec_Monolith.data(), MonolithSize));
+  const std::vector<FloatT>& GetWeights() {
+    M3HIP_CALL(gpu->Handle(), Download(gpu->Handle(), weightvec_Monolith.data(), MonolithSize));
     return weightvec_Monolith;
   }
   m3hip_handle Handle() const { return gpu->Handle(); }
 
  private:
+  template <class... A>
+  static int Upload(m3hip_handle h, uint64_t n, int np, int mk, const float* x, A... rest) { return m3hip_binned_upload(h, n, np, mk, x, rest...); }
+  template <class... A>
+  static int Upload(m3hip_handle h, uint64_t n, int np, int mk, const double* x, A... rest) { return m3hip_binned_upload_f64(h, n, np, mk, x, rest...); }
+  static int Download(m3hip_handle h, float* out, int n) { return m3hip_get_binned_weights(h, out, n); }
+  static int Download(m3hip_handle h, double* out, int n) { return m3hip_get_binned_weights_f64(h, out, n); }
+
   std::unique_ptr<SMonolithGPU> gpu;
   int MonolithSize;
-  std::vector<float> weightvec_Monolith;
+  std::vector<FloatT> weightvec_Monolith;
 };
+
+using BinnedSplineHandler = BinnedSplineHandlerT<float>;

@@ -274,6 +274,8 @@ class SampleHandlerFD : public SampleHandlerBase {
   }
   /// weights OscillationHandler::Evaluate would have left behind the event pointers
   void SetOscillationWeights(const std::vector<float>& w) { M3HIP_CALL(h, m3hip_set_osc_table(h, w.data(), w.size())); }
+  /// M3::float_t = double build (with a BinnedSplineHandlerT<double> behind the handle)
+  void SetOscillationWeights(const std::vector<double>& w) { M3HIP_CALL(h, m3hip_set_osc_table_f64(h, w.data(), w.size())); }
 
   // ---- per step (ref: Samples/SampleHandlerFD.cpp:316-343, 1262-1300)
   void Reweight() override { M3HIP_CALL(h, m3hip_reweight(h, fPropVal, nPar)); }

@@ -19,6 +19,7 @@ M3HIP_SYMBOLS = [
     "m3hip_set_spline_param_map", "m3hip_set_binning", "m3hip_upload_events", "m3hip_set_osc_table",
     "m3hip_set_data", "m3hip_set_test_statistic",
     "m3hip_binned_upload", "m3hip_binned_upload_events", "m3hip_get_binned_weights",
+    "m3hip_binned_upload_f64", "m3hip_get_binned_weights_f64", "m3hip_set_osc_table_f64", "m3hip_get_event_weights_f64",
     "m3hip_set_binning_edges", "m3hip_upload_kinematics", "m3hip_compute_bins", "m3hip_add_kin_shift",
     "m3hip_clear_kin_shifts", "m3hip_add_kin_cut", "m3hip_get_event_bins",
     "m3hip_binning_begin", "m3hip_binning_add_uniform", "m3hip_binning_add_nonuniform", "m3hip_binning_end",
@@ -115,6 +116,10 @@ def load_m3hip():
         "m3hip_binned_upload": [vp, u64, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp],
         "m3hip_binned_upload_events": [vp, u64, u64, vp, vp],
         "m3hip_get_binned_weights": [vp, vp, i32],
+        "m3hip_binned_upload_f64": [vp, u64, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp],
+        "m3hip_get_binned_weights_f64": [vp, vp, i32],
+        "m3hip_set_osc_table_f64": [vp, vp, u64],
+        "m3hip_get_event_weights_f64": [vp, vp, u64, u64],
         "m3hip_upload_kinematics": [vp, u64, u64, vp, vp, i32],
         "m3hip_compute_bins": [vp],
         "m3hip_add_kin_shift": [vp, i32, i32, i32, i32],

@@ -128,6 +128,14 @@ struct m3hip_ctx {
   float* d_b_xcoeff = nullptr;
   float4* d_b_many = nullptr;
   float* d_b_w = nullptr;
+  // M3::float_t = double build of the sample side (m3hip_binned_upload_f64)
+  bool f64 = false;
+  double* d_b_xcoeff_d = nullptr;
+  double* d_b_many_d = nullptr;
+  double* d_b_w_d = nullptr;
+  double* d_coeff_x_d = nullptr;
+  double* d_osc_table_d = nullptr;
+  double* d_event_w_d = nullptr;
   int32_t* d_bwidx = nullptr;
   uint32_t Kb = 0;
 
@@ -289,6 +297,12 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_b_xcoeff); h->d_b_xcoeff = nullptr;
   dev_free(h->d_b_many); h->d_b_many = nullptr;
   dev_free(h->d_b_w); h->d_b_w = nullptr;
+  dev_free(h->d_b_xcoeff_d); h->d_b_xcoeff_d = nullptr;
+  dev_free(h->d_b_many_d); h->d_b_many_d = nullptr;
+  dev_free(h->d_b_w_d); h->d_b_w_d = nullptr;
+  dev_free(h->d_coeff_x_d); h->d_coeff_x_d = nullptr;
+  dev_free(h->d_event_w_d); h->d_event_w_d = nullptr;
+  h->f64 = false;
   dev_free(h->d_bwidx); h->d_bwidx = nullptr;
   h->b_M = h->b_U = h->b_C = 0;
   h->Kb = 0;
@@ -346,6 +360,9 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.osc_table = h->d_osc_table;
   a.bwidx = h->d_bwidx;
   a.bw = h->d_b_w;
+  a.bw_d = h->d_b_w_d;
+  a.osc_table_d = h->d_osc_table_d;
+  a.event_w_d = h->d_event_w_d;
   a.n_bw_slots = h->Kb;
   a.hist = h->d_hist;
   a.hist_rep = h->hist_rep;
@@ -398,6 +415,7 @@ int m3hip_destroy(m3hip_handle h) {
   }
   dev_free(h->d_params);
   dev_free(h->d_osc_table);
+  dev_free(h->d_osc_table_d);
   dev_free(h->d_bin_samples);
   dev_free(h->d_bin_axes);
   dev_free(h->d_edges);
@@ -779,10 +797,10 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   return M3HIP_OK;
 }
 
-int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
-                        int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
-                        const int32_t* uniquecoeffindices, int n_coeff, const float* xcoeff, const float* manycoeff) {
-  if (!h) return M3HIP_EINVAL;
+// shared part of m3hip_binned_upload / _f64: validation, the empty event space, the index tables
+static int binned_upload_common(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
+                                int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
+                                const int32_t* uniquecoeffindices, int n_coeff, const void* xcoeff, const void* manycoeff) {
   if (n_events == 0 || monolith_size <= 0 || n_unique < 0 || n_coeff < 0 || !coeffindexvec || !uniquesplinevec ||
       (n_unique && (!uniquecoeffindices || !xcoeff || !manycoeff)))
     return fail(h, M3HIP_EINVAL, "binned_upload: empty / NULL arguments");
@@ -809,21 +827,57 @@ int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max
   if ((rc = dev_alloc(h, &h->d_b_cidx, size_t(monolith_size)))) return rc;
   if ((rc = dev_alloc(h, &h->d_b_usv, size_t(monolith_size)))) return rc;
   if ((rc = dev_alloc(h, &h->d_b_uniq, size_t(n_unique)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_xcoeff, size_t(n_coeff)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_many, size_t(n_coeff)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_w, size_t(monolith_size)))) return rc;
   HIPCHK(h, hipMemcpy(h->d_b_cidx, coeffindexvec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_b_usv, uniquesplinevec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
   if (n_unique) HIPCHK(h, hipMemcpy(h->d_b_uniq, uniquecoeffindices, sizeof(int32_t) * n_unique, hipMemcpyHostToDevice));
+  h->b_M = monolith_size;
+  h->b_U = n_unique;
+  h->b_C = n_coeff;
+  return M3HIP_OK;
+}
+
+int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
+                        int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
+                        const int32_t* uniquecoeffindices, int n_coeff, const float* xcoeff, const float* manycoeff) {
+  if (!h) return M3HIP_EINVAL;
+  int rc = binned_upload_common(h, n_events, n_params, max_knots, xpts, npts, monolith_size, coeffindexvec, uniquesplinevec, n_unique,
+                                uniquecoeffindices, n_coeff, xcoeff, manycoeff);
+  if (rc) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_xcoeff, size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_many, size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_w, size_t(monolith_size)))) return rc;
   if (n_coeff) {
     HIPCHK(h, hipMemcpy(h->d_b_xcoeff, xcoeff, sizeof(float) * n_coeff, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_b_many, manycoeff, sizeof(float) * 4 * size_t(n_coeff), hipMemcpyHostToDevice));
   }
   std::vector<float> ones(size_t(monolith_size), 1.0f);  // flat bin-splines keep weight 1 (BinnedSplineHandler.cpp:236)
   HIPCHK(h, hipMemcpy(h->d_b_w, ones.data(), sizeof(float) * monolith_size, hipMemcpyHostToDevice));
-  h->b_M = monolith_size;
-  h->b_U = n_unique;
-  h->b_C = n_coeff;
+  return M3HIP_OK;
+}
+
+int m3hip_binned_upload_f64(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const double* xpts, const int16_t* npts,
+                            int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
+                            const int32_t* uniquecoeffindices, int n_coeff, const double* xcoeff, const double* manycoeff) {
+  if (!h) return M3HIP_EINVAL;
+  if (!xpts || !npts || n_params <= 0 || max_knots <= 0) return fail(h, M3HIP_EINVAL, "binned_upload_f64: NULL / empty knot table");
+  // the float knot table only feeds dx of event-by-event splines, of which this build has none
+  std::vector<float> xf(size_t(n_params) * max_knots);
+  for (size_t i = 0; i < xf.size(); ++i) xf[i] = float(xpts[i]);
+  int rc = binned_upload_common(h, n_events, n_params, max_knots, xf.data(), npts, monolith_size, coeffindexvec, uniquesplinevec, n_unique,
+                                uniquecoeffindices, n_coeff, xcoeff, manycoeff);
+  if (rc) return rc;
+  if ((rc = dev_alloc(h, &h->d_coeff_x_d, xf.size()))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_xcoeff_d, size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_many_d, 4 * size_t(n_coeff)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_w_d, size_t(monolith_size)))) return rc;
+  HIPCHK(h, hipMemcpy(h->d_coeff_x_d, xpts, sizeof(double) * xf.size(), hipMemcpyHostToDevice));
+  if (n_coeff) {
+    HIPCHK(h, hipMemcpy(h->d_b_xcoeff_d, xcoeff, sizeof(double) * n_coeff, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_b_many_d, manycoeff, sizeof(double) * 4 * size_t(n_coeff), hipMemcpyHostToDevice));
+  }
+  std::vector<double> ones(size_t(monolith_size), 1.0);
+  HIPCHK(h, hipMemcpy(h->d_b_w_d, ones.data(), sizeof(double) * monolith_size, hipMemcpyHostToDevice));
+  h->f64 = true;
   return M3HIP_OK;
 }
 
@@ -860,9 +914,20 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
   return M3HIP_OK;
 }
 
+int m3hip_get_binned_weights_f64(m3hip_handle h, double* out, int monolith_size) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (monolith_size != h->b_M || h->b_M == 0) return fail(h, M3HIP_EINVAL, "get_binned_weights_f64: size mismatch");
+  if (!h->f64) return fail(h, M3HIP_ESTATE, "get_binned_weights_f64: the bin-splines were uploaded as float");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, wait_stream(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_b_w_d, sizeof(double) * monolith_size, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
 int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) {
   if (!h || !out) return M3HIP_EINVAL;
   if (monolith_size != h->b_M || h->b_M == 0) return fail(h, M3HIP_EINVAL, "get_binned_weights: size mismatch");
+  if (h->f64) return fail(h, M3HIP_ESTATE, "get_binned_weights: the bin-splines were uploaded as double, use _f64");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, wait_stream(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_b_w, sizeof(float) * monolith_size, hipMemcpyDeviceToHost));
@@ -1127,19 +1192,47 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
   return M3HIP_OK;
 }
 
+static int osc_table_resize(m3hip_handle h, uint64_t n) {
+  if (n == h->n_osc) return M3HIP_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  dev_free(h->d_osc_table);
+  dev_free(h->d_osc_table_d);
+  h->d_osc_table = nullptr;
+  h->d_osc_table_d = nullptr;
+  h->n_osc = 0;
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_osc_table, size_t(n)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_osc_table_d, size_t(n)))) return rc;
+  h->n_osc = n;
+  return M3HIP_OK;
+}
+
+// both precisions of the table are kept: the float -> double widening is exact, the narrowing is what a
+// float_t = float build would have stored
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
   if (!h) return M3HIP_EINVAL;
   if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table: empty table");
   HIPCHK(h, hipSetDevice(h->device));
-  if (n != h->n_osc) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    dev_free(h->d_osc_table);
-    int rc = dev_alloc(h, &h->d_osc_table, size_t(n));
-    if (rc) return rc;
-    h->n_osc = n;
-  }
-  HIPCHK(h, hipMemcpyAsync(h->d_osc_table, table, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+  int rc = osc_table_resize(h, n);
+  if (rc) return rc;
+  std::vector<double> wide(table, table + n);
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_osc_table, table, sizeof(float) * n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_osc_table_d, wide.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  return M3HIP_OK;
+}
+
+int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) {
+  if (!h) return M3HIP_EINVAL;
+  if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table_f64: empty table");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = osc_table_resize(h, n);
+  if (rc) return rc;
+  std::vector<float> narrow(n);
+  for (uint64_t i = 0; i < n; ++i) narrow[i] = float(table[i]);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_osc_table, narrow.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_osc_table_d, table, sizeof(double) * n, hipMemcpyHostToDevice));
   return M3HIP_OK;
 }
 
@@ -1193,6 +1286,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   p.n_par = n_par;
   p.par_map = h->d_parmap;
   p.coeff_x = h->d_coeff_x;
+  p.coeff_x_d = h->d_coeff_x_d;
   p.npts = h->d_npts;
   p.curr_seg = h->d_currseg;
   p.n_params = h->P;
@@ -1225,6 +1319,11 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     ba.pval = h->d_pval;
     ba.weightvec = h->d_b_w;
     ba.n_unique = h->b_U;
+    ba.xcoeff_d = h->d_b_xcoeff_d;
+    ba.manycoeff_d = h->d_b_many_d;
+    ba.weightvec_d = h->d_b_w_d;
+    ba.params = h->d_params;
+    ba.par_map = h->d_parmap;
     launch_binned_weights(ba, h->stream);
   }
   if (!h->h_shifts.empty()) {  // functional shifts: re-bin every event from its shifted kinematics
@@ -1242,11 +1341,20 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
       if ((rc = dev_alloc(h, &h->d_event_w, size_t(h->E_pad)))) return rc;
       a.event_w = h->d_event_w;
     }
+    if (h->f64 && !h->d_event_w_d) {
+      if ((rc = dev_alloc(h, &h->d_event_w_d, size_t(h->E_pad)))) return rc;
+      a.event_w_d = h->d_event_w_d;
+    }
     mode |= kModeEventW | kModeEval;
   }
   if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->knobs, h->stream);
-  launch_reweight_brick(a, uint32_t(h->h_bricks.size()), mode, h->knobs, h->stream);
+  if (h->f64) {
+    if (!h->h_bricks.empty()) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
+    launch_reweight_uniform_f64(a, uint32_t(h->h_tiles.size()), mode, h->stream);
+  } else {
+    launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->knobs, h->stream);
+    launch_reweight_brick(a, uint32_t(h->h_bricks.size()), mode, h->knobs, h->stream);
+  }
   if (h->timing) {
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     h->pending = 0;
@@ -1376,6 +1484,17 @@ int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, u
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
   HIPCHK(h, hipMemcpy(out, h->d_event_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
+int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offset, uint64_t n) {
+  if (!h || !out) return M3HIP_EINVAL;
+  if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_weights_f64: bad range");
+  if (!h->d_event_w_d) return fail(h, M3HIP_ESTATE, "get_event_weights_f64: needs m3hip_binned_upload_f64 and m3hip_record_event_weights(h, 1) before the reweight");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  collect_timing(h);
+  HIPCHK(h, hipMemcpy(out, h->d_event_w_d + event_offset, sizeof(double) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
 }
 

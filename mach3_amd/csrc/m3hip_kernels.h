@@ -67,6 +67,11 @@ struct ReweightArgs {
   const float* bw;           // weightvec_Monolith of the binned spline handler
   uint32_t n_bw_slots;
   const float* osc_table;
+  // M3::float_t = double build of the sample side (Manager/Core.h:27-51: the default, non-low-memory
+  // build): bin-spline weights, oscillation weights and the event weight product are double
+  const double* bw_d;
+  const double* osc_table_d;
+  double* event_w_d;         // [E_pad] (may be null)
   double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
   int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
   uint64_t e_pad;
@@ -85,6 +90,8 @@ struct PrepArgs {
   int32_t n_par;
   const int32_t* par_map;     // [P] spline parameter -> global index
   const float* coeff_x;       // [P*K]
+  const double* coeff_x_d;    // [P*K] or null: knots as double (float_t = double build: xPts are double and the
+                              // float parameter value is compared against them, SplineBase.cpp:51-54)
   const int16_t* npts;        // [P]
   int16_t* curr_seg;          // [P] FastSplineInfo.CurrSegment (state)
   int32_t n_params, max_knots;
@@ -169,6 +176,13 @@ struct BinnedArgs {
   const float* pval;
   float* weightvec;                   // [M]
   int32_t n_unique;
+  // float_t = double build: the same tables in double; xvar is the parameter's double value itself
+  // (BinnedSplineHandler.cpp:327), read through par_map from the device parameter vector
+  const double* xcoeff_d;
+  const double* manycoeff_d;          // [C][4]
+  double* weightvec_d;
+  const double* params;
+  const int32_t* par_map;
 };
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s);
 
@@ -196,6 +210,8 @@ struct ReweightKnobs {
 };
 
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
+// float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
+void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s);
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);

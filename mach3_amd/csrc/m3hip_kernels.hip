@@ -14,6 +14,8 @@
 // bit-identical to a serial CPU evaluation in the reference's operation order.
 #include "m3hip_kernels.h"
 
+#include <type_traits>
+
 namespace m3hip {
 
 // ------------------------------------------------------------------------------------
@@ -51,16 +53,21 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
       if (nPoints > 0) {                         // :60 parameters without knots are skipped
         int kHigh = nPoints - 1;
         const int PreviousSegment = a.curr_seg[i];
-        if (xvar <= xArray[0]) {
+        // comparisons run in double: exact for float knots (both sides promote exactly), and what the
+        // float_t = double build does with its double knots
+        const double* xd = a.coeff_x_d ? a.coeff_x_d + (size_t)i * K : nullptr;
+        auto X = [&](int k) -> double { return xd ? xd[k] : (double)xArray[k]; };
+        const double xv = (double)xvar;
+        if (xv <= X(0)) {
           segment = 0;
-        } else if (xvar >= xArray[nPoints - 1]) {
+        } else if (xv >= X(nPoints - 1)) {
           segment = kHigh;
-        } else if (xArray[PreviousSegment + 1] > xvar && xvar >= xArray[PreviousSegment]) {  // :76
+        } else if (X(PreviousSegment + 1) > xv && xv >= X(PreviousSegment)) {  // :76
           segment = PreviousSegment;
         } else {
           while (kHigh - segment > 1) {  // :84-94
             const int kHalf = (segment + kHigh) / 2;
-            if (xvar > xArray[kHalf]) segment = kHalf;
+            if (xv > X(kHalf)) segment = kHalf;
             else kHigh = kHalf;
           }
         }
@@ -158,27 +165,38 @@ __device__ __forceinline__ float2 stream_load(const float2* p) {
 // Per-event gathers of the fused epilogue, batched so that several independent loads are in
 // flight per lane (a plain loop over a run-time slot count serialises index load -> gather).
 // Multiplication order is the slot order, as CalcWeightTotal walks its pointer vectors.
-__device__ __forceinline__ float mul_binned_weights(float tw, const ReweightArgs& a, uint64_t ev) {
+// WT = M3::float_t of the sample side: float (low-memory build, the one SMonolith needs) or double
+template <class WT>
+__device__ __forceinline__ const WT* binned_table(const ReweightArgs& a);
+template <>
+__device__ __forceinline__ const float* binned_table<float>(const ReweightArgs& a) { return a.bw; }
+template <>
+__device__ __forceinline__ const double* binned_table<double>(const ReweightArgs& a) { return a.bw_d; }
+
+template <class WT>
+__device__ __forceinline__ WT mul_binned_weights(WT tw, const ReweightArgs& a, uint64_t ev) {
+  const WT* __restrict__ bw = binned_table<WT>(a);
   uint32_t k = 0;
   for (; k + 4 <= a.n_bw_slots; k += 4) {
     int bi[4];
-    float wv[4];
+    WT wv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) bi[u] = a.bwidx[(uint64_t)(k + u) * a.e_pad + ev];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = bi[u] >= 0 ? a.bw[bi[u]] : 1.0f;
+    for (int u = 0; u < 4; ++u) wv[u] = bi[u] >= 0 ? bw[bi[u]] : WT(1);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (bi[u] >= 0) tw *= wv[u];
   }
   for (; k < a.n_bw_slots; ++k) {
     const int bi = a.bwidx[(uint64_t)k * a.e_pad + ev];
-    if (bi >= 0) tw *= a.bw[bi];
+    if (bi >= 0) tw *= bw[bi];
   }
   return tw;
 }
 
-__device__ __forceinline__ float mul_norm_weights(float tw, const ReweightArgs& a, uint64_t ev) {
+template <class WT>
+__device__ __forceinline__ WT mul_norm_weights(WT tw, const ReweightArgs& a, uint64_t ev) {
   uint32_t m = 0;
   for (; m + 4 <= a.n_norm_slots; m += 4) {
     int idx[4];
@@ -189,16 +207,16 @@ __device__ __forceinline__ float mul_norm_weights(float tw, const ReweightArgs& 
     for (int u = 0; u < 4; ++u) v[u] = idx[u] >= 0 ? a.params[idx[u]] : 1.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (idx[u] >= 0) tw *= static_cast<float>(v[u]);  // double -> float cast per pointer (SampleHandlerFD.cpp:580)
+      if (idx[u] >= 0) tw *= static_cast<WT>(v[u]);  // static_cast<M3::float_t> per pointer (SampleHandlerFD.cpp:580)
   }
   for (; m < a.n_norm_slots; ++m) {
     const int idx = a.nidx[(uint64_t)m * a.e_pad + ev];
-    if (idx >= 0) tw *= static_cast<float>(a.params[idx]);
+    if (idx >= 0) tw *= static_cast<WT>(a.params[idx]);
   }
   return tw;
 }
 
-template <int MODE, int UNROLL, bool NT>
+template <int MODE, int UNROLL, bool NT, bool F64 = false>
 __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 (kModeFill only)
   const uint32_t tile = a.tile_base + blockIdx.x;
@@ -266,19 +284,23 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   if (MODE & (kModeFill | kModeEventW)) {
     // ---- kernel (ii): CalcWeightTotal (SampleHandlerFD.cpp:568-594): norm pointers first
     // (double -> float cast each), then total_weight_pointers = {osc, spline total weight}.
-    float tw = mul_norm_weights(1.0f, a, ev);  // -1: empty ELL slot
+    using WT = typename std::conditional<F64, double, float>::type;  // M3::float_t
+    WT tw = mul_norm_weights<WT>(WT(1), a, ev);  // -1: empty ELL slot
     const int oi = a.osc[ev];
-    if (oi >= 0) tw *= a.osc_table[oi];
-    tw = mul_binned_weights(tw, a, ev);  // bin-spline weights, in SetSplinePointers order
-    tw *= w;
-    if (MODE & kModeEventW) a.event_w[ev] = tw;
+    if (oi >= 0) tw *= F64 ? (WT)a.osc_table_d[oi] : (WT)a.osc_table[oi];
+    tw = mul_binned_weights<WT>(tw, a, ev);  // bin-spline weights, in SetSplinePointers order
+    tw *= (WT)w;                              // F64: no event-by-event splines in that build, w == 1
+    if (MODE & kModeEventW) {
+      if (F64) a.event_w_d[ev] = (double)tw;
+      else a.event_w[ev] = (float)tw;
+    }
     if (MODE & kModeFill) {
       __syncthreads();
       const int b = a.bin[ev];
       // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`
-      if (lane < td.n_events && tw > 0.f && b >= 0) {
+      if (lane < td.n_events && tw > WT(0) && b >= 0) {
         atomicAdd(&lds_hist[b], (double)tw);
-        if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // float square, then widened (:445)
+        if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // square in float_t, then widened (:445)
       }
       __syncthreads();
       const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
@@ -316,6 +338,14 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
   else launch_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
 }
 
+
+void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s) {
+  if (n_tiles == 0) return;
+  const size_t lds = sizeof(double) * 2 * (size_t)a.n_bins;
+  const dim3 g(n_tiles), b(256);
+  if (mode == kModeFill) hipLaunchKernelGGL((k_reweight_uniform<kModeFill, 8, true, true>), g, b, lds, s, a);
+  else hipLaunchKernelGGL((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, true>), g, b, lds, s, a);
+}
 
 // ------------------------------------------------------------------------------------
 // k_reweight_brick: one workgroup per brick (<= 1024 events with ragged parameter lists).
@@ -630,8 +660,27 @@ __global__ __launch_bounds__(256) void k_binned_weights(BinnedArgs a) {
   a.weightvec[iSpline] = weight;
 }
 
+// float_t = double build: double tables, std::fma, and xvar is the parameter's own double value
+// (BinnedSplineHandler.cpp:320-337 with M3::float_t = double, M3::fmaf_t = std::fma, Core.h:44-51)
+__global__ __launch_bounds__(256) void k_binned_weights_f64(BinnedArgs a) {
+  const int iCoeff = blockIdx.x * 256 + threadIdx.x;
+  if (iCoeff >= a.n_unique) return;
+  const int iSpline = a.uniquecoeffindices[iCoeff];
+  const int uniqueIndex = a.uniquesplinevec[iSpline];
+  const int segCoeff = a.coeffindexvec[iSpline] + a.ptab[uniqueIndex].seg;
+  const double* c = a.manycoeff_d + (size_t)segCoeff * 4;
+  const double y = c[0], b = c[1], cc = c[2], d = c[3];
+  const double xvar = a.params[a.par_map[uniqueIndex]];
+  const double dx = xvar - a.xcoeff_d[segCoeff];
+  double weight = fma(dx, fma(dx, fma(dx, d, cc), b), y);
+  if (weight < 0) weight = 0.;
+  a.weightvec_d[iSpline] = weight;
+}
+
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
-  if (a.n_unique > 0) hipLaunchKernelGGL(k_binned_weights, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
+  if (a.n_unique <= 0) return;
+  if (a.weightvec_d) hipLaunchKernelGGL(k_binned_weights_f64, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_binned_weights, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------

@@ -188,18 +188,22 @@ class SMonolith:
 class BinnedSplineHandler:
     """Bin-by-bin splines on the GPU: the per-step part of BinnedSplineHandler
     (ref: Splines/BinnedSplineHandler.cpp:295-341).  `bs` holds the handler's flat members
-    (coeffindexvec, uniquesplinevec, uniquecoeffindices, xcoeff, manycoeff, xpts, npts)."""
+    (coeffindexvec, uniquesplinevec, uniquecoeffindices, xcoeff, manycoeff, xpts, npts).  The dtype of
+    xcoeff selects M3::float_t: float32 (low-memory build) or float64 (the reference's default build,
+    Manager/Core.h:27-51), which also switches the sample's weight product to double."""
 
     def __init__(self, engine: Engine, n_events: int, bs: dict):
         self.eng = engine
         self.bs = bs
         self.nParams = int(bs["n_params"])
         self.MonolithSize = int(bs["monolith_size"])
-        engine._chk(engine.lib.m3hip_binned_upload(
-            engine.h, n_events, self.nParams, bs["max_knots"], _ptr(bs["xpts"], np.float32), _ptr(bs["npts"], np.int16),
+        self.float_t = np.float64 if bs["xcoeff"].dtype == np.float64 else np.float32
+        up = engine.lib.m3hip_binned_upload_f64 if self.float_t == np.float64 else engine.lib.m3hip_binned_upload
+        engine._chk(up(
+            engine.h, n_events, self.nParams, bs["max_knots"], _ptr(bs["xpts"], self.float_t), _ptr(bs["npts"], np.int16),
             self.MonolithSize, _ptr(bs["coeffindexvec"], np.int32), _ptr(bs["uniquesplinevec"], np.int32),
             len(bs["uniquecoeffindices"]), _ptr(bs["uniquecoeffindices"], np.int32), len(bs["xcoeff"]),
-            _ptr(bs["xcoeff"], np.float32), _ptr(bs["manycoeff"], np.float32)))
+            _ptr(bs["xcoeff"], self.float_t), _ptr(bs["manycoeff"], self.float_t)))
 
     def GetName(self):
         return "BinnedSplineHandler"
@@ -220,8 +224,9 @@ class BinnedSplineHandler:
         self.eng._chk(self.eng.lib.m3hip_binned_upload_events(self.eng.h, event_offset, len(wo) - 1, _ptr(wo, np.uint64), _ptr(wi, np.int32)))
 
     def GetWeights(self):
-        out = np.empty(self.MonolithSize, np.float32)
-        self.eng._chk(self.eng.lib.m3hip_get_binned_weights(self.eng.h, _ptr(out, np.float32), self.MonolithSize))
+        out = np.empty(self.MonolithSize, self.float_t)
+        get = self.eng.lib.m3hip_get_binned_weights_f64 if self.float_t == np.float64 else self.eng.lib.m3hip_get_binned_weights
+        self.eng._chk(get(self.eng.h, _ptr(out, self.float_t), self.MonolithSize))
         return out
 
 
@@ -308,6 +313,11 @@ class SampleHandlerFD:
         return out
 
     def SetOscillationWeights(self, table):
+        """float64 tables go through m3hip_set_osc_table_f64 (M3::float_t = double build)"""
+        if np.asarray(table).dtype == np.float64:
+            t = np.ascontiguousarray(table, np.float64)
+            self.eng._chk(self.eng.lib.m3hip_set_osc_table_f64(self.eng.h, _ptr(t, np.float64), len(t)))
+            return
         t = np.ascontiguousarray(table, np.float32)
         self.eng._chk(self.eng.lib.m3hip_set_osc_table(self.eng.h, _ptr(t, np.float32), len(t)))
 
@@ -352,9 +362,10 @@ class SampleHandlerFD:
     def RecordEventWeights(self, on=True):
         self.eng._chk(self.eng.lib.m3hip_record_event_weights(self.eng.h, int(on)))
 
-    def GetEventWeights(self, off, n):
-        out = np.empty(n, np.float32)
-        self.eng._chk(self.eng.lib.m3hip_get_event_weights(self.eng.h, _ptr(out, np.float32), off, n))
+    def GetEventWeights(self, off, n, float_t=np.float32):
+        out = np.empty(n, float_t)
+        get = self.eng.lib.m3hip_get_event_weights_f64 if float_t == np.float64 else self.eng.lib.m3hip_get_event_weights
+        self.eng._chk(get(self.eng.h, _ptr(out, float_t), off, n))
         return out
 
     def GetSplineWeights(self, off, n):

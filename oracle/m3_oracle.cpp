@@ -32,7 +32,10 @@
 
 namespace {
 
-typedef float m3_float_t;  // ref: Manager/Core.h:27-34 (_LOW_MEMORY_STRUCTS_)
+typedef m3o_float_t m3_float_t;  // ref: Manager/Core.h:27-39 (float with _LOW_MEMORY_STRUCTS_, else double)
+// ref: Manager/Core.h:44-51 M3::fmaf_t
+static inline float m3_fmaf_t(float x, float y, float z) { return std::fmaf(x, y, z); }
+static inline double m3_fmaf_t(double x, double y, double z) { return std::fma(x, y, z); }
 typedef short m3_int_t;
 
 const double kLowMCBound = M3O_LOW_MC_BOUND;
@@ -633,9 +636,11 @@ struct m3o_binned {
   std::vector<m3_float_t> weightvec_Monolith;
 };
 
-m3o_binned* m3o_binned_create(int n_params, int max_knots, const float* xpts, const int16_t* npts, int monolith_size,
+int m3o_float_t_size(void) { return int(sizeof(m3o_float_t)); }
+
+m3o_binned* m3o_binned_create(int n_params, int max_knots, const m3o_float_t* xpts, const int16_t* npts, int monolith_size,
                               const int* coeffindexvec, const int* uniquesplinevec, int n_unique,
-                              const int* uniquecoeffindices, const float* xcoeff, const float* manycoeff) {
+                              const int* uniquecoeffindices, const m3o_float_t* xcoeff, const m3o_float_t* manycoeff) {
   m3o_binned* b = new m3o_binned();
   b->nParams = short(n_params);
   b->MonolithSize = monolith_size;
@@ -704,12 +709,12 @@ void m3o_binned_evaluate(m3o_binned* b) {
     const m3_float_t d = b->manycoeff_arr[coeffOffset + 3];
     const m3_float_t xvar = m3_float_t(*b->SplineInfoArray[uniqueIndex].splineParsPointer);  // ref: :327
     const m3_float_t dx = xvar - b->xcoeff_arr[segCoeff];
-    m3_float_t weight = fmaf(dx, fmaf(dx, fmaf(dx, d, c), bb), y);  // M3::fmaf_t, float build
+    m3_float_t weight = m3_fmaf_t(dx, m3_fmaf_t(dx, m3_fmaf_t(dx, d, c), bb), y);  // M3::fmaf_t
     if (weight < 0) weight = 0.;  // ref: :337
     b->weightvec_Monolith[iSpline] = weight;
   }
 }
-const float* m3o_binned_weights(const m3o_binned* b) { return b->weightvec_Monolith.data(); }
+const m3o_float_t* m3o_binned_weights(const m3o_binned* b) { return b->weightvec_Monolith.data(); }
 const int16_t* m3o_binned_segments(const m3o_binned* b) { return b->SplineSegments.data(); }
 
 /* ------------------------------------------------------------------------- */
@@ -1022,7 +1027,10 @@ struct m3o_sample {
 m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int32_t* sample_id,
                               int kin_stride, const double* kin, const uint64_t* norm_off,
                               const int16_t* norm_idx, const double* par_base, const int32_t* osc_idx,
-                              const float* osc_table, m3o_monolith* mono) {
+                              const m3o_float_t* osc_table, m3o_monolith* mono) {
+#ifdef M3O_FLOAT_T_DOUBLE
+  if (mono) return nullptr;  // SMonolith's float weights cannot sit behind const M3::float_t* in this build
+#endif
   m3o_sample* s = new m3o_sample();
   s->Binning = b;
   s->SplineHandler = mono;
@@ -1047,7 +1055,9 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
     // ref: SampleHandlerFD.cpp:1108-1122 osc pointer first (SetupOscParameters runs before SetupSplines)
     if (osc_idx && osc_idx[e] >= 0) ev.total_weight_pointers.push_back(&osc_table[osc_idx[e]]);
     // ref: SampleHandlerFD.cpp:1244-1249 then the monolith's total weight
+#ifndef M3O_FLOAT_T_DOUBLE
     if (mono) ev.total_weight_pointers.push_back(&mono->cpu_total_weights[e]);
+#endif
   }
   const int nb = b->TotalNumberOfBins;
   s->SampleHandlerFD_array.assign(nb, 0.);
@@ -1208,7 +1218,7 @@ const double* m3o_sample_mc(const m3o_sample* s) { return s->SampleHandlerFD_arr
 const double* m3o_sample_w2(const m3o_sample* s) { return s->SampleHandlerFD_array_w2.data(); }
 const double* m3o_sample_data(const m3o_sample* s) { return s->SampleHandlerFD_data.data(); }
 
-void m3o_sample_event_weights(const m3o_sample* s, float* out) {
+void m3o_sample_event_weights(const m3o_sample* s, m3o_float_t* out) {
   for (size_t e = 0; e < s->MCSamples.size(); ++e) out[e] = CalcWeightTotal(&s->MCSamples[e]);
 }
 void m3o_sample_event_bins(const m3o_sample* s, int32_t* out) {

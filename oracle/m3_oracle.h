@@ -101,19 +101,29 @@ const int16_t* m3o_monolith_segments(const m3o_monolith* m);     /* SplineSegmen
 const float* m3o_monolith_param_values(const m3o_monolith* m);   /* ParamValues[P] */
 int16_t* m3o_monolith_curr_segment_state(m3o_monolith* m);       /* FastSplineInfo.CurrSegment[P] */
 
-/* ---- binned spline handler: Splines/BinnedSplineHandler.cpp:295-341 (float_t = float build) ----
+/* M3::float_t (Manager/Core.h:27-51): float with MaCh3_LOW_MEMORY_STRUCTS (the build SMonolith's float
+ * weights can be plugged into), double by default.  The library is built once per choice
+ * (libm3oracle_*_f64.so: -DM3O_FLOAT_T_DOUBLE); the event-by-event monolith stays float in both. */
+#ifdef M3O_FLOAT_T_DOUBLE
+typedef double m3o_float_t;
+#else
+typedef float m3o_float_t;
+#endif
+int m3o_float_t_size(void);
+
+/* ---- binned spline handler: Splines/BinnedSplineHandler.cpp:295-341 ----
  * Arrays BORROWED, in the reference's members' layout: coeffindexvec[M] (first knot of each
  * bin-spline), uniquesplinevec_Monolith[M] (its unique spline parameter), uniquecoeffindices[U]
  * (the non-flat ones), xcoeff_arr[C], manycoeff_arr[4C]; xpts/npts give SplineInfoArray. */
 typedef struct m3o_binned m3o_binned;
-m3o_binned* m3o_binned_create(int n_params, int max_knots, const float* xpts, const int16_t* npts,
+m3o_binned* m3o_binned_create(int n_params, int max_knots, const m3o_float_t* xpts, const int16_t* npts,
                               int monolith_size, const int* coeffindexvec, const int* uniquesplinevec,
-                              int n_unique, const int* uniquecoeffindices, const float* xcoeff,
-                              const float* manycoeff);
+                              int n_unique, const int* uniquecoeffindices, const m3o_float_t* xcoeff,
+                              const m3o_float_t* manycoeff);
 void m3o_binned_destroy(m3o_binned* b);
 void m3o_binned_set_spline_pointers(m3o_binned* b, const double* const* ptrs);
 void m3o_binned_evaluate(m3o_binned* b);
-const float* m3o_binned_weights(const m3o_binned* b);   /* weightvec_Monolith[M] */
+const m3o_float_t* m3o_binned_weights(const m3o_binned* b);   /* weightvec_Monolith[M] */
 const int16_t* m3o_binned_segments(const m3o_binned* b);
 
 /* ---- binning: Samples/SampleStructs.h:172-676, Samples/BinningHandler.cpp:257-355 ---- */
@@ -151,8 +161,8 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
                               int kin_stride, const double* kin,
                               const uint64_t* norm_off, const int16_t* norm_idx,
                               const double* par_base,
-                              const int32_t* osc_idx, const float* osc_table,
-                              m3o_monolith* mono);
+                              const int32_t* osc_idx, const m3o_float_t* osc_table,
+                              m3o_monolith* mono); /* mono must be NULL in the float_t = double build */
 void m3o_sample_destroy(m3o_sample* s);
 /* SetSplinePointers with a BinnedSplineHandler (SampleHandlerFD.cpp:1196-1243): per event the CSR
  * w_off/w_idx of indices into weightvec_Monolith */
@@ -172,7 +182,7 @@ const double* m3o_sample_mc(const m3o_sample* s);
 const double* m3o_sample_w2(const m3o_sample* s);
 const double* m3o_sample_data(const m3o_sample* s);
 /* per-event CalcWeightTotal and FindGlobalBin, for event-level parity */
-void m3o_sample_event_weights(const m3o_sample* s, float* out);
+void m3o_sample_event_weights(const m3o_sample* s, m3o_float_t* out);
 void m3o_sample_event_bins(const m3o_sample* s, int32_t* out);
 /* phase timings of the last reweight (seconds): spline eval, fill */
 void m3o_sample_last_timing(const m3o_sample* s, double* t_spline, double* t_fill);

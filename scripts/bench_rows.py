@@ -16,28 +16,36 @@ def timeit(fn, n=200, spin=0.7):
     return (time.perf_counter()-t)/n*1e6
 
 rng=np.random.default_rng(5)
-# ---- binned splines: 1e6 events, 50 unique parameters, 1e6 bin-splines, ~30 weights per event
-P, cells, E = 50, 20000, 1_000_000
-bs = make_binned(P, cells, rng)
-cell = rng.integers(0, cells, E)
-mask = rng.random((E, P)) < 0.6
-cnt = mask.sum(1)
-w_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
-w_idx = (cell[:, None] * P + np.arange(P)[None, :])[mask].astype(np.int32)
-par = np.zeros(P + 4); par[P:] = 1
-eng = Engine(0)
-h = BinnedSplineHandler(eng, E, bs); h.setSplinePointers(par)
-edges = np.linspace(0, 5, 201); kin = rng.gamma(3.0, 0.35, E); sid = np.zeros(E, np.int32)
-sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kBarlowBeeston)
-sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sid, 200), rng.integers(-1, 4000, E).astype(np.int32), None, None)
-h.SetEventSplines(0, w_off, w_idx); sh.SetOscillationWeights(rng.random(4000).astype(np.float32))
-sh.Reweight(); sh.AddData(sh.GetMCArray())
-def step():
-    par[:P] = rng.uniform(-2, 2, P); return sh.Step()
-eng.timing_enable(True); us = timeit(step); k_ms,_ = eng.timing_read(0)
-print(f"binned: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: step {us:.1f} us, event kernel {k_ms*1e3:.1f} us "
-      f"({(w_idx.nbytes + 8*E)/k_ms/1e6:.0f} GB/s of index+bin/osc bytes)")
-eng.close()
+only = sys.argv[1] if len(sys.argv) > 1 else "all"
+# ---- binned splines: 1e6 events, 50 unique parameters, 1e6 bin-splines, ~30 weights per event; both M3::float_t builds
+def binned_row(float_t):
+    P, cells, E = 50, 20000, 1_000_000
+    bs = make_binned(P, cells, rng, float_t=float_t)
+    cell = rng.integers(0, cells, E)
+    mask = rng.random((E, P)) < 0.6
+    cnt = mask.sum(1)
+    w_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    w_idx = (cell[:, None] * P + np.arange(P)[None, :])[mask].astype(np.int32)
+    par = np.zeros(P + 4); par[P:] = 1
+    eng = Engine(0)
+    h = BinnedSplineHandler(eng, E, bs); h.setSplinePointers(par)
+    edges = np.linspace(0, 5, 201); kin = rng.gamma(3.0, 0.35, E); sid = np.zeros(E, np.int32)
+    sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kBarlowBeeston)
+    sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sid, 200), rng.integers(-1, 4000, E).astype(np.int32), None, None)
+    h.SetEventSplines(0, w_off, w_idx); sh.SetOscillationWeights(rng.random(4000).astype(float_t))
+    sh.Reweight(); sh.AddData(sh.GetMCArray())
+    def step():
+        par[:P] = rng.uniform(-2, 2, P); return sh.Step()
+    eng.timing_enable(True); us = timeit(step); k_ms,_ = eng.timing_read(0)
+    print(f"binned float_t={np.dtype(float_t).name}: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: "
+          f"step {us:.1f} us, event kernel {k_ms*1e3:.1f} us ({(w_idx.nbytes + 8*E)/k_ms/1e6:.0f} GB/s of index+bin/osc bytes)", flush=True)
+    eng.close()
+
+if only in ("all", "binned"):
+    binned_row(np.float32)
+    binned_row(np.float64)
+if only == "binned":
+    sys.exit(0)
 
 # ---- device binning + one energy-scale shift on config 2 at 1e6 events
 spec = synth.CONFIGS["c2"].scaled(1_000_000, n_params=16)

@@ -97,13 +97,16 @@ def debug_layout(n_params, max_knots, npts, ch):
                         n_bricks=nbr, bdesc=bdesc[:nbr], words=words[:nw])
 
 
-def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_frac=0.1):
+def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_frac=0.1, float_t=np.float32):
     """Synthetic BinnedSplineHandler members (ref: Splines/BinnedSplineHandler.h:116-140): one
     bin-spline per (cell, parameter); a fraction is flat (no coefficients, weight stays 1), some dip
     below zero (exercising the weight < 0 -> 0 clamp, BinnedSplineHandler.cpp:337).  Parameters have
-    different knot counts."""
+    different knot counts.  float_t = float64 gives the default (non-low-memory) build's tables, with
+    knots that are not representable in float."""
     knots = {p: np.linspace(-3, 3, [7, 5, 3][p % 3]) for p in range(n_params)}
-    xpts = np.full((n_params, max_knots), -999.0, np.float32)
+    if float_t == np.float64:
+        knots = {p: xs + 0.01 * np.sqrt(2.0) * (1 + np.arange(len(xs))) for p, xs in knots.items()}
+    xpts = np.full((n_params, max_knots), -999.0, float_t)
     npts = np.zeros(n_params, np.int16)
     for p, xs in knots.items():
         xpts[p, :len(xs)] = xs
@@ -123,14 +126,14 @@ def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_fra
                 y[rng.integers(0, len(xs))] = -0.4
             c = natural_cubic(xs, y)
             uniq.append(i)
-            xcoeff.append(np.asarray(xs, np.float32))
+            xcoeff.append(np.asarray(xs, float_t))
             many.append(c.reshape(-1))
             ci += len(xs)
     return dict(n_params=n_params, max_knots=max_knots, monolith_size=n_cells * n_params,
                 xpts=np.ascontiguousarray(xpts.reshape(-1)), npts=npts,
                 coeffindexvec=np.asarray(coeffindexvec, np.int32), uniquesplinevec=np.asarray(usv, np.int32),
                 uniquecoeffindices=np.asarray(uniq, np.int32),
-                xcoeff=np.concatenate(xcoeff).astype(np.float32), manycoeff=np.concatenate(many).astype(np.float32))
+                xcoeff=np.concatenate(xcoeff).astype(float_t), manycoeff=np.concatenate(many).astype(float_t))
 
 
 def make_binned_events(n_events, n_params, n_cells, rng):

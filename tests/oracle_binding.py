@@ -12,7 +12,8 @@ _libs = {}
 
 
 def load(variant="serial"):
-    """variant: 'serial' (bit-exact reference order) or 'omp' (timed baseline)"""
+    """variant: 'serial' (bit-exact reference order), 'omp' (timed baseline) or 'serial_f64' (M3::float_t =
+    double on the binned-spline / sample side; lib.float_t is the matching numpy dtype)"""
     if variant in _libs:
         return _libs[variant]
     path = os.path.join(ROOT, "oracle", f"libm3oracle_{variant}.so")
@@ -35,6 +36,8 @@ def load(variant="serial"):
     for n in ("m3o_monolith_total_weights", "m3o_monolith_spline_weights", "m3o_monolith_tf1_weights",
               "m3o_monolith_segments", "m3o_monolith_param_values", "m3o_monolith_curr_segment_state"):
         getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = vp
+    lib.m3o_float_t_size.argtypes = []; lib.m3o_float_t_size.restype = i32
+    lib.float_t = np.float64 if lib.m3o_float_t_size() == 8 else np.float32
     lib.m3o_binned_create.argtypes = [i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]; lib.m3o_binned_create.restype = vp
     lib.m3o_binned_destroy.argtypes = [vp]; lib.m3o_binned_destroy.restype = None
     lib.m3o_binned_set_spline_pointers.argtypes = [vp, vp]; lib.m3o_binned_set_spline_pointers.restype = None
@@ -146,6 +149,8 @@ class OracleBinned:
         self.lib = lib
         self.bs = bs
         self.P, self.M = bs["n_params"], bs["monolith_size"]
+        for k in ("xpts", "xcoeff", "manycoeff"):
+            assert bs[k].dtype == lib.float_t, (k, bs[k].dtype)
         self.h = lib.m3o_binned_create(self.P, bs["max_knots"], bs["xpts"].ctypes.data, bs["npts"].ctypes.data, self.M,
                                        bs["coeffindexvec"].ctypes.data, bs["uniquesplinevec"].ctypes.data,
                                        len(bs["uniquecoeffindices"]), bs["uniquecoeffindices"].ctypes.data,
@@ -162,7 +167,7 @@ class OracleBinned:
 
     @property
     def weights(self):
-        return _view(self.lib.m3o_binned_weights(self.h), self.M, np.float32)
+        return _view(self.lib.m3o_binned_weights(self.h), self.M, self.lib.float_t)
 
     @property
     def segments(self):
@@ -216,6 +221,7 @@ class OracleSample:
         if kin.ndim == 1:
             kin = kin.reshape(-1, 1)
         self.E = kin.shape[0]
+        assert osc_table is None or osc_table.dtype == lib.float_t
         self.keep = (binning, sample_id, kin, norm_off, norm_idx, par, osc_idx, osc_table, mono)
         self.nb = binning.n_bins()
         self.h = lib.m3o_sample_create(
@@ -260,7 +266,7 @@ class OracleSample:
         return _view(self.lib.m3o_sample_w2(self.h), self.nb, np.float64).copy()
 
     def event_weights(self):
-        out = np.empty(self.E, np.float32)
+        out = np.empty(self.E, self.lib.float_t)
         self.lib.m3o_sample_event_weights(self.h, out.ctypes.data)
         return out
 

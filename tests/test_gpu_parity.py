@@ -676,6 +676,80 @@ def test_binned_splines_match_oracle(fresh_engine):
     ob_binned.close()
 
 
+def test_binned_splines_double_build_match_oracle(fresh_engine):
+    """The reference's default build, M3::float_t = double (Manager/Core.h:27-51): bin-spline tables,
+    std::fma cubic on the parameter's own double value, float-cast value against double knots in the
+    segment search, and the sample's weight product / w*w in double.  Bin-spline weights and event
+    weights bit-exact in fp64, bins 1e-12, LLH 1e-9."""
+    from helpers import make_binned, make_binned_events
+    from mach3_amd.engine import BinnedSplineHandler
+
+    rng = np.random.default_rng(41)
+    P, cells, E, n_norm = 8, 300, 6000, 5
+    bs = make_binned(P, cells, rng, float_t=np.float64)
+    w_off, w_idx = make_binned_events(E, P, cells, rng)
+    par = np.zeros(P + n_norm)
+    par[P:] = 1.0
+    opar = par.copy()
+    edges = np.linspace(0, 5, 51)
+    kin = rng.gamma(3.0, 0.4, E)
+    sample_id = np.zeros(E, np.int32)
+    nn = rng.integers(0, 4, E)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = (P + rng.integers(0, n_norm, int(norm_off[-1]))).astype(np.int16)
+    osc_idx = rng.integers(-1, 64, E).astype(np.int32)
+    osc = rng.random(64)                       # double oscillation weights
+
+    lib = ob.load("serial_f64")
+    assert lib.float_t == np.float64
+    ob_binned = ob.OracleBinned(lib, bs)
+    ob_binned.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc, None)
+    osamp.set_binned(ob_binned, w_off, w_idx)
+    osamp.set_test_statistic(capi.kBarlowBeeston)
+
+    handler = BinnedSplineHandler(fresh_engine, E, bs)
+    assert handler.float_t == np.float64
+    handler.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 1, np.array([0, 50], np.int32), par, capi.kBarlowBeeston)
+    sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sample_id, 50), osc_idx, norm_off, norm_idx)
+    handler.SetEventSplines(0, w_off, w_idx)
+    sh.SetOscillationWeights(osc)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    clamped = differs_from_float = 0
+    knots = bs["xpts"].reshape(P, -1)
+    for lap in range(8):
+        par[:P] = rng.uniform(-3.5, 3.5, P)
+        if lap == 3:
+            par[0] = knots[0, 2]                     # a double knot: the float-cast value decides the segment
+            par[1] = float(np.float32(knots[1, 1]))  # the float image of a knot
+        par[P:] = 1 + 0.05 * rng.standard_normal(n_norm)
+        opar[:] = par
+        sh.Reweight()
+        llh = sh.GetLikelihood()
+        osamp.reweight()
+        w_gpu, w_cpu = handler.GetWeights(), ob_binned.weights
+        assert w_gpu.dtype == np.float64 and np.array_equal(w_gpu.view(np.uint64), w_cpu.view(np.uint64))
+        clamped += int((w_cpu == 0).sum())
+        differs_from_float += int((w_cpu != w_cpu.astype(np.float32)).sum())
+        seg, _ = sh.GetSegments(P)
+        assert np.array_equal(seg, ob_binned.segments)
+        ew = sh.GetEventWeights(0, E, np.float64)
+        assert np.array_equal(ew.view(np.uint64), osamp.event_weights().view(np.uint64))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    assert clamped > 0 and differs_from_float > 1000
+    osamp.close()
+    ob_binned.close()
+
+
 def test_kinematic_cuts_on_shifted_variables(fresh_engine):
     """SampleHandlerFD::IsEventSelected (ref: Samples/SampleHandlerFD.cpp:281-294): cuts lo <= x < hi on
     a binning axis and on a cut-only column, evaluated after the functional shifts."""

@@ -309,3 +309,37 @@ def test_binned_spline_kat(lib):
     b.evaluate()
     assert b.weights[0] == np.float32(0.8) and b.weights[2] == np.float32(0.5)
     b.close()
+
+
+def test_binned_spline_kat_double_build():
+    """M3::float_t = double (Manager/Core.h:27-51): the cubic runs on the parameter's own double value with
+    std::fma (BinnedSplineHandler.cpp:327-332), while FindSplineSegment casts the value to float before
+    comparing it with the double knots (Splines/SplineBase.cpp:51-54)."""
+    lib64 = ob.load("serial_f64")
+    assert lib64.float_t == np.float64
+    xs = np.array([-1.0, 0.1, 1.0])              # 0.1 is not a float: float32(0.1) = 0.100000001490116 > 0.1
+    c = natural_cubic(xs, [0.8, 1.0, 1.3]).astype(np.float64)
+    bs = dict(n_params=1, max_knots=3, monolith_size=2, xpts=xs.copy(), npts=np.array([3], np.int16),
+              coeffindexvec=np.array([0, 3], np.int32), uniquesplinevec=np.array([0, 0], np.int32),
+              uniquecoeffindices=np.array([0], np.int32), xcoeff=xs.copy(), manycoeff=c.reshape(-1).copy())
+    b = ob.OracleBinned(lib64, bs)
+    par = np.array([-0.5])
+    b.set_spline_pointers(par)
+    b.evaluate()
+    assert b.segments[0] == 0 and b.weights.dtype == np.float64 and b.weights[1] == 1.0   # entry 1 is flat
+    # a double value just BELOW the knot whose float image lies ABOVE it: the float image picks segment 1,
+    # the cubic then runs with the double's negative dx in that segment
+    par[0] = 0.0999999999
+    assert par[0] < 0.1 < float(np.float32(par[0]))
+    b.evaluate()
+    assert b.segments[0] == 1
+    y, bb, cc, dd = c[1]
+    dx = par[0] - 0.1
+    assert dx < 0 and b.weights[0] == pytest.approx(y + dx * (bb + dx * (cc + dx * dd)), rel=1e-15)
+    # the float build would have seen dx = float(par) - float(0.1) = 0 exactly here
+    par[0] = 0.5
+    b.evaluate()
+    dx = 0.5 - 0.1
+    assert b.weights[0] == pytest.approx(y + dx * (bb + dx * (cc + dx * dd)), rel=1e-15)
+    assert b.weights[0] != float(np.float32(b.weights[0]))      # a genuine double
+    b.close()
