@@ -59,48 +59,65 @@ def pmc_traffic(config_name, per_gpu):
     return best
 
 
-def cpu_baseline(spec, budget_s=12.0, sample_events=100_000):
+def cpu_baseline(spec, budget_s=10.0, sample_events=200_000):
     """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events`
-    events of the same workload; steps/s scaled to the full event count."""
+    events of the same workload; steps/s scaled to the full event count.  Timed DragRace style at
+    min(cores, 16) threads (the reference refuses more unless OMP_NUM_THREADS is exported,
+    Manager/Monitor.cpp:122-138) and, briefly, at 8 threads; phases as SURVEY section 8d asks."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from mach3_amd import synth
 
     n = min(sample_events, spec.n_events)
     lib = ob.load("omp")
-    lib.m3o_set_num_threads(min(os.cpu_count() or 1, 16))  # the reference caps at 16 (Manager/Monitor.cpp:122-138)
+    cores = os.cpu_count() or 1
+    lib.m3o_set_num_threads(min(cores, 16))
     mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp")
-    threads = lib.m3o_max_threads()
     samp.reweight()
     samp.add_data(samp.mc)
-    laps, t_spl, t_fill = 0, 0.0, 0.0
-    for lap in range(1, 4):  # warm-up
-        par[:] = synth.params(spec, lap)
-        samp.reweight()
-        samp.get_likelihood()
-    t0 = time.perf_counter()
-    while True:
-        par[:] = synth.params(spec, 100 + laps)
-        samp.reweight()
-        samp.get_likelihood()
-        a, b = samp.last_timing()
-        t_spl += a
-        t_fill += b
-        laps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or laps >= 200:
-            break
-    sps_sample = laps / el
+
+    def run(threads, budget, max_laps):
+        lib.m3o_set_num_threads(threads)
+        for lap in range(1, 3):  # warm-up
+            par[:] = synth.params(spec, lap)
+            samp.reweight()
+            samp.get_likelihood()
+        laps, t_spl, t_fill, t_llh = 0, 0.0, 0.0, 0.0
+        t0 = time.perf_counter()
+        while True:
+            par[:] = synth.params(spec, 100 + laps)
+            samp.reweight()
+            t1 = time.perf_counter()
+            samp.get_likelihood()
+            t_llh += time.perf_counter() - t1
+            a, b = samp.last_timing()
+            t_spl += a
+            t_fill += b
+            laps += 1
+            el = time.perf_counter() - t0
+            if el > budget or laps >= max_laps:
+                break
+        return {"threads": int(lib.m3o_max_threads()), "laps": laps, "seconds": el, "steps_per_s": laps / el * n / spec.n_events,
+                "ms_per_lap": 1e3 * el / laps, "spline_eval_ms": 1e3 * t_spl / laps, "fill_ms": 1e3 * t_fill / laps,
+                "llh_ms": 1e3 * t_llh / laps}
+
+    main_run = run(min(cores, 16), budget_s, 2000)
+    sweep = {str(main_run["threads"]): main_run["steps_per_s"]}
+    if cores >= 8 and main_run["threads"] != 8:
+        r8 = run(8, 0.35 * budget_s, 1000)
+        sweep["8"] = r8["steps_per_s"]
     samp.close()
     mono.close()
     return {
-        "value": sps_sample * n / spec.n_events,
+        "value": main_run["steps_per_s"],
         "unit": "steps/s",
-        "cores": int(threads),
+        "cores": main_run["threads"],
         "kind": "port",
-        "sample": f"first {n} of {spec.n_events} events, {laps} laps in {el:.1f} s "
-                  f"({1e3 * el / laps:.2f} ms/lap: spline eval {1e3 * t_spl / laps:.2f} ms, fill {1e3 * t_fill / laps:.2f} ms); "
-                  f"steps/s scaled by {n}/{spec.n_events}",
+        "sample": f"first {n} of {spec.n_events} events, {main_run['laps']} laps in {main_run['seconds']:.1f} s "
+                  f"({main_run['ms_per_lap']:.2f} ms/lap: spline eval {main_run['spline_eval_ms']:.2f} ms, fill {main_run['fill_ms']:.2f} ms, "
+                  f"LLH {main_run['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}",
+        "steps_per_s_by_threads": sweep,
+        "host_cores": cores,
     }
 
 

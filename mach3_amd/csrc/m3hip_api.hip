@@ -351,6 +351,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.bricks = h->d_bricks;
   a.ptab = h->d_ptab;
   a.pval = h->d_pval;
+  a.n_params = h->P;
   a.spline_w = h->d_spline_w;
   a.event_w = h->d_event_w;
   a.bin = h->d_bin;

@@ -56,6 +56,7 @@ struct ReweightArgs {
   const BrickDev* bricks;
   const PTab* ptab;          // [P]
   const float* pval;         // [P] ParamValues
+  int32_t n_params;          // P
   float* spline_w;           // [E_pad] monolith total weight per event (may be null)
   float* event_w;            // [E_pad] CalcWeightTotal per event (may be null)
   // fused fill

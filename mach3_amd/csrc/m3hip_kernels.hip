@@ -356,33 +356,45 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
 // staging array; phase B lets every event multiply its slice in ascending parameter order.
 // HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
 // ------------------------------------------------------------------------------------
-constexpr int kBrickThreads = 512;                               // 4 workgroups per CU (LDS: 4 x ~37 KiB)
+constexpr int kBrickThreads = 512;                               // 2 workgroups per CU (~61 KiB LDS, <= 128 VGPRs)
 constexpr int kBrickEvPerLane = M3_GROUP / kBrickThreads;         // events per lane in phase B
 constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;   // responses per lane and stage
-constexpr int kBrickBatch = 4;                                    // coefficient loads in flight per lane
 constexpr int kBrickMaxStages = 30;
+constexpr int kBrickLdsParams = 1024;                             // per-step parameter table kept in LDS up to this P
+constexpr int kBrickRunsPerLane = M3_BRICK_MAX_RUNS / kBrickThreads;
 
 struct RRun {      // per-step resolved run: address = base + r, dx of the run's parameter
   int32_t base;    // coef_off + seg * n_run - start_r   (float4 units from the brick's store)
   float dx;
 };
 
-// Latency structure: the kernel is software-pipelined over stages.  While stage s waits for its
-// coefficient loads, the independent loads of stage s+1 (event slices, response words, run
-// entries -> resolved run table in the other LDS buffer) are already in flight, so per stage only
-// ONE dependent HBM round trip (the coefficient load itself) sits on the critical path.
-template <int MODE, bool NT>
+// Latency structure.  Per stage only the coefficient loads sit on the critical path, kBrickBatch per
+// lane in flight at once (8: two round trips for a full stage).  Everything a stage
+// needs before it can issue them -- its response words, event slices and run entries -- is requested
+// right after the previous stage's loads were consumed and arrives under that stage's barrier and
+// phase B; the run entries are resolved against the per-step parameter table, which lives in LDS, so
+// no second global round trip hides in the resolution.
+template <int MODE, bool NT, int kBrickBatch>
 __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
   __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
   __shared__ uint32_t lds_hdr[1 + M3_STAGE_HDR * kBrickMaxStages];
+  __shared__ PTab lds_ptab[kBrickLdsParams];
+  __shared__ float lds_pval[kBrickLdsParams];
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
   const uint32_t* __restrict__ words = bd.words;
+  const bool tab_in_lds = a.n_params <= kBrickLdsParams;  // kernel-uniform
 
-  // all stage headers in one round trip
+  // all stage headers and the per-step parameter table in one round trip
   if (lane < 1 + M3_STAGE_HDR * kBrickMaxStages) lds_hdr[lane] = words[lane < bd.n_hdr_words ? lane : 0];
+  if (tab_in_lds) {
+    for (int p = lane; p < a.n_params; p += kBrickThreads) {
+      lds_ptab[p] = a.ptab[p];
+      lds_pval[p] = a.pval[p];
+    }
+  }
   if (MODE & kModeFill) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
@@ -394,31 +406,53 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
   for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
 
   const uint32_t n_stages = lds_hdr[0];
-  // what a stage needs before its coefficient loads can be issued
+  // what the NEXT stage needs before its coefficient loads can be issued
   uint32_t ec_n[kBrickEvPerLane];
-  uint32_t m_n[kBrickRespPerLane];
+  uint32_t m_n[kBrickRespPerLane];   // kind 0: {run:16 | dst:16} words, kind 1: the TF1's parameter
+  uint4 rt_n[kBrickRunsPerLane];     // kind 0: raw run entries {coef_off, n_run, start_r, param}
 
-  auto prefetch = [&](uint32_t s) {
+  auto prefetch_issue = [&](uint32_t s) {  // global loads only: nothing here waits
     const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
-    const uint32_t kind = h[0], n_resp = h[1];
+    const uint32_t kind = h[0], n_resp = h[1], last = n_resp - 1;
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
       const uint32_t e = lane * kBrickEvPerLane + q;
-      ec_n[q] = e < bd.n_events ? words[h[5] + e] : 0u;
+      ec_n[q] = words[h[5] + (e < bd.n_events ? e : 0u)];
     }
     if (kind == 0) {
       const uint32_t* __restrict__ resp = words + h[4];
 #pragma unroll
       for (int u = 0; u < kBrickRespPerLane; ++u) {
         const uint32_t r = lane + u * kBrickThreads;
-        m_n[u] = r < n_resp ? resp[r] : 0u;
+        m_n[u] = resp[r < n_resp ? r : last];
       }
-      RRun* runs_s = lds_runs[s & 1];
       const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
       const uint32_t n_runs = h[2];
-      for (uint32_t r = lane; r < n_runs; r += kBrickThreads) {  // resolve the stage's runs for this step
-        const uint4 rt = runs[r];  // {coef_off, n_run, start_r, param}
-        const PTab pt = a.ptab[rt.w];
+#pragma unroll
+      for (int u = 0; u < kBrickRunsPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        rt_n[u] = runs[r < n_runs ? r : n_runs - 1];
+      }
+    } else {
+      const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
+#pragma unroll
+      for (int u = 0; u < kBrickRespPerLane; ++u) {
+        const uint32_t r = lane + u * kBrickThreads;
+        m_n[u] = par[r < n_resp ? r : last];
+      }
+    }
+  };
+  auto prefetch_commit = [&](uint32_t s) {  // resolve the stage's runs for this step into its LDS table
+    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
+    if (h[0] != 0) return;
+    const uint32_t n_runs = h[2];
+    RRun* runs_s = lds_runs[s & 1];
+#pragma unroll
+    for (int u = 0; u < kBrickRunsPerLane; ++u) {
+      const uint32_t r = lane + u * kBrickThreads;
+      if (r < n_runs) {
+        const uint4 rt = rt_n[u];
+        const PTab pt = tab_in_lds ? lds_ptab[rt.w] : a.ptab[rt.w];
         RRun rr;
         rr.base = (int32_t)(rt.x + (uint32_t)pt.seg * rt.y) - (int32_t)rt.z;
         rr.dx = pt.dx;
@@ -427,7 +461,10 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
     }
   };
 
-  if (n_stages > 0) prefetch(0);
+  if (n_stages > 0) {
+    prefetch_issue(0);
+    prefetch_commit(0);
+  }
   for (uint32_t s = 0; s < n_stages; ++s) {
     const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
     const uint32_t kind = h[0], n_resp = h[1];
@@ -454,7 +491,6 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
             c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(r < n_resp ? rr.base + (int32_t)r : rr.base)]);
             dx[u] = rr.dx;
           }
-          if (b0 == 0 && s + 1 < n_stages) prefetch(s + 1);  // rides under the coefficient loads
 #pragma unroll
           for (int u = 0; u < kBrickBatch; ++u) {
             const uint32_t r = lane + (b0 + u) * kBrickThreads;
@@ -463,36 +499,44 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
         }
       }
     } else {
-      const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
       const float2* __restrict__ tp = bd.tf1 + h[6];
+      const uint32_t last = n_resp - 1;
 #pragma unroll
-      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += 8) {
+      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += kBrickBatch) {
         if ((uint32_t)(b0 * kBrickThreads) < n_resp) {
-          float2 c[8];
-          uint32_t p[8];
+          float2 c[kBrickBatch];
+          float x[kBrickBatch];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < kBrickBatch; ++u) {
             const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            const uint32_t rr = r < n_resp ? r : 0u;
-            p[u] = par[rr];
-            c[u] = stream_load<NT>(&tp[rr]);
+            c[u] = stream_load<NT>(&tp[r < n_resp ? r : last]);
+            x[u] = tab_in_lds ? lds_pval[m[b0 + u]] : a.pval[m[b0 + u]];
           }
-          if (b0 == 0 && s + 1 < n_stages) prefetch(s + 1);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < kBrickBatch; ++u) {
             const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            if (r < n_resp) stage_w[r] = fmaf(c[u].x, a.pval[p[u]], c[u].y);  // SplineMonolith.cpp:779
+            if (r < n_resp) stage_w[r] = fmaf(c[u].x, x[u], c[u].y);  // SplineMonolith.cpp:779
           }
         }
       }
     }
+    if (s + 1 < n_stages) prefetch_issue(s + 1);  // in flight during the barrier and phase B
     __syncthreads();
     // phase B: the event's slice of the staging array, ascending parameter = reference order
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
       const uint32_t start = ec[q] & 0xFFFFu, cnt = ec[q] >> 16;
-      for (uint32_t i = 0; i < cnt; ++i) w[q] *= stage_w[start + i];
+      uint32_t i = 0;
+      for (; i + 4 <= cnt; i += 4) {  // four LDS reads in flight; the product itself stays sequential
+        const float v0 = stage_w[start + i], v1 = stage_w[start + i + 1], v2 = stage_w[start + i + 2], v3 = stage_w[start + i + 3];
+        w[q] *= v0;
+        w[q] *= v1;
+        w[q] *= v2;
+        w[q] *= v3;
+      }
+      for (; i < cnt; ++i) w[q] *= stage_w[start + i];
     }
+    if (s + 1 < n_stages) prefetch_commit(s + 1);
   }
   __syncthreads();  // last phase B / lds_hist zeroing complete
 
@@ -531,13 +575,15 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
 
 template <int MODE>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true>), g, dim3(kBrickThreads), lds, s, a);
-  else hipLaunchKernelGGL((k_reweight_brick<MODE, false>), g, dim3(kBrickThreads), lds, s, a);
+  // 8 coefficient loads per lane in flight (two round trips per stage); 16 would need > 128 VGPRs and spills
+  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true, 8>), g, dim3(kBrickThreads), lds, s, a);
+  else hipLaunchKernelGGL((k_reweight_brick<MODE, false, 8>), g, dim3(kBrickThreads), lds, s, a);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {
   if (n_bricks == 0) return;
-  const size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
   if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
