@@ -48,7 +48,7 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 //   [0]                      n_stages
 //   [1 + 8*s .. 8 + 8*s]     stage header: kind (0 TSpline3, 1 TF1), n_resp, n_runs, off_runs,
 //                            off_resp, off_evt, coef_off, 0
-//   off_runs  (TSpline3)     n_runs x {coef_off (float4 from the brick's spline store), n_run,
+//   off_runs  (TSpline3)     n_runs x {coef_off (float4 from the brick's spline store), plane stride (n_run rounded up to 8 float4 = 128 B),
 //                            start_r (first response of the run in the stage), param}
 //   off_resp  TSpline3: n_resp words {run : 16 | dst << 16}; TF1: n_resp parameters packed two
 //             per word (low half first)
@@ -152,8 +152,11 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
       if (a == b) continue;
       const uint32_t n_run = b - a, nseg = uint32_t(npts[p] - 1);
       if (n_runs >= 65536u) { *err = "brick: more than 65536 runs in a stage"; return false; }
+      // every segment plane of a run starts on a 128-byte line: a step reads ONE plane per run, so an
+      // unaligned plane would drag in the neighbouring planes' lines at both ends
+      const uint32_t stride = (n_run + 7u) & ~7u;
       runs.push_back(uint32_t(spl_f4));
-      runs.push_back(n_run);
+      runs.push_back(stride);
       runs.push_back(a - r0);
       runs.push_back(uint32_t(p));
       for (uint32_t r = a; r < b; ++r) {
@@ -161,7 +164,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
         resp[r - r0] = (n_runs & 0xFFFFu) | (dst << 16);
         bh->spl_src.push_back(inv_s[r]);
       }
-      spl_f4 += uint64_t(n_run) * nseg;
+      spl_f4 += uint64_t(stride) * nseg;
       ++n_runs;
     }
     uint32_t* h = &w[1 + size_t(M3_STAGE_HDR) * stage];
@@ -228,11 +231,12 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
     if (h[0] != 0) continue;
     const uint32_t* runs = words + h[3];
     for (uint32_t r = 0; r < h[2]; ++r) {
-      const uint32_t coef_off = runs[4 * r], n_run = runs[4 * r + 1], p = runs[4 * r + 3];
+      const uint32_t coef_off = runs[4 * r], stride = runs[4 * r + 1], p = runs[4 * r + 3];
+      const uint32_t n_run = (r + 1 < h[2] ? runs[4 * (r + 1) + 2] : h[1]) - runs[4 * r + 2];  // responses of the run
       const uint32_t nseg = uint32_t(npts[p] - 1);
       for (uint32_t q = 0; q < n_run; ++q) {
         const float* src = in.coeff_many + 4ull * in.nknots_arr[bh.spl_src[src_i++]];
-        for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (uint64_t(coef_off) + uint64_t(k) * n_run + q) * 4, src + 4 * k, 16);
+        for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (uint64_t(coef_off) + uint64_t(k) * stride + q) * 4, src + 4 * k, 16);
       }
     }
   }

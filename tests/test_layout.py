@@ -117,11 +117,13 @@ def brick_event_lists(npts, ch, lay, b):
             resp = w[int(h[4]): int(h[4]) + n_resp]
             for r in range(n_resp):
                 run, dst = int(resp[r]) & 0xFFFF, int(resp[r]) >> 16
-                coef_off, n_run, start_r, p = [int(v) for v in runs[run]]
+                coef_off, stride, start_r, p = [int(v) for v in runs[run]]
+                n_run = (int(runs[run + 1][2]) if run + 1 < n_runs else n_resp) - start_r
+                assert stride % 8 == 0 and coef_off % 8 == 0 and n_run <= stride < n_run + 8
                 q = r - start_r
                 assert 0 <= q < n_run
                 nseg = int(npts[p]) - 1
-                quads = np.stack([spl[spl_off + coef_off + k * n_run + q] for k in range(nseg)])
+                quads = np.stack([spl[spl_off + coef_off + k * stride + q] for k in range(nseg)])
                 assert stage[dst] is None
                 stage[dst] = (p, "spl", quads)
         else:
