@@ -378,6 +378,86 @@ def test_ragged_bricks_match_oracle(fresh_engine, cfg, n_events, n_params):
     omono.close()
 
 
+def _ragged_events(rng, E, P, occ, xs, empty_frac=0.0, tf1_only_frac=0.0):
+    events = []
+    for _ in range(E):
+        u = rng.random()
+        ev = []
+        if u >= empty_frac:
+            for p in range(P):
+                if rng.random() < occ:
+                    if p in xs and u >= empty_frac + tf1_only_frac:
+                        ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))))
+                    elif p not in xs:
+                        ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
+        events.append(ev)
+    return events
+
+
+def _eval_matches(engine, P, K, cx, npts, ch, rng, laps=3):
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, K, cx, npts, ch)
+    par, opar = np.zeros(P), np.zeros(P)
+    omono.set_spline_pointers(opar)
+    mono = SMonolith(engine, P, K, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    for _ in range(laps):
+        par[:] = rng.uniform(-3.5, 3.5, P)
+        opar[:] = par
+        mono.Evaluate()
+        mono.SynchroniseMemTransfer()
+        omono.evaluate()
+        assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+    info = engine.info()
+    omono.close()
+    return info
+
+
+@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick"])
+def test_extreme_shapes(fresh_engine, case):
+    """Edges of the layout: a single event; ragged groups in which a third of the events carry no response
+    at all (weight stays 1, SplineMonolith.cpp:798) and some carry TF1s only; a brick with ~190k responses
+    in its 1024 events (24+ stages, close to the 30-stage limit)."""
+    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3}[case])
+    X7, X5, X3 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2]), np.array([-1.0, 0, 1])
+    if case == "one_event":
+        xs = {0: X7}
+        cx, npts, ch = make_monolith(1, 7, xs, [[(0, "spl", natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7)))]])
+        info = _eval_matches(fresh_engine, 1, 7, cx, npts, ch, rng, laps=5)
+        assert info.n_tiles_uniform == 1 and info.n_tiles_brick == 0
+    elif case == "holes":
+        P = 40
+        xs = {p: (X7, X5, X3)[p % 3] for p in range(0, P, 2)}   # even parameters are TSpline3, odd are TF1
+        events = _ragged_events(rng, 2500, P, 0.3, xs, empty_frac=0.33, tf1_only_frac=0.1)
+        assert sum(1 for e in events if not e) > 700
+        cx, npts, ch = make_monolith(P, 7, xs, events)
+        info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng)
+        assert info.n_tiles_brick == 3
+    else:
+        P = 230
+        xs = {p: (X7, X5)[p % 2] for p in range(P) if p % 3 != 2}   # two thirds TSpline3, one third TF1
+        events = _ragged_events(rng, 1024, P, 0.8, xs)
+        n_resp = sum(len(e) for e in events)
+        assert 180_000 < n_resp < 200_000
+        cx, npts, ch = make_monolith(P, 7, xs, events)
+        info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng, laps=2)
+        assert info.n_tiles_brick == 1
+
+
+def test_brick_stage_limit_is_reported(fresh_engine):
+    """more responses in a 1024-event group than 30 stages hold: the upload is refused with a message,
+    nothing is silently truncated"""
+    rng = np.random.default_rng(9)
+    P = 330
+    X3 = np.array([-1.0, 0, 1])
+    xs = {p: X3 for p in range(P)}
+    events = _ragged_events(rng, 1024, P, 0.85, xs)
+    assert sum(len(e) for e in events) > 260_000
+    cx, npts, ch = make_monolith(P, 3, xs, events)
+    with pytest.raises(capi.M3HipError, match="stages"):
+        SMonolith(fresh_engine, P, 3, cx, npts, [ch])
+
+
 def test_uniform_and_ragged_groups_in_one_sample(fresh_engine):
     """1024 dense events followed by ragged ones, plus events without any response."""
     P = 12

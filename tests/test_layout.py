@@ -205,3 +205,15 @@ def test_ragged_requires_ascending_parameters():
     cx, npts, ch = make_monolith(2, 7, {0: X7, 1: X7}, events)
     rc, err, _ = debug_layout(2, 7, npts, ch)
     assert rc != 0 and "ascending" in err
+
+
+def test_brick_stage_limit_is_reported():
+    """more responses in a 1024-event group than 30 stages of 8192 hold: refused with a message"""
+    rng = np.random.default_rng(9)
+    P, X3 = 330, np.array([-1.0, 0, 1])
+    c = natural_cubic(X3, [0.9, 1.0, 1.2])
+    events = [[(p, "spl", c) for p in range(P) if rng.random() < 0.85] for _ in range(1024)]
+    assert sum(len(e) for e in events) > 260_000
+    cx, npts, ch = make_monolith(P, 3, {p: X3 for p in range(P)}, events)
+    rc, err, _ = debug_layout(P, 3, npts, ch)
+    assert rc != 0 and "stages" in err
