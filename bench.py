@@ -59,6 +59,9 @@ def pmc_traffic(config_name, per_gpu):
     return best
 
 
+EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "4"))
+
+
 def cpu_baseline(spec, budget_s=10.0, sample_events=200_000):
     """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events`
     events of the same workload; steps/s scaled to the full event count.  Timed DragRace style at
@@ -233,7 +236,7 @@ def main():
         n_spin += 1
     for i in range(args.warmup):
         step(i)
-    eng.timing_enable(True)
+    eng.timing_enable(EVENT_EVERY)  # hipEvents around every EVENT_EVERY-th launch of the timed region
     eng.timing_reset()
     if dist is not None:
         dist.barrier()
@@ -291,6 +294,7 @@ def main():
                 "alg_bytes_per_launch": int(info.alg_bytes_fused),
                 "avg_kernel_ms": k_ms,
                 "launches_timed": int(k_n),
+                "event_sampling": f"every {EVENT_EVERY}th launch of the timed region carries a hipEvent pair stamped with the dispatch's own start/end (hipExtLaunchKernelGGL)",
             },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -85,7 +85,7 @@ def load_m3hip():
     global _hip
     if _hip is not None:
         return _hip
-    path = lib_path("libm3hip.so")
+    path = os.environ.get("M3HIP_LIB") or lib_path("libm3hip.so")  # M3HIP_LIB: A/B runs of two builds (scripts/ab_step.py)
     if not os.path.exists(path):
         raise M3HipError(-2, f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
                              "this engine has no CPU fallback")

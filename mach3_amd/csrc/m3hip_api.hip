@@ -171,6 +171,7 @@ struct m3hip_ctx {
   int hist_rep = 32;
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
+  bool w2_spread = false;  // w2 currently lives spread over the flush replicas (not yet folded into replica 0)
   double* h_out = nullptr;  // pinned, device-mapped: [1 + n_samples], then one uint64 ticket word
   double* d_out = nullptr;
   bool want_event_w = false;
@@ -180,7 +181,8 @@ struct m3hip_ctx {
   int rank = 0, n_ranks = 1;
 
   // timing
-  bool timing = false;
+  int timing = 0;           // 0: off, N: bracket every N-th launch with hipEvents
+  uint64_t timing_ctr = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int pending = -1;
   double acc_ms[2] = {0, 0};
@@ -749,6 +751,7 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   h->n_bins = nb;
   h->n_samples = n_samples;
   h->first_w2 = true;
+  h->w2_spread = false;
   return M3HIP_OK;
 }
 
@@ -1336,6 +1339,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   const double t_c = now_s();
 
   ReweightArgs a = make_rw_args(h);
+  if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;
   if (h->want_event_w) {
     if (!h->d_event_w) {
@@ -1348,23 +1352,30 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     }
     mode |= kModeEventW | kModeEval;
   }
-  if (h->timing) HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  // sampled launches carry two events that receive the dispatch's own start / end timestamps
+  const bool timed = h->timing > 0 && (h->timing_ctr++ % uint64_t(h->timing)) == 0;
+  const uint32_t n_tiles = uint32_t(h->h_tiles.size()), n_bricks = uint32_t(h->h_bricks.size());
+  ReweightKnobs ku = h->knobs, kb = h->knobs;  // with both kinds of tile: start on the first launch, stop on the second
+  if (timed) {
+    ku.ev_start = n_tiles ? h->ev0 : nullptr;
+    ku.ev_stop = (n_tiles && !n_bricks) ? h->ev1 : nullptr;
+    kb.ev_start = n_tiles ? nullptr : h->ev0;
+    kb.ev_stop = n_bricks ? h->ev1 : nullptr;
+  }
   if (h->f64) {
-    if (!h->h_bricks.empty()) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
-    launch_reweight_uniform_f64(a, uint32_t(h->h_tiles.size()), mode, h->stream);
+    if (n_bricks) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
+    launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
-    launch_reweight_uniform(a, uint32_t(h->h_tiles.size()), mode, h->knobs, h->stream);
-    launch_reweight_brick(a, uint32_t(h->h_bricks.size()), mode, h->knobs, h->stream);
+    launch_reweight_uniform(a, n_tiles, mode, ku, h->stream);
+    launch_reweight_brick(a, n_bricks, mode, kb, h->stream);
   }
-  if (h->timing) {
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    h->pending = 0;
-  }
+  if (timed && (n_tiles || n_bricks)) h->pending = 0;
   HIPCHK(h, hipGetLastError());
   if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
     // fold the 32 flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins), and w2
     // only travels while it is still being accumulated
     launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, h->first_w2 ? 1 : 0, h->stream);
+    if (h->first_w2) h->w2_spread = false;
     int r = g_rccl.AllReduce(h->d_hist, h->d_hist, size_t(h->n_bins), /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (r == 0 && h->first_w2) {
       double* w2 = h->d_hist + size_t(h->hist_rep) * h->n_bins;
@@ -1392,6 +1403,8 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.n_samples = h->n_samples;
   l.sample_off = h->d_sample_off;
   l.kind = h->teststat;
+  // W2 that was frozen by the last reweight is folded in place once; while UpdateW2 keeps accumulating it is summed on the fly
+  l.w2_mode = !h->w2_spread ? kW2Replica0 : (h->update_w2 ? kW2Fold : kW2FoldInPlace);
   l.out = h->d_out;
   // completion is signalled through host memory: k_llh writes the results, then this ticket
   volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(h->h_out + 1 + h->n_samples);
@@ -1400,6 +1413,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.dbg_clock = h->d_dbg_clock;
   const double t_a = now_s();
   launch_llh(l, h->stream);
+  if (l.w2_mode == kW2FoldInPlace) h->w2_spread = false;
   HIPCHK(h, hipGetLastError());
   const double t_b = now_s();
   {
@@ -1600,6 +1614,7 @@ int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int
   HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * n_bins * 2 * h->hist_rep));
   HIPCHK(h, hipMemcpy(h->d_hist, mc, sizeof(double) * n_bins, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_hist + size_t(h->hist_rep) * n_bins, w2, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+  h->w2_spread = false;
   return M3HIP_OK;
 }
 
@@ -1673,7 +1688,8 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
 
 int m3hip_timing_enable(m3hip_handle h, int enable) {
   if (!h) return M3HIP_EINVAL;
-  h->timing = enable != 0;
+  h->timing = enable > 0 ? enable : 0;
+  h->timing_ctr = 0;
   return M3HIP_OK;
 }
 

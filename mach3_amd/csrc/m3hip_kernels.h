@@ -187,6 +187,7 @@ struct BinnedArgs {
 };
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s);
 
+enum LlhW2Mode : int { kW2Replica0 = 0, kW2Fold = 1, kW2FoldInPlace = 2 };
 struct LlhArgs {
   const double* data;
   const double* hist;  // [2][hist_rep][n_bins]
@@ -195,6 +196,8 @@ struct LlhArgs {
   int32_t n_samples;
   const int32_t* sample_off;  // [n_samples + 1]
   int32_t kind;
+  int32_t w2_mode;  // kW2Replica0: w2 sits folded in replica 0; kW2Fold: sum the replicas (read only);
+                    // kW2FoldInPlace: sum them, store the sum in replica 0 and clear the others (at the freeze)
   double* out;  // [1 + n_samples] (device pointer, may be mapped pinned host memory)
   uint64_t* dbg_clock;           // optional: [1] <- wall_clock64() at k_llh end
   volatile uint64_t* done_flag;  // mapped pinned host word; set to `ticket` after `out` is written
@@ -208,11 +211,14 @@ struct ReweightKnobs {
   int unroll = 8;   // loads kept in flight per lane: 8 or 16
   int nt = 1;       // 1: non-temporal coefficient loads (+5% on C2: planes are read once per launch)
   int lds_pad = 0;  // > 0: dynamic LDS bytes per workgroup, to cap workgroups per CU
+  // optional: events that receive the dispatch's own start / end timestamps (hipExtLaunchKernelGGL) --
+  // the same clock readings a profiler reports, without extra packets on the stream
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 // float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
-void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s);
+void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);

@@ -14,6 +14,8 @@
 // bit-identical to a serial CPU evaluation in the reference's operation order.
 #include "m3hip_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace m3hip {
@@ -21,6 +23,9 @@ namespace m3hip {
 // ------------------------------------------------------------------------------------
 // k_prep: one workgroup.  Parameter-only work of a step.
 // ------------------------------------------------------------------------------------
+// (A one-pass 1024-lane variant with the proposal and the knots staged through LDS / registers was
+// measured 3.5 us SLOWER per step than this arrangement in an A/B on one box -- scripts/ab_step.py -- although
+// it has fewer dependent round trips on paper; the simple version stays.)
 __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   const int tid = threadIdx.x;
   if (a.dbg_clock && tid == 0) a.dbg_clock[0] = wall_clock64();
@@ -316,15 +321,22 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   }
 }
 
+// plain launch, or -- when the caller wants the dispatch timed -- the extended launch that stamps two events
+#define M3_LAUNCH(kernel, g, b, lds, s, k, a)                                                                   \
+  do {                                                                                                          \
+    if ((k).ev_start || (k).ev_stop) hipExtLaunchKernelGGL((kernel), g, b, (uint32_t)(lds), s, (k).ev_start, (k).ev_stop, 0, a); \
+    else hipLaunchKernelGGL((kernel), g, b, lds, s, a);                                                          \
+  } while (0)
+
 template <int MODE>
 static void launch_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
   const dim3 b(256);
   if (k.unroll >= 16) {
-    if (k.nt) hipLaunchKernelGGL((k_reweight_uniform<MODE, 16, true>), g, b, lds, s, a);
-    else hipLaunchKernelGGL((k_reweight_uniform<MODE, 16, false>), g, b, lds, s, a);
+    if (k.nt) M3_LAUNCH((k_reweight_uniform<MODE, 16, true>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_uniform<MODE, 16, false>), g, b, lds, s, k, a);
   } else {
-    if (k.nt) hipLaunchKernelGGL((k_reweight_uniform<MODE, 8, true>), g, b, lds, s, a);
-    else hipLaunchKernelGGL((k_reweight_uniform<MODE, 8, false>), g, b, lds, s, a);
+    if (k.nt) M3_LAUNCH((k_reweight_uniform<MODE, 8, true>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_uniform<MODE, 8, false>), g, b, lds, s, k, a);
   }
 }
 
@@ -339,12 +351,12 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 }
 
 
-void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, hipStream_t s) {
+void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s) {
   if (n_tiles == 0) return;
   const size_t lds = sizeof(double) * 2 * (size_t)a.n_bins;
   const dim3 g(n_tiles), b(256);
-  if (mode == kModeFill) hipLaunchKernelGGL((k_reweight_uniform<kModeFill, 8, true, true>), g, b, lds, s, a);
-  else hipLaunchKernelGGL((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, true>), g, b, lds, s, a);
+  if (mode == kModeFill) M3_LAUNCH((k_reweight_uniform<kModeFill, 8, true, true>), g, b, lds, s, k, a);
+  else M3_LAUNCH((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, true>), g, b, lds, s, k, a);
 }
 
 // ------------------------------------------------------------------------------------
@@ -576,8 +588,8 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
 template <int MODE>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
   // 8 coefficient loads per lane in flight (two round trips per stage); 16 would need > 128 VGPRs and spills
-  if (k.nt) hipLaunchKernelGGL((k_reweight_brick<MODE, true, 8>), g, dim3(kBrickThreads), lds, s, a);
-  else hipLaunchKernelGGL((k_reweight_brick<MODE, false, 8>), g, dim3(kBrickThreads), lds, s, a);
+  if (k.nt) M3_LAUNCH((k_reweight_brick<MODE, true, 8>), g, dim3(kBrickThreads), lds, s, k, a);
+  else M3_LAUNCH((k_reweight_brick<MODE, false, 8>), g, dim3(kBrickThreads), lds, s, k, a);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {
@@ -858,49 +870,49 @@ void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipSt
   hipLaunchKernelGGL(k_fold_hist, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins, with_w2);
 }
 
+// sum of one bin over the flush replicas, in replica order (fixed => reproducible), 16 loads in flight
+__device__ __forceinline__ double fold_replicas(const double* base, int hist_rep, int n_bins) {
+  double m = 0.0;
+  for (int r0 = 0; r0 < hist_rep; r0 += 16) {
+    double am[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) m += am[u];
+  }
+  return m;
+}
+
 __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   __shared__ double scratch[4];
-  // fold the flush replicas (fixed order) into the first one; afterwards mc / w2 are plain vectors
-  double* mc = const_cast<double*>(a.hist);
+  const double* mc = a.hist;
   double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
-  for (int i = threadIdx.x; i < a.n_bins; i += 256) {
-    // replica order is fixed (0, 1, 2, ...); loads are issued eight at a time so the fold costs
-    // a few memory round trips, not hist_rep of them
-    double m = 0.0, v = 0.0;
-    for (int r0 = 0; r0 < a.hist_rep; r0 += 8) {
-      double am[8], av[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool ok = r0 + u < a.hist_rep;
-        am[u] = ok ? mc[(r0 + u) * a.n_bins + i] : 0.0;
-        av[u] = ok ? w2[(r0 + u) * a.n_bins + i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        m += am[u];
-        v += av[u];
-      }
-    }
-    if (a.hist_rep > 1) {
-      mc[i] = m;
-      w2[i] = v;
-      for (int r = 1; r < a.hist_rep; ++r) mc[r * a.n_bins + i] = w2[r * a.n_bins + i] = 0.0;
-    }
-  }
-  __syncthreads();
-  // GetLikelihood(): all global bins (SampleHandlerFD.cpp:1284-1300)
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < a.n_bins; i += 256) acc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
-  const double total = block_sum_256(acc, scratch);
-  if (threadIdx.x == 0) a.out[0] = total;
-  // GetSampleLikelihood(s): bins [start, end) of each sample (:1262-1281)
+  // GetLikelihood() = sum over samples of GetSampleLikelihood(s) = sum over the sample's bins of
+  // GetTestStatLLH (SampleHandlerFD.cpp:1262-1300).  The bin vectors are read straight from the flush
+  // replicas: nothing is written back, so the call can be repeated.
+  double total = 0.0;
   for (int s = 0; s < a.n_samples; ++s) {
     const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
     double sacc = 0.0;
-    for (int i = b0 + threadIdx.x; i < b1; i += 256) sacc += d_test_stat_llh(a.kind, a.data[i], mc[i], w2[i]);
+    for (int i = b0 + threadIdx.x; i < b1; i += 256) {
+      const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
+      double v;
+      if (a.w2_mode == kW2Replica0) {
+        v = w2[i];
+      } else {
+        v = fold_replicas(w2 + i, a.hist_rep, a.n_bins);
+        if (a.w2_mode == kW2FoldInPlace) {  // W2 was frozen by this reweight: keep it as one plain vector
+          w2[i] = v;
+          for (int r = 1; r < a.hist_rep; ++r) w2[(size_t)r * a.n_bins + i] = 0.0;
+        }
+      }
+      sacc += d_test_stat_llh(a.kind, a.data[i], m, v);
+    }
     const double st = block_sum_256(sacc, scratch);
     if (threadIdx.x == 0) a.out[1 + s] = st;
+    total += st;
   }
+  if (threadIdx.x == 0) a.out[0] = total;
   // publish: results first, then the ticket the host is spinning on (system scope: host memory)
   if (threadIdx.x == 0 && a.dbg_clock) a.dbg_clock[1] = wall_clock64();
   if (threadIdx.x == 0 && a.done_flag) {

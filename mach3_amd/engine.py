@@ -266,6 +266,7 @@ class SampleHandlerFD:
         self.sample_bin_offset = off
         self.nBins = int(off[-1])
         self.par = par_vector  # plays _fPropVal; read at Reweight() time
+        self._step_cache = None
         self.SetTestStatistic(test_statistic, update_w2)
 
     def GetName(self):
@@ -341,10 +342,16 @@ class SampleHandlerFD:
 
     def Step(self) -> float:
         """Reweight() + GetLikelihood(): one proposal's sample part (ref: Fitters/MR2T2.cpp:66-76)."""
-        p = np.ascontiguousarray(self.par, np.float64)
-        tot = C.c_double(0)
-        self.eng._chk(self.eng.lib.m3hip_step(self.eng.h, _ptr(p, np.float64), len(p), C.byref(tot), None))
-        return tot.value
+        p = self.par
+        c = self._step_cache
+        if c is None or c[0] is not p:  # the pointer of the caller's parameter array is looked up once
+            assert isinstance(p, np.ndarray) and p.dtype == np.float64 and p.flags["C_CONTIGUOUS"]
+            tot = C.c_double(0)
+            c = self._step_cache = (p, _ptr(p, np.float64), len(p), tot, C.byref(tot))
+        rc = self.eng.lib.m3hip_step(self.eng.h, c[1], c[2], c[4], None)
+        if rc:
+            self.eng._chk(rc)
+        return c[3].value
 
     def _bins(self):
         mc = np.empty(self.nBins, np.float64)
