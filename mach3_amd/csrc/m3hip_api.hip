@@ -119,6 +119,10 @@ struct m3hip_ctx {
   float* d_event_w = nullptr;
   float* d_osc_table = nullptr;
   uint64_t n_osc = 0;
+  bool osc_valid_f32 = false, osc_valid_f64 = false;  // which precision of the table is current on the device
+  void* h_osc_stage[2] = {nullptr, nullptr};           // pinned staging of the per-step table upload
+  uint64_t osc_stage_ticket[2] = {0, 0};
+  int osc_stage_pos = 0;
 
   // binned spline handler (optional)
   int b_M = 0, b_U = 0, b_C = 0;
@@ -419,6 +423,8 @@ int m3hip_destroy(m3hip_handle h) {
   dev_free(h->d_params);
   dev_free(h->d_osc_table);
   dev_free(h->d_osc_table_d);
+  for (int i = 0; i < 2; ++i)
+    if (h->h_osc_stage[i]) (void)hipHostFree(h->h_osc_stage[i]);
   dev_free(h->d_bin_samples);
   dev_free(h->d_bin_axes);
   dev_free(h->d_edges);
@@ -1203,26 +1209,47 @@ static int osc_table_resize(m3hip_handle h, uint64_t n) {
   dev_free(h->d_osc_table_d);
   h->d_osc_table = nullptr;
   h->d_osc_table_d = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    if (h->h_osc_stage[i]) (void)hipHostFree(h->h_osc_stage[i]);
+    h->h_osc_stage[i] = nullptr;
+    h->osc_stage_ticket[i] = 0;
+  }
   h->n_osc = 0;
+  h->osc_valid_f32 = h->osc_valid_f64 = false;
   int rc;
   if ((rc = dev_alloc(h, &h->d_osc_table, size_t(n)))) return rc;
   if ((rc = dev_alloc(h, &h->d_osc_table_d, size_t(n)))) return rc;
+  for (int i = 0; i < 2; ++i) HIPCHK(h, hipHostMalloc(&h->h_osc_stage[i], sizeof(double) * n, hipHostMallocDefault));
   h->n_osc = n;
   return M3HIP_OK;
 }
 
-// both precisions of the table are kept: the float -> double widening is exact, the narrowing is what a
-// float_t = float build would have stored
+// Per-step upload (OscillationHandler::Evaluate runs inside every Reweight, SampleHandlerFD.cpp:319-324): the
+// table is copied into a pinned staging slot and goes to the device with an asynchronous copy on the engine's
+// stream, no synchronisation.  Only the precision handed over is uploaded; the other one is derived on the
+// device when a reweight needs it.
+static int osc_upload(m3hip_handle h, const void* table, uint64_t n, size_t elem, void* dst) {
+  const int slot = h->osc_stage_pos;
+  h->osc_stage_pos ^= 1;
+  if (h->osc_stage_ticket[slot] > h->ticket_done) {  // the copy that last used this slot may still be in flight
+    HIPCHK(h, wait_stream(h->stream));
+    h->ticket_done = h->ticket;
+  }
+  memcpy(h->h_osc_stage[slot], table, elem * n);
+  HIPCHK(h, hipMemcpyAsync(dst, h->h_osc_stage[slot], elem * n, hipMemcpyHostToDevice, h->stream));
+  h->osc_stage_ticket[slot] = h->ticket + 1;  // completes no later than the next step's kernels
+  return M3HIP_OK;
+}
+
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
   if (!h) return M3HIP_EINVAL;
   if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table: empty table");
   HIPCHK(h, hipSetDevice(h->device));
   int rc = osc_table_resize(h, n);
   if (rc) return rc;
-  std::vector<double> wide(table, table + n);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(h->d_osc_table, table, sizeof(float) * n, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_osc_table_d, wide.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  if ((rc = osc_upload(h, table, n, sizeof(float), h->d_osc_table))) return rc;
+  h->osc_valid_f32 = true;
+  h->osc_valid_f64 = false;
   return M3HIP_OK;
 }
 
@@ -1232,11 +1259,9 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = osc_table_resize(h, n);
   if (rc) return rc;
-  std::vector<float> narrow(n);
-  for (uint64_t i = 0; i < n; ++i) narrow[i] = float(table[i]);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(h->d_osc_table, narrow.data(), sizeof(float) * n, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_osc_table_d, table, sizeof(double) * n, hipMemcpyHostToDevice));
+  if ((rc = osc_upload(h, table, n, sizeof(double), h->d_osc_table_d))) return rc;
+  h->osc_valid_f64 = true;
+  h->osc_valid_f32 = false;
   return M3HIP_OK;
 }
 
@@ -1338,6 +1363,15 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   }
   const double t_c = now_s();
 
+  if (h->n_osc) {  // the oscillation weights in the precision this build of the sample side multiplies in
+    if (h->f64 && !h->osc_valid_f64) {
+      launch_osc_convert(h->d_osc_table, nullptr, h->d_osc_table_d, h->n_osc, true, h->stream);
+      h->osc_valid_f64 = true;
+    } else if (!h->f64 && !h->osc_valid_f32) {
+      launch_osc_convert(nullptr, h->d_osc_table_d, h->d_osc_table, h->n_osc, false, h->stream);
+      h->osc_valid_f32 = true;
+    }
+  }
   ReweightArgs a = make_rw_args(h);
   if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;

@@ -221,6 +221,7 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_llh(const LlhArgs& a, hipStream_t s);
+void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);
 
 }  // namespace m3hip

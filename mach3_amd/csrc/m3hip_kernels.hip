@@ -921,6 +921,20 @@ __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   }
 }
 
+// oscillation-weight table in the other precision of M3::float_t (widening is exact; narrowing is what a
+// float build would have stored)
+__global__ __launch_bounds__(256) void k_osc_widen(const float* src, double* dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = (double)src[i];
+}
+__global__ __launch_bounds__(256) void k_osc_narrow(const double* src, float* dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s) {
+  const unsigned g = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  if (widen) hipLaunchKernelGGL(k_osc_widen, dim3(g), dim3(256), 0, s, f32, reinterpret_cast<double*>(dst), n);
+  else hipLaunchKernelGGL(k_osc_narrow, dim3(g), dim3(256), 0, s, f64, reinterpret_cast<float*>(dst), n);
+}
+
 void launch_llh(const LlhArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_llh, dim3(1), dim3(256), 0, s, a); }
 
 }  // namespace m3hip

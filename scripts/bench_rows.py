@@ -47,6 +47,25 @@ if only in ("all", "binned"):
 if only == "binned":
     sys.exit(0)
 
+# ---- per-step oscillation-table upload (OscillationHandler::Evaluate output), config 2 at 1e6 events
+if only in ("all", "osc"):
+    spec = synth.CONFIGS["c2"].scaled(1_000_000, n_params=16)
+    eng, mono, sh, par = build_from_synth(spec)
+    sh.Reweight(); sh.AddData(sh.GetMCArray())
+    for n_tbl in (4000, 200000):
+        tbl = rng.random(n_tbl).astype(np.float32)
+        sh.SetOscillationWeights(tbl)
+        def step_a():
+            par[:spec.n_par] = synth.params(spec, int(rng.integers(1, 60))); return sh.Step()
+        def step_b():
+            sh.SetOscillationWeights(tbl); return step_a()
+        a = timeit(step_a); b = timeit(step_b)
+        print(f"osc table of {n_tbl} floats re-uploaded every step: {b:.1f} us/step vs {a:.1f} us/step with a static table (+{b-a:.1f} us)", flush=True)
+    eng.close()
+if only == "osc":
+    sys.exit(0)
+
+
 # ---- device binning + one energy-scale shift on config 2 at 1e6 events
 spec = synth.CONFIGS["c2"].scaled(1_000_000, n_params=16)
 eng, mono, sh0, par = build_from_synth(spec)

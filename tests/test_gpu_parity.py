@@ -378,6 +378,45 @@ def test_ragged_bricks_match_oracle(fresh_engine, cfg, n_events, n_params):
     omono.close()
 
 
+def test_oscillation_weights_change_every_step(fresh_engine):
+    """OscillationHandler::Evaluate runs inside every Reweight (SampleHandlerFD.cpp:319-324): the weight table
+    behind the events' oscillation pointers is re-uploaded per step (asynchronously, no sync in between) and
+    the fused result follows it."""
+    spec = synth.CONFIGS["c2"].scaled(6000, n_params=12)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, spec.n_events)
+    otbl = osamp.keep[7]                       # the oracle's events point into this array
+    assert otbl.dtype == np.float32 and (ev["osc_idx"] >= 0).sum() > 4000
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    rng = np.random.default_rng(8)
+    sh.RecordEventWeights(True)
+    for lap in range(1, 8):
+        otbl[:] = rng.random(len(otbl)).astype(np.float32)
+        if lap == 5:
+            otbl[::3] = 0.0                    # zero weights: those events drop out of the fill (w <= 0)
+        sh.SetOscillationWeights(otbl)
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventWeights(0, spec.n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    # back-to-back uploads without a step in between: the last one wins
+    sh.SetOscillationWeights(rng.random(len(otbl)).astype(np.float32))
+    otbl[:] = rng.random(len(otbl)).astype(np.float32)
+    sh.SetOscillationWeights(otbl)
+    sh.SetOscillationWeights(otbl)
+    llh = sh.Step()
+    osamp.reweight()
+    _llh_close(llh, osamp.get_likelihood())
+    osamp.close()
+    omono.close()
+
+
 def _ragged_events(rng, E, P, occ, xs, empty_frac=0.0, tf1_only_frac=0.0):
     events = []
     for _ in range(E):
