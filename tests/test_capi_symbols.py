@@ -41,3 +41,13 @@ def test_create_fails_loudly_without_device():
     from mach3_amd.engine import Engine
     with pytest.raises(capi.M3HipError):
         Engine(0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header compiles as C99 (plain pointers and sizes, no C++ or torch types)"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "m3hip.h"\nint main(void) { return M3HIP_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
