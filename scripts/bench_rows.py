@@ -18,10 +18,12 @@ def timeit(fn, n=200, spin=0.7):
 rng=np.random.default_rng(5)
 only = sys.argv[1] if len(sys.argv) > 1 else "all"
 # ---- binned splines: 1e6 events, 50 unique parameters, 1e6 bin-splines, ~30 weights per event; both M3::float_t builds
-def binned_row(float_t):
+def binned_row(float_t, sort_by_cell=False):
     P, cells, E = 50, 20000, 1_000_000
     bs = make_binned(P, cells, rng, float_t=float_t)
     cell = rng.integers(0, cells, E)
+    if sort_by_cell:
+        cell = np.sort(cell)  # events that share a spline bin sit next to each other (what ordering the MC by kinematic bin gives)
     mask = rng.random((E, P)) < 0.6
     cnt = mask.sum(1)
     w_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
@@ -37,13 +39,15 @@ def binned_row(float_t):
     def step():
         par[:P] = rng.uniform(-2, 2, P); return sh.Step()
     eng.timing_enable(True); us = timeit(step); k_ms,_ = eng.timing_read(0)
-    print(f"binned float_t={np.dtype(float_t).name}: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: "
+    print(f"binned float_t={np.dtype(float_t).name} sorted_by_cell={sort_by_cell}: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: "
           f"step {us:.1f} us, event kernel {k_ms*1e3:.1f} us ({(w_idx.nbytes + 8*E)/k_ms/1e6:.0f} GB/s of index+bin/osc bytes)", flush=True)
     eng.close()
 
 if only in ("all", "binned"):
     binned_row(np.float32)
     binned_row(np.float64)
+    binned_row(np.float32, True)
+    binned_row(np.float64, True)
 if only == "binned":
     sys.exit(0)
 
