@@ -1,5 +1,7 @@
 """Host-side re-layout (reference flat arrays -> segment-major tiles): pure data movement,
 checked on the CPU against the source arrays through the m3hip_debug_layout probe."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ from helpers import debug_layout, make_monolith, natural_cubic
 from mach3_amd import synth
 
 TE = 256
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def check_uniform_tiles(n_params, K, npts, ch, lay):
@@ -217,3 +220,18 @@ def test_brick_stage_limit_is_reported():
     cx, npts, ch = make_monolith(P, 3, {p: X3 for p in range(P)}, events)
     rc, err, _ = debug_layout(P, 3, npts, ch)
     assert rc != 0 and "stages" in err
+
+
+def test_layout_under_sanitizers(tmp_path):
+    """the host re-layout under AddressSanitizer + UBSan (GPU sanitizers are not available on the pool):
+    exact-size input arrays and stores, random dense / mixed / ragged / empty chunks, the stage-limit refusal"""
+    import subprocess
+    exe = tmp_path / "layout_sanitize"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread", "-o", str(exe),
+                        os.path.join(ROOT, "tests", "cpp", "layout_sanitize.cpp"), os.path.join(ROOT, "mach3_amd", "csrc", "m3hip_layout.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+    assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    assert "stages exceed" in r.stdout and r.stdout.count("bricks") >= 5
