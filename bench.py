@@ -258,6 +258,15 @@ def main():
 
     if rank == 0:
         tr = pmc_traffic(args.config, per_gpu)
+        cfg_index = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}.get(base.name, "?")
+        stat_name = {0: "Poisson", 1: "Barlow-Beeston", 2: "IceCube", 3: "Pearson", 4: "Dembinski-Abdelmotteleb"}.get(int(spec.test_statistic), "?")
+        if info.n_tiles_brick and info.n_tiles_uniform:
+            kernel_name = "k_reweight_uniform<fill> + k_reweight_brick<fill> (spline eval + weight product + bin fill, fused; both launches timed together)"
+        elif info.n_tiles_brick:
+            kernel_name = "k_reweight_brick<fill> (ragged groups: spline eval + weight product + bin fill, fused)"
+        else:
+            kernel_name = "k_reweight_uniform<fill> (spline eval + weight product + bin fill, fused)"
+
         out = {
             "metric": "LLH evaluations/sec (MCMC steps/sec)",
             "value": n_gpus * args.steps / el,
@@ -272,9 +281,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1] ({base.name}): {per_gpu} events/GPU, {spec.n_params} TSpline3 systematics x "
-                            f"{spec.n_knots} knots (occupancy {spec.occupancy:g}), {spec.n_norm} norm systematics, pre-staged osc table, "
-                            f"{spec.total_bins} bins, Poisson LLH",
+                "workload": f"BASELINE configs[{cfg_index}] ({base.name}): {per_gpu} events/GPU, {spec.n_params} "
+                            f"{'TSpline3/TF1 (alternating)' if spec.mixed else 'TSpline3'} systematics x {spec.n_knots} knots "
+                            f"(occupancy {spec.occupancy:g}), {spec.n_norm} norm systematics, pre-staged osc table, "
+                            f"{spec.total_bins} bins, {stat_name} LLH",
                 "events_per_gpu": per_gpu,
                 "total_events": per_gpu * n_gpus,
                 "spline_responses_per_gpu": int(info.n_splines),
@@ -284,7 +294,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_reweight_uniform<fill> (spline eval + weight product + bin fill, fused)",
+                "kernel": kernel_name,
                 "achieved": info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
