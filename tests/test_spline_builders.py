@@ -72,6 +72,38 @@ def test_root_tspline3_restatements_agree_and_interpolate(shim):
     assert np.allclose(b, 0.3 - 0.4 * x + 0.15 * x ** 2, atol=1e-12) and np.allclose(d[:-1], 0.05, atol=1e-12)
 
 
+def test_root_tspline3_restatement_satisfies_the_fmm_equations():
+    """ROOT's TSpline3 without end-point options is Forsythe-Malcolm-Moler's `spline`: the unique C2 cubic
+    interpolant whose third derivative in the first (last) segment equals the third divided difference of the
+    first (last) four points.  The restatement is checked against these defining equations rather than against
+    another implementation (it is NOT scipy's not-a-knot spline for n > 4; for n = 4 both reduce to the cubic
+    through the four points)."""
+    from scipy.interpolate import CubicSpline
+    olib = ob.load("serial")
+    rng = np.random.default_rng(3)
+
+    def third_divided_difference(x, y):
+        t = [float(v) for v in y]
+        for k in range(1, 4):
+            t = [(t[i + 1] - t[i]) / (x[i + k] - x[i]) for i in range(len(t) - 1)]
+        return t[0]
+
+    for n in (4, 5, 7, 12, 30):
+        for _ in range(20):
+            x = np.cumsum(rng.uniform(0.5, 1.5, n))
+            y = 1 + 0.2 * rng.standard_normal(n)
+            b, c, d = root_coeffs(olib, x, y)
+            h = np.diff(x)
+            assert np.allclose(y[:-1] + h * (b[:-1] + h * (c[:-1] + h * d[:-1])), y[1:], atol=1e-12)        # interpolates
+            assert np.allclose(b[:-1] + h * (2 * c[:-1] + 3 * d[:-1] * h), b[1:], atol=1e-11)                 # C1
+            assert np.allclose(2 * c[:-2] + 6 * d[:-2] * h[:-1], 2 * c[1:-1], atol=1e-11)                     # C2
+            assert abs(d[0] - third_divided_difference(x[:4], y[:4])) < 1e-12                                 # FMM end conditions
+            assert abs(d[n - 2] - third_divided_difference(x[-4:], y[-4:])) < 1e-12
+            if n == 4:
+                cs = CubicSpline(x, y, bc_type="not-a-knot")
+                assert np.allclose(b[:-1], cs.c[2], atol=1e-12) and np.allclose(d[:-1], cs.c[0], atol=1e-12)
+
+
 @pytest.mark.parametrize("interp", [kTSpline3, kLinear, kMonotonic, kAkima, kKochanekBartels, kLinearFunc])
 def test_facade_builders_match_oracle_bitwise(shim, interp):
     olib = ob.load("serial")
