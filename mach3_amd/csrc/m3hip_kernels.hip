@@ -371,7 +371,8 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
 constexpr int kBrickThreads = 512;                               // 2 workgroups per CU (~61 KiB LDS, <= 128 VGPRs)
 constexpr int kBrickEvPerLane = M3_GROUP / kBrickThreads;         // events per lane in phase B
 constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;   // responses per lane and stage
-constexpr int kBrickMaxStages = 30;
+constexpr int kBrickMaxStages = M3_BRICK_MAX_STAGES;
+static_assert(1 + M3_STAGE_HDR * kBrickMaxStages <= kBrickThreads, "the stage headers are fetched by one load per lane");
 constexpr int kBrickLdsParams = 1024;                             // per-step parameter table kept in LDS up to this P
 constexpr int kBrickRunsPerLane = M3_BRICK_MAX_RUNS / kBrickThreads;
 
