@@ -26,24 +26,25 @@ namespace m3hip {
 // (A one-pass 1024-lane variant with the proposal and the knots staged through LDS / registers was
 // measured 3.5 us SLOWER per step than this arrangement in an A/B on one box -- scripts/ab_step.py -- although
 // it has fewer dependent round trips on paper; the simple version stays.)
-__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+__global__ __launch_bounds__(1024) void k_prep(PrepArgs a) {
   const int tid = threadIdx.x;
+  const int nt = blockDim.x;  // 256 up to P = 256, else enough lanes for one parameter each (<= 1024): see launch_prep
   if (a.dbg_clock && tid == 0) a.dbg_clock[0] = wall_clock64();
   // ResetHistograms: mc always, w2 only while FirstTimeW2 (SampleHandlerFD.cpp:454-463)
   if (a.reset_hist) {
     const int n = a.hist_rep * a.n_bins;
-    for (int b = tid; b < n; b += 256) {
+    for (int b = tid; b < n; b += nt) {
       a.hist[b] = 0.0;
       if (a.reset_w2) a.hist[n + b] = 0.0;
     }
   }
   if (a.params_src) {
-    for (int i = tid; i < a.n_par; i += 256) a.params_dev[i] = a.params_src[i];
+    for (int i = tid; i < a.n_par; i += nt) a.params_dev[i] = a.params_src[i];
     if (tid == 0) a.params_dev[a.n_par] = 1.0;
     __syncthreads();  // from here on read the device copy, not host memory over PCIe
   }
   const int K = a.max_knots;
-  for (int i = tid; i < a.n_params; i += 256) {
+  for (int i = tid; i < a.n_params; i += nt) {
     float xvar;
     int segment = 0;
     const int nPoints = a.npts[i];
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   }
   if (a.n_res > 0) {  // few unique slot lists: resolve them here and save a launch
     __syncthreads();
-    for (int i = tid; i < a.n_res; i += 256) {
+    for (int i = tid; i < a.n_res; i += nt) {
       const int p = a.u_param[i];
       const int pl0 = a.u_plane0[i];
       RSlot r;
@@ -127,7 +128,12 @@ __global__ __launch_bounds__(256) void k_resolve(PrepArgs a, int32_t n_res) {
   a.resolved[i] = r;
 }
 
-void launch_prep(const PrepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, a); }
+void launch_prep(const PrepArgs& a, hipStream_t s) {
+  // every pass over the parameters is a chain of dependent loads (map -> value -> knots): with P > 256 one
+  // lane per parameter keeps it to a single pass (A/B on one box: -3 us per step at P = 512, -8 us at P = 1024)
+  const int nt = a.n_params <= 256 ? 256 : (a.n_params <= 512 ? 512 : 1024);
+  hipLaunchKernelGGL(k_prep, dim3(1), dim3(nt), 0, s, a);
+}
 void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s) {
   if (n_res > 0) hipLaunchKernelGGL(k_resolve, dim3((n_res + 255) / 256), dim3(256), 0, s, a, n_res);
 }

@@ -6,7 +6,8 @@ import numpy as np, ctypes as C
 from mach3_amd import synth
 from mach3_amd.engine import build_from_synth
 ev = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-spec = synth.CONFIGS["c2"].scaled(ev)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+spec = synth.CONFIGS[cfg].scaled(ev)
 eng, mono, sh, par = build_from_synth(spec)
 sh.Reweight(); sh.AddData(sh.GetMCArray())
 laps=[synth.params(spec,i+1) for i in range(16)]
@@ -16,7 +17,7 @@ for rep in range(3):
     t=time.perf_counter()
     for i in range(500): par[:]=laps[i%16]; sh.Step()
     us=(time.perf_counter()-t)/500*1e6
-    print(os.path.basename(os.environ.get("M3HIP_LIB","libm3hip.so")), f"E={ev} step {us:.1f} us", flush=True)
+    print(os.path.basename(os.environ.get("M3HIP_LIB","libm3hip.so")), f"{cfg} E={ev} step {us:.1f} us", flush=True)
 eng.lib.m3hip_debug_device_span(eng.h, 1, None); dev=[]
 for i in range(200):
     par[:]=laps[i%16]; sh.Step()
