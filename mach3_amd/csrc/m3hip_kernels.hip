@@ -23,9 +23,9 @@ namespace m3hip {
 // ------------------------------------------------------------------------------------
 // k_prep: one workgroup.  Parameter-only work of a step.
 // ------------------------------------------------------------------------------------
-// (A one-pass 1024-lane variant with the proposal and the knots staged through LDS / registers was
-// measured 3.5 us SLOWER per step than this arrangement in an A/B on one box -- scripts/ab_step.py -- although
-// it has fewer dependent round trips on paper; the simple version stays.)
+// (Two variants with fewer dependent round trips on paper -- the proposal staged through LDS, and the knots of a
+// parameter preloaded into registers before the PCIe wait -- were each measured 2.5-3.5 us SLOWER per step in
+// same-box A/B runs (scripts/ab_step.py); the simple version stays.)
 __global__ __launch_bounds__(1024) void k_prep(PrepArgs a) {
   const int tid = threadIdx.x;
   const int nt = blockDim.x;  // 256 up to P = 256, else enough lanes for one parameter each (<= 1024): see launch_prep
