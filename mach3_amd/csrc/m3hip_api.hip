@@ -1355,11 +1355,16 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     ba.par_map = h->d_parmap;
     launch_binned_weights(ba, h->stream);
   }
-  if (!h->h_shifts.empty()) {  // functional shifts: re-bin every event from its shifted kinematics
+  // functional shifts: every event is re-binned from its shifted kinematics, inside the reweight kernels'
+  // epilogue (the float_t = double variant keeps the separate k_find_bins pass)
+  const bool dyn_bins = !h->h_shifts.empty();
+  if (dyn_bins) {
     if (!h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
-    BinArgs b = make_bin_args(h);
-    b.compute_nominal = 0;
-    launch_find_bins(b, h->stream);
+    if (h->f64) {
+      BinArgs b = make_bin_args(h);
+      b.compute_nominal = 0;
+      launch_find_bins(b, h->stream);
+    }
   }
   const double t_c = now_s();
 
@@ -1373,6 +1378,10 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     }
   }
   ReweightArgs a = make_rw_args(h);
+  if (dyn_bins && !h->f64) {
+    a.dyn = make_bin_args(h);
+    a.dyn.compute_nominal = 0;
+  }
   if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;
   if (h->want_event_w) {
@@ -1400,8 +1409,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     if (n_bricks) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
     launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
-    launch_reweight_uniform(a, n_tiles, mode, ku, h->stream);
-    launch_reweight_brick(a, n_bricks, mode, kb, h->stream);
+    launch_reweight_uniform(a, n_tiles, mode, ku, h->stream, dyn_bins);
+    launch_reweight_brick(a, n_bricks, mode, kb, h->stream, dyn_bins);
   }
   if (timed && (n_tiles || n_bricks)) h->pending = 0;
   HIPCHK(h, hipGetLastError());

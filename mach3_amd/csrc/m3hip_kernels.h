@@ -51,72 +51,6 @@ struct BrickDev {
   uint32_t pad_;
 };
 
-struct ReweightArgs {
-  const TileDev* tiles;
-  const BrickDev* bricks;
-  const PTab* ptab;          // [P]
-  const float* pval;         // [P] ParamValues
-  int32_t n_params;          // P
-  float* spline_w;           // [E_pad] monolith total weight per event (may be null)
-  float* event_w;            // [E_pad] CalcWeightTotal per event (may be null)
-  // fused fill
-  const int32_t* bin;        // [E_pad]
-  const int32_t* osc;        // [E_pad]
-  const int16_t* nidx;       // [M][E_pad] ELL of global parameter indices, padded with n_par (-> 1.0)
-  const double* params;      // [n_par + 1], last entry 1.0
-  const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
-  const float* bw;           // weightvec_Monolith of the binned spline handler
-  uint32_t n_bw_slots;
-  const float* osc_table;
-  // M3::float_t = double build of the sample side (Manager/Core.h:27-51: the default, non-low-memory
-  // build): bin-spline weights, oscillation weights and the event weight product are double
-  const double* bw_d;
-  const double* osc_table_d;
-  double* event_w_d;         // [E_pad] (may be null)
-  double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
-  int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
-  uint64_t e_pad;
-  uint32_t n_norm_slots;     // M
-  int32_t n_bins;
-  int32_t fill_w2;
-  uint32_t tile_base;        // index of the first tile handled by this launch
-};
-
-enum ReweightMode : int { kModeEval = 1, kModeFill = 2, kModeEventW = 4 };
-
-struct PrepArgs {
-  // FindSplineSegment inputs
-  const double* params_src;   // pinned host (device-mapped) or device: proposed values [n_par]
-  double* params_dev;         // [n_par + 1] device copy, [n_par] = 1.0
-  int32_t n_par;
-  const int32_t* par_map;     // [P] spline parameter -> global index
-  const float* coeff_x;       // [P*K]
-  const double* coeff_x_d;    // [P*K] or null: knots as double (float_t = double build: xPts are double and the
-                              // float parameter value is compared against them, SplineBase.cpp:51-54)
-  const int16_t* npts;        // [P]
-  int16_t* curr_seg;          // [P] FastSplineInfo.CurrSegment (state)
-  int32_t n_params, max_knots;
-  // outputs
-  PTab* ptab;
-  float* pval;
-  int16_t* seg_out;
-  // host-supplied vals/segments path (RunGPU_SplineMonolith inputs); params_src unused then
-  const float* vals_in;
-  const int16_t* seg_in;
-  // slot-list resolution (all unique lists, flattened): see RSlot
-  const int32_t* u_param;   // [n_res] parameter of the slot
-  const int32_t* u_plane0;  // [n_res] first plane of the slot, -1 for a TF1 slot
-  RSlot* resolved;          // [n_res]
-  int32_t n_res;            // 0: resolution is done by k_resolve instead
-  uint64_t* dbg_clock;      // optional: [0] <- wall_clock64() at k_prep start (diagnostics)
-  // histogram reset (ResetHistograms)
-  double* hist;
-  int32_t hist_rep;
-  int32_t n_bins;
-  int32_t reset_w2;
-  int32_t reset_hist;
-};
-
 // ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307
 constexpr int M3_MAX_DIM = 4;
 struct BinAxis {       // one axis of one sample
@@ -165,6 +99,74 @@ struct BinArgs {
   uint64_t n_events;
 };
 void launch_find_bins(const BinArgs& a, hipStream_t s);
+
+struct ReweightArgs {
+  const TileDev* tiles;
+  const BrickDev* bricks;
+  const PTab* ptab;          // [P]
+  const float* pval;         // [P] ParamValues
+  int32_t n_params;          // P
+  float* spline_w;           // [E_pad] monolith total weight per event (may be null)
+  float* event_w;            // [E_pad] CalcWeightTotal per event (may be null)
+  // fused fill
+  const int32_t* bin;        // [E_pad]
+  const int32_t* osc;        // [E_pad]
+  const int16_t* nidx;       // [M][E_pad] ELL of global parameter indices, padded with n_par (-> 1.0)
+  const double* params;      // [n_par + 1], last entry 1.0
+  const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
+  const float* bw;           // weightvec_Monolith of the binned spline handler
+  uint32_t n_bw_slots;
+  const float* osc_table;
+  // M3::float_t = double build of the sample side (Manager/Core.h:27-51: the default, non-low-memory
+  // build): bin-spline weights, oscillation weights and the event weight product are double
+  const double* bw_d;
+  const double* osc_table_d;
+  double* event_w_d;         // [E_pad] (may be null)
+  double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
+  int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
+  uint64_t e_pad;
+  uint32_t n_norm_slots;     // M
+  int32_t n_bins;
+  int32_t fill_w2;
+  uint32_t tile_base;        // index of the first tile handled by this launch
+  BinArgs dyn;               // DYN variants only: the event's bin is recomputed from its shifted kinematics in the
+                             // epilogue (functional parameters), instead of being read from `bin`
+};
+
+enum ReweightMode : int { kModeEval = 1, kModeFill = 2, kModeEventW = 4 };
+
+struct PrepArgs {
+  // FindSplineSegment inputs
+  const double* params_src;   // pinned host (device-mapped) or device: proposed values [n_par]
+  double* params_dev;         // [n_par + 1] device copy, [n_par] = 1.0
+  int32_t n_par;
+  const int32_t* par_map;     // [P] spline parameter -> global index
+  const float* coeff_x;       // [P*K]
+  const double* coeff_x_d;    // [P*K] or null: knots as double (float_t = double build: xPts are double and the
+                              // float parameter value is compared against them, SplineBase.cpp:51-54)
+  const int16_t* npts;        // [P]
+  int16_t* curr_seg;          // [P] FastSplineInfo.CurrSegment (state)
+  int32_t n_params, max_knots;
+  // outputs
+  PTab* ptab;
+  float* pval;
+  int16_t* seg_out;
+  // host-supplied vals/segments path (RunGPU_SplineMonolith inputs); params_src unused then
+  const float* vals_in;
+  const int16_t* seg_in;
+  // slot-list resolution (all unique lists, flattened): see RSlot
+  const int32_t* u_param;   // [n_res] parameter of the slot
+  const int32_t* u_plane0;  // [n_res] first plane of the slot, -1 for a TF1 slot
+  RSlot* resolved;          // [n_res]
+  int32_t n_res;            // 0: resolution is done by k_resolve instead
+  uint64_t* dbg_clock;      // optional: [0] <- wall_clock64() at k_prep start (diagnostics)
+  // histogram reset (ResetHistograms)
+  double* hist;
+  int32_t hist_rep;
+  int32_t n_bins;
+  int32_t reset_w2;
+  int32_t reset_hist;
+};
 
 // ---- binned splines (ref: Splines/BinnedSplineHandler.cpp:295-341)
 struct BinnedArgs {
@@ -216,10 +218,10 @@ struct ReweightKnobs {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 
-void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
+void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
 // float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
-void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
 void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);

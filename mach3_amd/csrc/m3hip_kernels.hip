@@ -138,6 +138,82 @@ void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s) {
   if (n_res > 0) hipLaunchKernelGGL(k_resolve, dim3((n_res + 255) / 256), dim3(256), 0, s, a, n_res);
 }
 
+// ---- per-event binning (a9), used by k_find_bins and by the fused epilogue when functional shifts are registered
+__device__ __forceinline__ int d_upper_bound_bin(const double* e, int n_edges, double v) {
+  // std::distance(begin, std::upper_bound(begin, end, v)) - 1
+  int lo = 0, hi = n_edges;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v < e[mid]) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo - 1;
+}
+
+__device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin) {
+  // Samples/SampleStructs.h:577-613
+  if (KinVar < e[0] || KinVar >= e[N_Bins]) return -1;
+  if (NomBin > -1) {
+    const double lower = e[NomBin], upper = e[NomBin + 1];
+    const double lower_lower = NomBin == 0 ? e[0] : e[NomBin - 1];                       // :615-646
+    const double upper_upper = (NomBin + 2 < N_Bins) ? e[NomBin + 2] : ((NomBin + 1 < N_Bins) ? e[NomBin + 1] : -999999.123456);
+    if (KinVar < upper && KinVar >= lower) return NomBin;
+    if (KinVar < lower && KinVar >= lower_lower) return NomBin - 1;
+    if (KinVar < upper_upper && KinVar >= upper) return NomBin + 1;
+  }
+  return d_upper_bound_bin(e, N_Bins + 1, KinVar);
+}
+
+// FindGlobalBin of one event in the per-step pass: registered shifts applied to the nominal kinematics
+// (ApplyShifts, SampleHandlerFD.cpp:545-564), the selection cuts on the shifted values (IsEventSelected,
+// :281-294), then nominal bin -> +-1 neighbour -> binary search per axis and, for non-uniform samples, the
+// candidate scan of the mega-bin (BinningHandler.cpp:257-291).  Shared by k_find_bins and the fused epilogue.
+__device__ int d_event_bin(const BinArgs& a, uint64_t ev) {
+  const int sid = a.sample_id[ev];
+  const BinSample sm = a.samples[sid];
+  double x[M3_MAX_DIM];
+  for (int c = 0; c < a.kin_stride; ++c) x[c] = a.kin[ev * a.kin_stride + c];
+  for (int s = 0; s < a.n_shifts; ++s) {
+    const KinShift sh = a.shifts[s];
+    if (sh.dim < a.kin_stride && (sh.sample < 0 || sh.sample == sid)) {
+      const double th = a.params[sh.param];
+      x[sh.dim] = sh.kind == 1 ? x[sh.dim] * (1.0 + th) : x[sh.dim] + th;
+    }
+  }
+  bool out = false;
+  for (int c = 0; c < a.n_cuts; ++c) {
+    const KinCut ct = a.cuts[c];
+    if (ct.column < a.kin_stride && (ct.sample < 0 || ct.sample == sid)) {
+      const double v = x[ct.column];
+      if ((v < ct.lo) || (v >= ct.hi)) out = true;
+    }
+  }
+  int global = 0;
+  for (int d = 0; d < sm.n_dim; ++d) {
+    const BinAxis ax = a.axes[sm.axis_off + d];
+    const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], a.nom_bin[ev * a.kin_stride + d]);
+    if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
+    global += b * ax.stride;
+  }
+  if (!sm.uniform && !out) {
+    // BinningHandler.cpp:277-290: `global` is the mega-bin; scan its candidate boxes in order, first
+    // box with lo < x <= hi on every axis (BinInfo::IsEventInside, SampleStructs.h:186-220) wins
+    const int32_t* go = a.grid_off + sm.map_off + global;
+    const int c0 = go[0], c1 = go[1];
+    int found = -1;
+    for (int c = c0; c < c1 && found < 0; ++c) {
+      const int box = a.grid_list[c];
+      const double* ext = a.boxes + ((size_t)sm.box_off + box) * sm.n_dim * 2;
+      bool inside = true;
+      for (int d = 0; d < sm.n_dim; ++d) inside &= (x[d] > ext[2 * d]) & (x[d] <= ext[2 * d + 1]);
+      if (inside) found = box;
+    }
+    global = found;
+    if (found < 0) out = true;
+  }
+  return out ? -1 : global + sm.global_offset;
+}
+
 // ------------------------------------------------------------------------------------
 // k_reweight_uniform: one workgroup (256 lanes = 256 events) per uniform tile.
 //
@@ -227,7 +303,7 @@ __device__ __forceinline__ WT mul_norm_weights(WT tw, const ReweightArgs& a, uin
   return tw;
 }
 
-template <int MODE, int UNROLL, bool NT, bool F64 = false>
+template <int MODE, int UNROLL, bool NT, bool F64 = false, bool DYN = false>
 __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 (kModeFill only)
   const uint32_t tile = a.tile_base + blockIdx.x;
@@ -307,7 +383,13 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     }
     if (MODE & kModeFill) {
       __syncthreads();
-      const int b = a.bin[ev];
+      int b;
+      if (DYN) {  // functional parameters: FindGlobalBin on the shifted kinematics, here instead of in a kernel of its own
+        b = lane < td.n_events ? d_event_bin(a.dyn, ev) : -1;
+        a.dyn.bin[ev] = b;
+      } else {
+        b = a.bin[ev];
+      }
       // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`
       if (lane < td.n_events && tw > WT(0) && b >= 0) {
         atomicAdd(&lds_hist[b], (double)tw);
@@ -346,11 +428,16 @@ static void launch_mode(const ReweightArgs& a, dim3 g, size_t lds, const Reweigh
   }
 }
 
-void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s) {
+void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
   if (n_tiles == 0) return;
   size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_tiles);
+  if (dyn_bins && (mode & kModeFill)) {
+    if (mode == kModeFill) M3_LAUNCH((k_reweight_uniform<kModeFill, 8, true, false, true>), g, dim3(256), lds, s, k, a);
+    else M3_LAUNCH((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, false, true>), g, dim3(256), lds, s, k, a);
+    return;
+  }
   if (mode == kModeEval) launch_mode<kModeEval>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_mode<kModeFill>(a, g, lds, k, s);
   else launch_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
@@ -393,7 +480,7 @@ struct RRun {      // per-step resolved run: address = base + r, dx of the run's
 // right after the previous stage's loads were consumed and arrives under that stage's barrier and
 // phase B; the run entries are resolved against the per-step parameter table, which lives in LDS, so
 // no second global round trip hides in the resolution.
-template <int MODE, bool NT, int kBrickBatch>
+template <int MODE, bool NT, int kBrickBatch, bool DYN = false>
 __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
   __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
@@ -572,7 +659,13 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
       tw *= w[q];
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
-        const int b = a.bin[ev];
+        int b;
+        if (DYN) {
+          b = e < bd.n_events ? d_event_bin(a.dyn, ev) : -1;
+          a.dyn.bin[ev] = b;
+        } else {
+          b = a.bin[ev];
+        }
         if (e < bd.n_events && tw > 0.f && b >= 0) {
           atomicAdd(&lds_hist[b], (double)tw);
           if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
@@ -599,11 +692,16 @@ static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const R
   else M3_LAUNCH((k_reweight_brick<MODE, false, 8>), g, dim3(kBrickThreads), lds, s, k, a);
 }
 
-void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
   if (n_bricks == 0) return;
   size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
+  if (dyn_bins && (mode & kModeFill)) {
+    if (mode == kModeFill) M3_LAUNCH((k_reweight_brick<kModeFill, true, 8, true>), g, dim3(kBrickThreads), lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<kModeFill | kModeEval | kModeEventW, true, 8, true>), g, dim3(kBrickThreads), lds, s, k, a);
+    return;
+  }
   if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
   else launch_brick_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
@@ -616,89 +714,25 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
 // search, exactly the reference's cascade (all routes give the same index; the integer result
 // is what the parity tests pin).
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int d_upper_bound_bin(const double* e, int n_edges, double v) {
-  // std::distance(begin, std::upper_bound(begin, end, v)) - 1
-  int lo = 0, hi = n_edges;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (v < e[mid]) hi = mid;
-    else lo = mid + 1;
-  }
-  return lo - 1;
-}
-
-__device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin) {
-  // Samples/SampleStructs.h:577-613
-  if (KinVar < e[0] || KinVar >= e[N_Bins]) return -1;
-  if (NomBin > -1) {
-    const double lower = e[NomBin], upper = e[NomBin + 1];
-    const double lower_lower = NomBin == 0 ? e[0] : e[NomBin - 1];                       // :615-646
-    const double upper_upper = (NomBin + 2 < N_Bins) ? e[NomBin + 2] : ((NomBin + 1 < N_Bins) ? e[NomBin + 1] : -999999.123456);
-    if (KinVar < upper && KinVar >= lower) return NomBin;
-    if (KinVar < lower && KinVar >= lower_lower) return NomBin - 1;
-    if (KinVar < upper_upper && KinVar >= upper) return NomBin + 1;
-  }
-  return d_upper_bound_bin(e, N_Bins + 1, KinVar);
-}
-
 __global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
   const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (ev >= a.n_events) return;
-  const int sid = a.sample_id[ev];
-  const BinSample sm = a.samples[sid];
-  // ApplyShifts (SampleHandlerFD.cpp:545-564): nominal values, then every registered shift in order
-  double x[M3_MAX_DIM];
-  for (int c = 0; c < a.kin_stride; ++c) x[c] = a.kin[ev * a.kin_stride + c];
-  if (!a.compute_nominal) {
-    for (int s = 0; s < a.n_shifts; ++s) {
-      const KinShift sh = a.shifts[s];
-      if (sh.dim < a.kin_stride && (sh.sample < 0 || sh.sample == sid)) {
-        const double th = a.params[sh.param];
-        x[sh.dim] = sh.kind == 1 ? x[sh.dim] * (1.0 + th) : x[sh.dim] + th;
-      }
-    }
+  if (!a.compute_nominal) {  // per-step pass (kept for the paths that do not fuse it into the reweight epilogue)
+    a.bin[ev] = d_event_bin(a, ev);
+    return;
   }
-  // IsEventSelected (SampleHandlerFD.cpp:281-294), on the shifted values
-  bool out = false;
-  for (int c = 0; c < a.n_cuts; ++c) {
-    const KinCut ct = a.cuts[c];
-    if (ct.column < a.kin_stride && (ct.sample < 0 || ct.sample == sid)) {
-      const double v = x[ct.column];
-      if ((v < ct.lo) || (v >= ct.hi)) out = true;
-    }
-  }
-  int global = 0;
+  // set-up pass: BinningHandler::FindNominalBin per axis (BinningHandler.cpp:294-307) on the nominal kinematics
+  const BinSample sm = a.samples[a.sample_id[ev]];
   for (int d = 0; d < sm.n_dim; ++d) {
     const BinAxis ax = a.axes[sm.axis_off + d];
     const double* e = a.edges + ax.edge_off;
-    int b;
-    if (a.compute_nominal) {
-      // BinningHandler::FindNominalBin (BinningHandler.cpp:294-307)
-      b = (x[d] < e[0] || x[d] >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x[d]);
-      a.nom_bin[ev * a.kin_stride + d] = b;
-    } else {
-      b = d_find_bin(e, ax.n_bins, x[d], a.nom_bin[ev * a.kin_stride + d]);
-    }
-    if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
-    global += b * ax.stride;
+    const double x = a.kin[ev * a.kin_stride + d];
+    a.nom_bin[ev * a.kin_stride + d] = (x < e[0] || x >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x);
   }
-  if (!sm.uniform && !out) {
-    // BinningHandler.cpp:277-290: `global` is the mega-bin; scan its candidate boxes in order, first
-    // box with lo < x <= hi on every axis (BinInfo::IsEventInside, SampleStructs.h:186-220) wins
-    const int32_t* go = a.grid_off + sm.map_off + global;
-    const int c0 = go[0], c1 = go[1];
-    int found = -1;
-    for (int c = c0; c < c1 && found < 0; ++c) {
-      const int box = a.grid_list[c];
-      const double* ext = a.boxes + ((size_t)sm.box_off + box) * sm.n_dim * 2;
-      bool inside = true;
-      for (int d = 0; d < sm.n_dim; ++d) inside &= (x[d] > ext[2 * d]) & (x[d] <= ext[2 * d + 1]);
-      if (inside) found = box;
-    }
-    global = found;
-    if (found < 0) out = true;
-  }
-  a.bin[ev] = out ? -1 : global + sm.global_offset;
+  // the global bin of the nominal event: the per-step cascade with the nominal bins just stored, no shifts
+  BinArgs n = a;
+  n.n_shifts = 0;
+  a.bin[ev] = d_event_bin(n, ev);
 }
 
 void launch_find_bins(const BinArgs& a, hipStream_t s) {

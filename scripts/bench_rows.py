@@ -68,10 +68,11 @@ if only in ("all", "osc"):
     eng.close()
 if only == "osc":
     sys.exit(0)
+n_ev_shift = int(os.environ.get("SHIFT_EVENTS", "1000000"))
 
 
 # ---- device binning + one energy-scale shift on config 2 at 1e6 events
-spec = synth.CONFIGS["c2"].scaled(1_000_000, n_params=16)
+spec = synth.CONFIGS["c2"].scaled(n_ev_shift, n_params=16)
 eng, mono, sh0, par = build_from_synth(spec)
 ev = synth.events_chunk(spec, 0, spec.n_events)
 par2 = np.concatenate([par, [0.0]])
@@ -85,7 +86,9 @@ def step2():
 a = timeit(step2)
 sh.AddKinShift(-1, 0, 1, spec.n_par)
 b = timeit(step2)
-print(f"device re-binning: E=1e6, 1-D 200 bins, one scale shift: step {a:.1f} us without, {b:.1f} us with shifts (+{b-a:.1f} us for k_find_bins)")
+print(f"device re-binning: E={n_ev_shift}, 1-D 200 bins, one scale shift: step {a:.1f} us without, {b:.1f} us with shifts (+{b-a:.1f} us)", flush=True)
+if only == "shift":
+    sys.exit(0)
 # ---- seam 2: SMonolith::Evaluate + SynchroniseMemTransfer incl. the 4 MB device-to-host copy
 mono.setSplinePointers(par)
 def step3():
