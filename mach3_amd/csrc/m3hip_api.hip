@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -142,6 +143,12 @@ struct m3hip_ctx {
   double* d_event_w_d = nullptr;
   int32_t* d_bwidx = nullptr;
   uint32_t Kb = 0;
+  // shared-list form of the same information (chosen at the first m3hip_binned_upload_events when neighbouring
+  // events mostly carry identical lists)
+  int bl_mode = -1;  // -1 undecided, 0 ELL, 1 shared lists
+  std::map<std::vector<int32_t>, int32_t> bl_map;
+  std::vector<int32_t> bl_off, bl_idx;
+  int32_t *d_bl_id = nullptr, *d_bl_off = nullptr, *d_bl_idx = nullptr;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
   BinSample* d_bin_samples = nullptr;
@@ -310,6 +317,11 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_event_w_d); h->d_event_w_d = nullptr;
   h->f64 = false;
   dev_free(h->d_bwidx); h->d_bwidx = nullptr;
+  dev_free(h->d_bl_id); h->d_bl_id = nullptr;
+  dev_free(h->d_bl_off); h->d_bl_off = nullptr;
+  dev_free(h->d_bl_idx); h->d_bl_idx = nullptr;
+  h->bl_mode = -1;
+  h->bl_map.clear(); h->bl_off.clear(); h->bl_idx.clear();
   h->b_M = h->b_U = h->b_C = 0;
   h->Kb = 0;
   dev_free(h->d_sample_id); h->d_sample_id = nullptr;
@@ -366,6 +378,9 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.params = h->d_params;
   a.osc_table = h->d_osc_table;
   a.bwidx = h->d_bwidx;
+  a.bl_id = h->bl_mode == 1 ? h->d_bl_id : nullptr;
+  a.bl_off = h->d_bl_off;
+  a.bl_idx = h->d_bl_idx;
   a.bw = h->d_b_w;
   a.bw_d = h->d_b_w_d;
   a.osc_table_d = h->d_osc_table_d;
@@ -905,6 +920,49 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
     if (c > mx) mx = uint32_t(c);
     for (uint64_t k = w_off[i]; k < w_off[i + 1]; ++k)
       if (w_idx[k] < 0 || w_idx[k] >= h->b_M) return fail(h, M3HIP_EINVAL, "binned_upload_events: weight index out of range");
+  }
+  if (h->bl_mode < 0) {
+    // Events registered in spline-bin order carry the same pointer list as their neighbours: then one list id
+    // per event replaces 4 B of index per weight.  Unordered events keep the ELL form (two dependent random
+    // gathers per weight would cost more than they save).  M3HIP_BINNED_LISTS=ell|shared overrides the choice.
+    uint64_t same = 0;
+    for (uint64_t i = 1; i < n; ++i) {
+      const uint64_t c = w_off[i + 1] - w_off[i];
+      if (c == w_off[i] - w_off[i - 1] && (c == 0 || memcmp(w_idx + w_off[i], w_idx + w_off[i - 1], sizeof(int32_t) * c) == 0)) ++same;
+    }
+    h->bl_mode = (n > 1 && 2 * same >= n - 1) ? 1 : 0;
+    if (const char* f = getenv("M3HIP_BINNED_LISTS")) h->bl_mode = (f[0] == 's') ? 1 : 0;
+  }
+  if (h->bl_mode == 1) {
+    if (!h->d_bl_id) {
+      int rc = dev_alloc(h, &h->d_bl_id, size_t(h->E_pad));
+      if (rc) return rc;
+      HIPCHK(h, hipMemset(h->d_bl_id, 0xFF, sizeof(int32_t) * h->E_pad));
+      h->bl_off.assign(1, 0);
+    }
+    std::vector<int32_t> ids(n);
+    std::vector<int32_t> key;
+    for (uint64_t i = 0; i < n; ++i) {
+      key.assign(w_idx + w_off[i], w_idx + w_off[i + 1]);
+      if (key.empty()) { ids[i] = -1; continue; }
+      auto it = h->bl_map.find(key);
+      if (it == h->bl_map.end()) {
+        it = h->bl_map.emplace(key, int32_t(h->bl_off.size()) - 1).first;
+        h->bl_idx.insert(h->bl_idx.end(), key.begin(), key.end());
+        h->bl_off.push_back(int32_t(h->bl_idx.size()));
+      }
+      ids[i] = it->second;
+    }
+    dev_free(h->d_bl_off);
+    dev_free(h->d_bl_idx);
+    h->d_bl_off = h->d_bl_idx = nullptr;
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_bl_off, h->bl_off.size()))) return rc;
+    if ((rc = dev_alloc(h, &h->d_bl_idx, h->bl_idx.size()))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_bl_off, h->bl_off.data(), sizeof(int32_t) * h->bl_off.size(), hipMemcpyHostToDevice));
+    if (!h->bl_idx.empty()) HIPCHK(h, hipMemcpy(h->d_bl_idx, h->bl_idx.data(), sizeof(int32_t) * h->bl_idx.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_bl_id + event_offset, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    return M3HIP_OK;
   }
   if (mx > h->Kb) {
     int32_t* nn = nullptr;

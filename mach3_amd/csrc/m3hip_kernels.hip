@@ -263,6 +263,24 @@ __device__ __forceinline__ const double* binned_table<double>(const ReweightArgs
 template <class WT>
 __device__ __forceinline__ WT mul_binned_weights(WT tw, const ReweightArgs& a, uint64_t ev) {
   const WT* __restrict__ bw = binned_table<WT>(a);
+  if (a.bl_id) {  // shared lists: lanes of a wave mostly walk the same list, so both look-ups are near-uniform
+    const int id = a.bl_id[ev];
+    if (id < 0) return tw;
+    int off = a.bl_off[id];
+    const int end = a.bl_off[id + 1];
+    for (; off + 4 <= end; off += 4) {
+      int bi[4];
+      WT wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bi[u] = a.bl_idx[off + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wv[u] = bw[bi[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tw *= wv[u];
+    }
+    for (; off < end; ++off) tw *= bw[a.bl_idx[off]];
+    return tw;
+  }
   uint32_t k = 0;
   for (; k + 4 <= a.n_bw_slots; k += 4) {
     int bi[4];

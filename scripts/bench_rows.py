@@ -24,7 +24,7 @@ def binned_row(float_t, sort_by_cell=False):
     cell = rng.integers(0, cells, E)
     if sort_by_cell:
         cell = np.sort(cell)  # events that share a spline bin sit next to each other (what ordering the MC by kinematic bin gives)
-    mask = rng.random((E, P)) < 0.6
+    mask = (rng.random((cells, P)) < 0.6)[cell]  # the pointer list belongs to the spline bin (sample / channel / mode / kinematic bin)
     cnt = mask.sum(1)
     w_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
     w_idx = (cell[:, None] * P + np.arange(P)[None, :])[mask].astype(np.int32)

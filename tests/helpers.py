@@ -136,13 +136,20 @@ def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_fra
                 xcoeff=np.concatenate(xcoeff).astype(float_t), manycoeff=np.concatenate(many).astype(float_t))
 
 
-def make_binned_events(n_events, n_params, n_cells, rng):
-    """per event: its cell's bin-splines for a random subset of the parameters, ascending"""
+def make_binned_events(n_events, n_params, n_cells, rng, per_cell_lists=False, sort_by_cell=False):
+    """per event: its cell's bin-splines for a subset of the parameters, ascending.  per_cell_lists: the subset
+    belongs to the cell (events of one spline bin carry identical pointer lists, as in the reference where the
+    list follows from sample / channel / mode / kinematic bin); sort_by_cell: events ordered by cell."""
+    cells = rng.integers(0, n_cells, n_events)
+    if sort_by_cell:
+        cells = np.sort(cells)
+    cell_mask = rng.random((n_cells, n_params)) < 0.6 if per_cell_lists else None
     w_off, w_idx = [0], []
-    for _ in range(n_events):
-        cell = int(rng.integers(0, n_cells))
+    for e in range(n_events):
+        cell = int(cells[e])
+        mask = cell_mask[cell] if per_cell_lists else rng.random(n_params) < 0.6
         for p in range(n_params):
-            if rng.random() < 0.6:
+            if mask[p]:
                 w_idx.append(cell * n_params + p)
         w_off.append(len(w_idx))
     return np.asarray(w_off, np.uint64), np.asarray(w_idx, np.int32)

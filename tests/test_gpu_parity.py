@@ -730,17 +730,25 @@ def test_functional_shifts_rebin_every_step(fresh_engine):
     omono.close()
 
 
-def test_binned_splines_match_oracle(fresh_engine):
+@pytest.mark.parametrize("lists", ["ell", "shared_sorted", "shared_forced"])
+def test_binned_splines_match_oracle(fresh_engine, lists, monkeypatch):
     """SURVEY 8f row 1: BinnedSplineHandler::Evaluate (segment search + clamped cubic per bin-spline)
     and the per-event gather of those weights into CalcWeightTotal, against the oracle: bin-spline
-    weights and event weights bit-exact, bins 1e-12, LLH 1e-9."""
+    weights and event weights bit-exact, bins 1e-12, LLH 1e-9.  The events' pointer lists reach the device
+    either as ELL planes (unordered MC) or as list ids into the distinct lists (MC ordered by spline bin;
+    also forced onto unordered events, where every event has a list of its own)."""
     from helpers import make_binned, make_binned_events
     from mach3_amd.engine import BinnedSplineHandler
 
     rng = np.random.default_rng(31)
     P, cells, E, n_norm = 9, 400, 5000, 4
     bs = make_binned(P, cells, rng)
-    w_off, w_idx = make_binned_events(E, P, cells, rng)
+    if lists == "shared_sorted":
+        w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=True, sort_by_cell=True)
+    else:
+        w_off, w_idx = make_binned_events(E, P, cells, rng)
+    if lists == "shared_forced":
+        monkeypatch.setenv("M3HIP_BINNED_LISTS", "shared")
     par = np.zeros(P + n_norm)
     par[P:] = 1.0
     opar = par.copy()
