@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 
@@ -93,7 +94,8 @@ int main(int argc, char** argv) {
     auto setpar = [&](int i, double v) { ph.SetParCurrProp(i, v); };
 
     double t0 = now_s();
-    auto splines = std::make_unique<SMonolith>(MasterSpline, SplineType);
+    const std::string dump = "/tmp/m3_dragrace_monolith_" + std::to_string(uint64_t(now_s() * 1e6)) + ".bin";
+    auto splines = std::make_unique<SMonolith>(MasterSpline, SplineType, /*SaveFlatTree=*/true, dump);
     std::vector<const double*> ptrs(P);
     for (int p = 0; p < P; ++p) ptrs[p] = ph.RetPointer(p);
     splines->setSplinePointers(ptrs);
@@ -118,6 +120,19 @@ int main(int argc, char** argv) {
         if (std::fabs(got - w) > 2e-5 * std::fabs(w)) throw MaCh3Exception(__FILE__, __LINE__, "Evaluate() disagrees with Eval() in double");
       }
       std::printf("Evaluate(): event weights agree with TSpline3_red::Eval (double) to 2e-5\n");
+    }
+    {
+      // PrepareSplineFile / LoadSplineFile round trip (ref: SplineMonolith.cpp:454-614): a monolith rebuilt from the
+      // flat dump evaluates to the same bits
+      SMonolith reloaded(dump);
+      std::remove(dump.c_str());
+      reloaded.setSplinePointers(ptrs);
+      reloaded.Evaluate();
+      reloaded.SynchroniseMemTransfer();
+      for (uint64_t e = 0; e < E; ++e)
+        if (std::memcmp(reloaded.retPointer(int(e)), splines->retPointer(int(e)), sizeof(float)) != 0)
+          throw MaCh3Exception(__FILE__, __LINE__, "monolith reloaded from its dump evaluates differently");
+      std::printf("LoadSplineFile(): %llu event weights of the reloaded monolith are bit-identical\n", (unsigned long long)E);
     }
     for (int i = 0; i < nPar; ++i) setpar(i, nominal[i]);
 

@@ -28,4 +28,5 @@ def test_cpp_driver_runs_a_chain():
     assert "agree with TSpline3_red::Eval" in out and "DragRace" in out and out.strip().endswith("OK")
     acc = float(out.split("acceptance ")[1].split(",")[0])
     assert 0.02 < acc < 0.98
-    assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out
+    assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out and "functional parameter" in out
+    assert "reloaded monolith are bit-identical" in out
