@@ -37,13 +37,18 @@ clean:
 .PHONY: all oracle clean isa
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
-examples: build/mr2t2_dragrace build/libm3facade_test.so
+examples: build/mr2t2_dragrace build/facade_check build/libm3facade_test.so
 
 # C shim over the header-only facade for the CPU tests (links libm3hip.so only for the symbols the headers reference)
 build/libm3facade_test.so: tests/cpp/facade_shim.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so
 	@mkdir -p build
 	g++ -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Iinclude -o $@ tests/cpp/facade_shim.cpp -L$(LIBDIR) -lm3hip \
 	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+build/facade_check: examples/facade_check.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -ffp-contract=off -Iinclude -o $@ examples/facade_check.cpp -L$(LIBDIR) -lm3hip \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../mach3_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
 build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
 	@mkdir -p build

@@ -31,7 +31,7 @@ class BinnedSplineHandlerT : public SplineBase {
                        const std::vector<short>& npts, const std::vector<int>& coeffindexvec_,
                        const std::vector<int>& uniquesplinevec_Monolith_, const std::vector<int>& uniquecoeffindices_,
                        const std::vector<FloatT>& xcoeff_arr, const std::vector<FloatT>& manycoeff_arr, int device_id = 0)
-      : gpu(new SMonolithGPU(device_id)), MonolithSize(int(coeffindexvec_.size())) {
+      : gpu(new SMonolithGPU(device_id)), MonolithSize(int(coeffindexvec_.size())), nEvents(n_events) {
     nParams = n_unique_params;
     M3HIP_CALL(gpu->Handle(), Upload(gpu->Handle(), n_events, nParams, max_knots, xpts.data(), npts.data(), MonolithSize, coeffindexvec_.data(),
                                      uniquesplinevec_Monolith_.data(), int(uniquecoeffindices_.size()), uniquecoeffindices_.data(),
@@ -66,7 +66,10 @@ class BinnedSplineHandlerT : public SplineBase {
     M3HIP_CALL(gpu->Handle(), Download(gpu->Handle(), weightvec_Monolith.data(), MonolithSize));
     return weightvec_Monolith;
   }
-  m3hip_handle Handle() const { return gpu->Handle(); }
+  m3hip_handle Handle() const override { return gpu->Handle(); }
+  unsigned int GetNEvents() const override { return nEvents; }
+  /// where the handler's unique spline parameters live in the parameter vector (setSplinePointers)
+  void SetSplineParameterIndices(const std::vector<int32_t>& idx) { M3HIP_CALL(gpu->Handle(), m3hip_set_spline_param_map(gpu->Handle(), idx.data(), int(idx.size()))); }
 
  private:
   template <class... A>
@@ -78,6 +81,7 @@ class BinnedSplineHandlerT : public SplineBase {
 
   std::unique_ptr<SMonolithGPU> gpu;
   int MonolithSize;
+  unsigned int nEvents;
   std::vector<FloatT> weightvec_Monolith;
 };
 

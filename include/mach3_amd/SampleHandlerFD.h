@@ -198,7 +198,7 @@ class SampleHandlerFD : public SampleHandlerBase {
  public:
   /// `Splines` keeps ownership of the device handle; `ParameterValues` plays
   /// ParameterHandlerBase::_fPropVal (read at every Reweight, like the reference's pointers).
-  SampleHandlerFD(std::string Name, std::unique_ptr<SMonolith> Splines, std::unique_ptr<BinningHandler> Bins,
+  SampleHandlerFD(std::string Name, std::unique_ptr<SplineBase> Splines, std::unique_ptr<BinningHandler> Bins,
                   const double* ParameterValues, int nParameters, bool UpdateW2_ = false)
       : SampleName(std::move(Name)), SplineHandler(std::move(Splines)), Binning(std::move(Bins)), fPropVal(ParameterValues),
         nPar(nParameters), UpdateW2(UpdateW2_) {
@@ -221,9 +221,12 @@ class SampleHandlerFD : public SampleHandlerBase {
   /// Samples/SampleHandlerFD.cpp:637-663, 1108-1133).
   void AddEvent(unsigned int iEvent, int Sample, const std::vector<double>& KinVars, const std::vector<int16_t>& NormParams, int OscIndex) {
     if (iEvent != n_added) throw MaCh3Exception(__FILE__, __LINE__, "events must be added in order");
+    // the first GetNDim(Sample) entries are the binning axes; further entries are cut-only columns (AddSelection)
+    const size_t nd = size_t(Binning->GetNDim(Sample));
+    if (KinVars.size() < nd) throw MaCh3Exception(__FILE__, __LINE__, "fewer kinematic variables than binning axes");
     std::vector<const double*> kv;
     std::vector<int> nom;
-    for (size_t d = 0; d < KinVars.size(); ++d) {
+    for (size_t d = 0; d < nd; ++d) {
       kv.push_back(&KinVars[d]);
       nom.push_back(Binning->FindNominalBin(Sample, int(d), KinVars[d]));
     }
@@ -326,7 +329,7 @@ class SampleHandlerFD : public SampleHandlerBase {
     }
   }
   const BinningHandler* GetBinning() const { return Binning.get(); }
-  SMonolith* GetSplineHandler() { return SplineHandler.get(); }
+  SplineBase* GetSplineHandler() { return SplineHandler.get(); }
 
  protected:
   void TestStatisticChanged() override { M3HIP_CALL(h, m3hip_set_test_statistic(h, int(fTestStatistic), UpdateW2 ? 1 : 0)); }
@@ -343,7 +346,7 @@ class SampleHandlerFD : public SampleHandlerBase {
   }
 
   std::string SampleName;
-  std::unique_ptr<SMonolith> SplineHandler;
+  std::unique_ptr<SplineBase> SplineHandler;
   std::unique_ptr<BinningHandler> Binning;
   const double* fPropVal;
   int nPar;

@@ -97,6 +97,11 @@ class SplineBase {
   virtual void PrepareSplineFile(std::string FileName) = 0;
   virtual void LoadSplineFile(std::string FileName) = 0;
   virtual void SynchroniseMemTransfer() const = 0;
+  /// the engine handle behind the operator and the number of MC events it spans: what SampleHandlerFD needs from
+  /// whichever spline handler it was given (event-by-event SMonolith or BinnedSplineHandler, as in the reference
+  /// where SampleHandlerFD holds a unique_ptr<SplineBase>, Samples/SampleHandlerFD.h:214)
+  virtual m3hip_handle Handle() const = 0;
+  virtual unsigned int GetNEvents() const = 0;
 
  protected:
   /// once per step and per PARAMETER, never per event (ref: Splines/SplineBase.cpp:44-109)
@@ -170,8 +175,8 @@ class SMonolith : public SplineBase {
   void setSplinePointers(std::vector<const double*> spline_ParsPointers) {
     for (M3::int_t i = 0; i < nParams; ++i) SplineInfoArray[i].splineParsPointer = spline_ParsPointers[i];
   }
-  unsigned int GetNEvents() const { return NEvents; }
-  m3hip_handle Handle() const { return gpu_spline_handler->Handle(); }
+  unsigned int GetNEvents() const override { return NEvents; }
+  m3hip_handle Handle() const override { return gpu_spline_handler->Handle(); }
 
   /// raw binary dump / reload of the flattened monolith (the reference writes ROOT trees,
   /// ref: SplineMonolith.cpp:454-614)

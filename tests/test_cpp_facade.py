@@ -30,3 +30,16 @@ def test_cpp_driver_runs_a_chain():
     assert 0.02 < acc < 0.98
     assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out and "functional parameter" in out
     assert "reloaded monolith are bit-identical" in out
+
+
+@pytest.mark.gpu
+def test_cpp_facade_binned_double_build_and_box_bins():
+    """examples/facade_check.cpp: BinnedSplineHandlerT<double>, a uniform + a non-uniform sample binned on the
+    device, a selection cut, double oscillation weights -- all through the C++ facade, against a host
+    evaluation in the same program."""
+    exe = os.path.join(ROOT, "build", "facade_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit-identical over 6 steps" in r.stdout and r.stdout.strip().endswith("OK")
