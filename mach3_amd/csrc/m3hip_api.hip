@@ -392,6 +392,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.n_norm_slots = h->M;
   a.n_bins = h->n_bins;
   a.fill_w2 = h->first_w2 ? 1 : 0;
+  a.hist_lds = sizeof(double) * (a.fill_w2 ? 2 : 1) * size_t(h->n_bins) <= size_t(M3_HIST_LDS_MAX_BYTES) ? 1 : 0;
   a.tile_base = 0;
   return a;
 }

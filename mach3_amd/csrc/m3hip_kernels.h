@@ -133,6 +133,9 @@ struct ReweightArgs {
   uint32_t n_norm_slots;     // M
   int32_t n_bins;
   int32_t fill_w2;
+  int32_t hist_lds;          // 1: workgroup-private bin vector in LDS, flushed once (few bins); 0: every event adds
+                             // straight into its workgroup's global replica (thousands of bins: no contention to hide,
+                             // and the LDS would cost occupancy)
   uint32_t tile_base;        // index of the first tile handled by this launch
   BinArgs dyn;               // DYN variants only: the event's bin is recomputed from its shifted kinematics in the
                              // epilogue (functional parameters), instead of being read from `bin`
@@ -227,6 +230,8 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 // float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
+// dynamic LDS of a fill launch and whether the bin vector is privatised there (see ReweightArgs::hist_lds)
+constexpr int M3_HIST_LDS_MAX_BYTES = 20 * 1024;
 void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   const uint32_t lane = threadIdx.x;
   const TileDev td = a.tiles[tile];
 
-  if (MODE & kModeFill) {
+  if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
   }
@@ -409,7 +409,16 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
         b = a.bin[ev];
       }
       // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`
-      if (lane < td.n_events && tw > WT(0) && b >= 0) {
+      const bool fills = lane < td.n_events && tw > WT(0) && b >= 0;
+      const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+      if (!a.hist_lds) {  // many bins: straight into this workgroup's replica
+        if (fills) {
+          atomicAdd(&a.hist[(size_t)rep * a.n_bins + b], (double)tw);
+          if (a.fill_w2) atomicAdd(&a.hist[(size_t)(a.hist_rep + rep) * a.n_bins + b], (double)(tw * tw));
+        }
+        return;
+      }
+      if (fills) {
         atomicAdd(&lds_hist[b], (double)tw);
         if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // square in float_t, then widened (:445)
       }
@@ -417,7 +426,6 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
       const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
       // one flush per workgroup, spread over hist_rep replicas of the bin vector: thousands of
       // workgroups adding into the same few hundred addresses serialise at the memory side
-      const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
       for (int i = lane; i < nb; i += 256) {
         const double v = lds_hist[i];
         const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
@@ -448,7 +456,7 @@ static void launch_mode(const ReweightArgs& a, dim3 g, size_t lds, const Reweigh
 
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
   if (n_tiles == 0) return;
-  size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  size_t lds = ((mode & kModeFill) && a.hist_lds) ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_tiles);
   if (dyn_bins && (mode & kModeFill)) {
@@ -464,7 +472,7 @@ void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, 
 
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s) {
   if (n_tiles == 0) return;
-  const size_t lds = sizeof(double) * 2 * (size_t)a.n_bins;
+  const size_t lds = a.hist_lds ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   const dim3 g(n_tiles), b(256);
   if (mode == kModeFill) M3_LAUNCH((k_reweight_uniform<kModeFill, 8, true, true>), g, b, lds, s, k, a);
   else M3_LAUNCH((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, true>), g, b, lds, s, k, a);
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
       lds_pval[p] = a.pval[p];
     }
   }
-  if (MODE & kModeFill) {
+  if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
@@ -685,13 +693,19 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
           b = a.bin[ev];
         }
         if (e < bd.n_events && tw > 0.f && b >= 0) {
-          atomicAdd(&lds_hist[b], (double)tw);
-          if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
+          if (a.hist_lds) {
+            atomicAdd(&lds_hist[b], (double)tw);
+            if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
+          } else {  // many bins: straight into this workgroup's replica
+            const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+            atomicAdd(&a.hist[(size_t)rep * a.n_bins + b], (double)tw);
+            if (a.fill_w2) atomicAdd(&a.hist[(size_t)(a.hist_rep + rep) * a.n_bins + b], (double)(tw * tw));
+          }
         }
       }
     }
   }
-  if (MODE & kModeFill) {
+  if ((MODE & kModeFill) && a.hist_lds) {
     __syncthreads();
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
@@ -712,7 +726,7 @@ static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const R
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
   if (n_bricks == 0) return;
-  size_t lds = (mode & kModeFill) ? sizeof(double) * 2 * (size_t)a.n_bins : 0;
+  size_t lds = ((mode & kModeFill) && a.hist_lds) ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
   if (dyn_bins && (mode & kModeFill)) {

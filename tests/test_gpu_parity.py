@@ -417,6 +417,63 @@ def test_oscillation_weights_change_every_step(fresh_engine):
     omono.close()
 
 
+@pytest.mark.parametrize("cfg,n_params", [("c2", 24), ("c3", 96)])
+def test_thousands_of_bins(fresh_engine, cfg, n_params):
+    """Bin vectors too large to privatise in LDS (2-D samples: here 3 x 60 x 40 = 7200 global bins): the fill goes
+    straight into the workgroup's global replica; uniform tiles (c2 shape) and bricks (c3 shape), device-side
+    2-D binning, Barlow-Beeston with W2 accumulated on the first step only."""
+    E = 9000
+    spec = synth.CONFIGS[cfg].scaled(E, n_params=n_params)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, E)
+    ev = synth.events_chunk(spec, 0, E)
+    rng = np.random.default_rng(12)
+    ex, ey = np.linspace(0.0, 5.0, 61), np.linspace(-1.0, 1.0, 41)
+    sample_id = rng.integers(0, 3, E).astype(np.int32)
+    kin = np.stack([ev["erec"], rng.uniform(-1.05, 1.05, E)], axis=1)
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    for _ in range(3):
+        b.add_uniform([ex, ey])
+    assert b.n_bins() == 7200
+    par = synth.params(spec, 0)
+    opar = par.copy()
+    omono = ob.OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, ev["norm_off"], ev["norm_idx"], opar, ev["osc_idx"], synth.osc_table(spec), omono)
+    osamp.set_test_statistic(capi.kBarlowBeeston)
+
+    mono = SMonolith(fresh_engine, spec.n_params, spec.n_knots, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    info = fresh_engine.info()
+    assert (info.n_tiles_brick > 0) == (cfg == "c3")
+    sh = SampleHandlerFD(fresh_engine, 3, None, par, capi.kBarlowBeeston, bin_edges=[[ex, ey]] * 3)
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    bins = sh.GetEventBins(0, E)
+    assert np.array_equal(bins, osamp.event_bins())
+    sh.SetupEvents(0, bins, ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+    sh.SetOscillationWeights(synth.osc_table(spec))
+    sh.Reweight()
+    osamp.reweight()
+    assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+    assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2, 3):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+        per = [sh.GetSampleLikelihood(i) for i in range(3)]
+        assert np.isclose(sum(per), llh, rtol=1e-12)
+    osamp.close()
+    omono.close()
+
+
 def _ragged_events(rng, E, P, occ, xs, empty_frac=0.0, tf1_only_frac=0.0):
     events = []
     for _ in range(E):
