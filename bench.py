@@ -156,7 +156,8 @@ def main():
         local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks share the card
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_comm = os.environ.get("M3_BENCH_FORCE_COMM") == "1"  # rehearsal: run the N > 1 plumbing with one rank
+    if world > 1 or force_comm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("M3_BENCH_BACKEND", "nccl")  # "gloo": plumbing rehearsal on one GPU
@@ -179,7 +180,7 @@ def main():
             f"{info.n_tiles_brick}b, setup {time.perf_counter() - t_setup:.1f} s")
 
     comm_mode = "none"
-    if world > 1 and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
+    if (world > 1 or force_comm) and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
         # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
         try:
             uid = [eng.comm_unique_id() if rank == 0 else None]
