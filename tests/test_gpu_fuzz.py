@@ -1,0 +1,125 @@
+"""Seeded random shapes through the whole fused step, against the oracle: event counts that are not multiples of
+anything, parameters with 3 / 5 / 7 knots or TF1 or nothing, uniform and ragged groups in one sample, events with
+no response, several samples, few and many bins, every test statistic, W2 frozen or updated.  The cases are
+deterministic (the seed is the test id); they are meant to find corner cases the hand-written tests miss."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from helpers import make_monolith, natural_cubic
+from mach3_amd import capi, synth
+from mach3_amd.engine import SMonolith, SampleHandlerFD
+
+pytestmark = pytest.mark.gpu
+
+RTOL_BIN = 1e-12
+RTOL_LLH = 1e-9
+KNOTS = {3: np.array([-1.0, 0.0, 1.0]), 5: np.array([-2.0, -1.0, 0.0, 1.0, 2.0]), 7: np.arange(-3.0, 4.0)}
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.integers(1, 60))
+    E = int(rng.integers(1, max(2, min(6000, 90_000 // P))))
+    kinds = rng.choice(["s3", "s5", "s7", "tf1", "none"], P, p=[0.15, 0.15, 0.3, 0.3, 0.1])
+    xs = {p: KNOTS[int(k[1])] for p, k in enumerate(kinds) if k[0] == "s"}
+    shape = rng.choice(["uniform", "ragged", "blocks"])
+    occ = float(rng.uniform(0.05, 0.95))
+    block_lists = [rng.random(P) < occ for _ in range(4)]
+    events = []
+    for e in range(E):
+        if shape == "uniform":
+            mask = np.ones(P, bool)
+        elif shape == "ragged":
+            mask = rng.random(P) < occ
+            if rng.random() < 0.1:
+                mask[:] = False
+        else:  # runs of events that share a list (uniform tiles) next to ragged stretches
+            blk = (e // 1500) % 5
+            mask = block_lists[blk] if blk < 4 else rng.random(P) < occ
+        ev = []
+        for p in range(P):
+            if not mask[p] or kinds[p] == "none":
+                continue
+            if p in xs:
+                ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))))
+            else:
+                ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0 + 0.01 * rng.standard_normal())))
+        events.append(ev)
+    n_samples = int(rng.integers(1, 4))
+    nb = int(rng.choice([3, 17, 200, 1500]))
+    n_norm = int(rng.integers(0, 5))
+    stat = int(rng.integers(0, 5))
+    return dict(rng=rng, P=P, E=E, xs=xs, events=events, n_samples=n_samples, nb=nb, n_norm=n_norm, stat=stat,
+                update_w2=bool(rng.random() < 0.3), use_osc=bool(rng.random() < 0.7), shape=str(shape))
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_shape(fresh_engine, seed):
+    c = _case(seed)
+    rng, P, E = c["rng"], c["P"], c["E"]
+    cx, npts, ch = make_monolith(P, 7, c["xs"], c["events"])
+    nPar = P + c["n_norm"]
+    par = np.zeros(nPar)
+    par[P:] = 1.0
+    opar = par.copy()
+    edges = np.linspace(0.0, 5.0, c["nb"] + 1)
+    kin = rng.gamma(3.0, 0.45, E)
+    kin[: min(E, 5)] = rng.choice(edges, min(E, 5))          # exactly on edges
+    sample_id = rng.integers(0, c["n_samples"], E).astype(np.int32)
+    nn = rng.integers(0, 3, E) if c["n_norm"] else np.zeros(E, np.int64)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = (P + rng.integers(0, max(c["n_norm"], 1), int(norm_off[-1]))).astype(np.int16)
+    osc = rng.random(40).astype(np.float32)
+    osc[3] = 0.0
+    osc_idx = rng.integers(-1, 40, E).astype(np.int32) if c["use_osc"] else None
+
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    for _ in range(c["n_samples"]):
+        b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc if c["use_osc"] else None, omono)
+    osamp.set_test_statistic(c["stat"], c["update_w2"])
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    off = (np.arange(c["n_samples"] + 1) * c["nb"]).astype(np.int32)
+    sh = SampleHandlerFD(fresh_engine, c["n_samples"], off, par, c["stat"], update_w2=c["update_w2"])
+    bins = synth.find_global_bin_uniform_1d(edges, kin, sample_id, c["nb"])
+    assert np.array_equal(bins, osamp.event_bins())
+    sh.SetupEvents(0, bins, osc_idx, norm_off, norm_idx)
+    if c["use_osc"]:
+        sh.SetOscillationWeights(osc)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    data = np.round(osamp.mc * rng.uniform(0.8, 1.2, len(osamp.mc)))
+    sh.AddData(data)
+    osamp.add_data(data)
+    tag = (seed, c["shape"], P, E, c["nb"], c["stat"])
+    for lap in range(3):
+        par[:P] = rng.uniform(-3.6, 3.6, P)
+        if lap == 1 and P > 1:
+            par[0], par[1] = -1.0, 2.0                      # exact knots
+        par[P:] = 1 + 0.1 * rng.standard_normal(c["n_norm"])
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetSplineWeights(0, E).view(np.uint32), omono.total_weights.view(np.uint32)), tag
+        assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32)), tag
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), tag
+        assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0), tag
+        want = osamp.get_likelihood()
+        if np.isfinite(want):
+            assert abs(llh - want) <= RTOL_LLH * max(abs(want), 1.0) or (c["stat"] == capi.kIceCube and abs(llh - want) <= 1e-6 * max(abs(want), 1.0)), (tag, llh, want)
+        else:
+            assert not np.isfinite(llh) or llh > 1e200, (tag, llh, want)
+    # seam 2 on the same monolith
+    mono.Evaluate()
+    mono.SynchroniseMemTransfer()
+    omono.evaluate()
+    assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32)), tag
+    osamp.close()
+    omono.close()
