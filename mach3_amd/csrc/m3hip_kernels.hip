@@ -487,7 +487,8 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
 // staging array; phase B lets every event multiply its slice in ascending parameter order.
 // HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
 // ------------------------------------------------------------------------------------
-constexpr int kBrickThreads = 512;                               // 2 workgroups per CU (~61 KiB LDS, <= 128 VGPRs)
+constexpr int kBrickThreads = 1024;                              // one event per lane; 2 workgroups per CU = 8 waves per SIMD
+constexpr int kBrickBatchDefault = 4;                             // coefficient loads in flight per lane: 8 would need > 64 VGPRs (spills)
 constexpr int kBrickEvPerLane = M3_GROUP / kBrickThreads;         // events per lane in phase B
 constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;   // responses per lane and stage
 constexpr int kBrickMaxStages = M3_BRICK_MAX_STAGES;
@@ -501,13 +502,16 @@ struct RRun {      // per-step resolved run: address = base + r, dx of the run's
 };
 
 // Latency structure.  Per stage only the coefficient loads sit on the critical path, kBrickBatch per
-// lane in flight at once (8: two round trips for a full stage).  Everything a stage
+// lane in flight at once (4: two round trips for a full stage of 8 responses per lane).  With one event per
+// lane the kernel fits 64 VGPRs, so two 1024-lane workgroups give every SIMD its full 8 waves: the loads of
+// one wave hide behind the LDS phases and barriers of the others (512-lane workgroups at 122 VGPRs, i.e. 4
+// waves per SIMD, were 9-12 % slower).  Everything a stage
 // needs before it can issue them -- its response words, event slices and run entries -- is requested
 // right after the previous stage's loads were consumed and arrives under that stage's barrier and
 // phase B; the run entries are resolved against the per-step parameter table, which lives in LDS, so
 // no second global round trip hides in the resolution.
 template <int MODE, bool NT, int kBrickBatch, bool DYN = false>
-__global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArgs a) {
+__global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
   __shared__ float stage_w[M3_BRICK_CAP];
   __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
   __shared__ uint32_t lds_hdr[1 + M3_STAGE_HDR * kBrickMaxStages];
@@ -719,9 +723,8 @@ __global__ __launch_bounds__(kBrickThreads, 4) void k_reweight_brick(ReweightArg
 
 template <int MODE>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  // 8 coefficient loads per lane in flight (two round trips per stage); 16 would need > 128 VGPRs and spills
-  if (k.nt) M3_LAUNCH((k_reweight_brick<MODE, true, 8>), g, dim3(kBrickThreads), lds, s, k, a);
-  else M3_LAUNCH((k_reweight_brick<MODE, false, 8>), g, dim3(kBrickThreads), lds, s, k, a);
+  if (k.nt) M3_LAUNCH((k_reweight_brick<MODE, true, kBrickBatchDefault>), g, dim3(kBrickThreads), lds, s, k, a);
+  else M3_LAUNCH((k_reweight_brick<MODE, false, kBrickBatchDefault>), g, dim3(kBrickThreads), lds, s, k, a);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
@@ -730,8 +733,8 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
   if (dyn_bins && (mode & kModeFill)) {
-    if (mode == kModeFill) M3_LAUNCH((k_reweight_brick<kModeFill, true, 8, true>), g, dim3(kBrickThreads), lds, s, k, a);
-    else M3_LAUNCH((k_reweight_brick<kModeFill | kModeEval | kModeEventW, true, 8, true>), g, dim3(kBrickThreads), lds, s, k, a);
+    if (mode == kModeFill) M3_LAUNCH((k_reweight_brick<kModeFill, true, kBrickBatchDefault, true>), g, dim3(kBrickThreads), lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<kModeFill | kModeEval | kModeEventW, true, kBrickBatchDefault, true>), g, dim3(kBrickThreads), lds, s, k, a);
     return;
   }
   if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
