@@ -553,7 +553,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
       const uint32_t e = lane * kBrickEvPerLane + q;
-      ec_n[q] = words[h[5] + (e < bd.n_events ? e : 0u)];
+      const uint16_t* __restrict__ st16 = reinterpret_cast<const uint16_t*>(words + h[5]);
+      ec_n[q] = (uint32_t)st16[e] | ((uint32_t)st16[e + 1] << 16);  // {start, end}; events past the last one get empty slices
     }
     if (kind == 0) {
       const uint32_t* __restrict__ resp = words + h[4];
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     // phase B: the event's slice of the staging array, ascending parameter = reference order
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
-      const uint32_t start = ec[q] & 0xFFFFu, cnt = ec[q] >> 16;
+      const uint32_t start = ec[q] & 0xFFFFu, cnt = (ec[q] >> 16) - start;
       uint32_t i = 0;
       for (; i + 4 <= cnt; i += 4) {  // four LDS reads in flight; the product itself stays sequential
         const float v0 = stage_w[start + i], v1 = stage_w[start + i + 1], v2 = stage_w[start + i + 2], v3 = stage_w[start + i + 3];

@@ -52,7 +52,9 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 //                            start_r (first response of the run in the stage), param}
 //   off_resp  TSpline3: n_resp words {run : 16 | dst << 16}; TF1: n_resp parameters packed two
 //             per word (low half first)
-//   off_evt   n_events words {start : 16 | count << 16}: the event's slice of the staging array
+//   off_evt   M3_EVT_WORDS words = M3_GROUP + 2 uint16, two per word (low half first): start[e] of the
+//             event's slice of the staging array; its length is start[e + 1] - start[e]; entries past
+//             the brick's last event repeat the total, so those events have empty slices
 //   coef_off  TF1 only: float2 index of the stage's first {a,b} in the brick's TF1 store
 // ------------------------------------------------------------------------------------
 bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_t e0, uint64_t e1, BrickHost* bh,
@@ -137,6 +139,14 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
   bh->spl_src.reserve(S);
   uint32_t stage = 0;
   std::vector<uint32_t> ev_cnt(ne), ev_start(ne), ev_cur(ne);
+  // the stage's slice starts as uint16 (a stage holds <= 8192 responses), padded with the total
+  auto push_evt = [&](std::vector<uint32_t>& out, const std::vector<uint32_t>& start, uint32_t total) {
+    for (uint32_t i = 0; i < uint32_t(M3_EVT_WORDS); ++i) {
+      const uint32_t e_lo = 2 * i, e_hi = 2 * i + 1;
+      const uint32_t lo = e_lo < ne ? start[e_lo] : total, hi = e_hi < ne ? start[e_hi] : total;
+      out.push_back((lo & 0xFFFFu) | (hi << 16));
+    }
+  };
   for (const Range& rg : st_s) {
     const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
     // event-major staging slots
@@ -176,7 +186,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
     w.insert(w.end(), resp.begin(), resp.end());
     h = &w[1 + size_t(M3_STAGE_HDR) * stage];
     h[5] = uint32_t(w.size());
-    for (uint32_t e = 0; e < ne; ++e) w.push_back((ev_start[e] & 0xFFFFu) | (ev_cnt[e] << 16));
+    push_evt(w, ev_start, n_resp);
     ++stage;
   }
   bh->n_spl_f4 = spl_f4;
@@ -208,7 +218,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
     for (uint32_t i = 0; i < n_resp; i += 2) w.push_back(params[i] | ((i + 1 < n_resp ? params[i + 1] : 0u) << 16));
     h = &w[1 + size_t(M3_STAGE_HDR) * stage];
     h[5] = uint32_t(w.size());
-    for (uint32_t e = 0; e < ne; ++e) w.push_back((ev_start[e] & 0xFFFFu) | (ev_cnt[e] << 16));
+    push_evt(w, ev_start, n_resp);
     h = &w[1 + size_t(M3_STAGE_HDR) * stage];
     h[6] = uint32_t(tf1_f2);
     tf1_f2 += n_resp;

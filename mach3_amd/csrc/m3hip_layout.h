@@ -40,6 +40,7 @@ constexpr int M3_BRICK_CAP = 8192;  // responses per brick stage (= floats of LD
 constexpr int M3_BRICK_MAX_RUNS = 1024;  // runs per stage (resolved run table lives in LDS)
 constexpr int M3_BRICK_MAX_STAGES = 30;  // stage headers are staged in LDS
 constexpr int M3_STAGE_HDR = 8;     // words per stage header
+constexpr int M3_EVT_WORDS = M3_GROUP / 2 + 1;  // per stage: M3_GROUP + 2 uint16 slice starts, two per word
 constexpr int M3_RUN_WORDS = 4;     // words per run entry
 
 enum TileKind : uint32_t { kTileUniform = 0, kTileBrick = 1 };

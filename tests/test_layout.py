@@ -133,10 +133,10 @@ def brick_event_lists(npts, ch, lay, b):
             par = w[int(h[4]): int(h[4]) + (n_resp + 1) // 2].view(np.uint16)[:n_resp]
             for r in range(n_resp):
                 stage[r] = (int(par[r]), "tf1", tf1[tf1_off + int(h[6]) + r])
-        evt = w[int(h[5]): int(h[5]) + nev]
+        starts = w[int(h[5]): int(h[5]) + 1024 // 2 + 1].view(np.uint16)
+        assert len(starts) == 1026 and all(int(v) == n_resp for v in starts[nev:])
         for e in range(nev):
-            start, cnt = int(evt[e]) & 0xFFFF, int(evt[e]) >> 16
-            out[e] += stage[start: start + cnt]
+            out[e] += stage[int(starts[e]): int(starts[e + 1])]
         assert all(x is not None for x in stage)
     return e0, out
 
