@@ -1,0 +1,29 @@
+"""Soak: many fused steps in one process; reports latency percentiles per block of steps and the process RSS, to catch
+leaks (host command lists, events) and drifts.  usage: soak.py [events] [steps]"""
+import sys, os, time, resource
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0,ROOT)
+import numpy as np
+from mach3_amd import synth
+from mach3_amd.engine import build_from_synth
+ev = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+spec = synth.CONFIGS["c2"].scaled(ev, n_params=32)
+eng, mono, sh, par = build_from_synth(spec)
+sh.Reweight(); sh.AddData(sh.GetMCArray())
+laps=[synth.params(spec,i+1) for i in range(64)]
+def rss_mb():
+    with open("/proc/self/statm") as f: return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
+blk = steps // 10
+llh0 = None
+for b in range(10):
+    ts = np.empty(blk)
+    for i in range(blk):
+        t0 = time.perf_counter(); par[:] = laps[i % 64]; l = sh.Step(); ts[i] = time.perf_counter() - t0
+        if i % 64 == 0:
+            if llh0 is None: llh0 = l
+            assert l == llh0, (l, llh0)   # same parameters -> bit-identical likelihood, every time
+    ts *= 1e6
+    free, total = eng.mem_info() if hasattr(eng, "mem_info") else (0, 0)
+    print(f"block {b}: {blk} steps, median {np.median(ts):.1f} us, p99 {np.percentile(ts,99):.1f}, p99.9 {np.percentile(ts,99.9):.1f}, max {ts.max():.0f} us, RSS {rss_mb():.0f} MB", flush=True)
+print("OK")
