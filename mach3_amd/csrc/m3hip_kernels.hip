@@ -232,21 +232,26 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 // coefficient planes are read exactly once per launch: NT marks them streaming so they do
 // not displace the small, hot per-step tables in L2
+// Pointers that reach a kernel inside a descriptor loaded from memory (TileDev / BrickDev) are generic ("flat")
+// to the compiler: it then emits flat_load (which also ties up the LDS counter) and cannot use scalar loads for
+// wave-uniform reads.  These stores all live in device global memory, so say so.
+#define M3_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const M3_GLOBAL T* as_global(const T* p) {
+  return (const M3_GLOBAL T*)p;
+}
+
 template <bool NT>
 __device__ __forceinline__ float4 stream_load(const float4* p) {
-  if (NT) {
-    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
-  return *p;
+  const M3_GLOBAL f32x4_t* g = (const M3_GLOBAL f32x4_t*)p;
+  const f32x4_t v = NT ? __builtin_nontemporal_load(g) : *g;
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 template <bool NT>
 __device__ __forceinline__ float2 stream_load(const float2* p) {
-  if (NT) {
-    const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
-    return make_float2(v.x, v.y);
-  }
-  return *p;
+  const M3_GLOBAL f32x2_t* g = (const M3_GLOBAL f32x2_t*)p;
+  const f32x2_t v = NT ? __builtin_nontemporal_load(g) : *g;
+  return make_float2(v.x, v.y);
 }
 
 // Per-event gathers of the fused epilogue, batched so that several independent loads are in
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
   float w = 1.0f;  // SplineMonolith.cpp:798
   {
     const float4* __restrict__ sp = td.spl + lane;
-    const RSlot* __restrict__ rs = td.res;
+    const M3_GLOBAL RSlot* __restrict__ rs = as_global(td.res);
     const uint32_t J = td.n_spl_slots;
     uint32_t j = 0;
     for (; j + UNROLL <= J; j += UNROLL) {
@@ -348,7 +353,9 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
       float dx[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const RSlot r = rs[j + u];
+        RSlot r;
+        r.plane = rs[j + u].plane;
+        r.f = rs[j + u].f;
         c[u] = stream_load<NT>(&sp[(size_t)(uint32_t)r.plane * M3_TE]);
         dx[u] = r.f;
       }
@@ -356,13 +363,15 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
       for (int u = 0; u < UNROLL; ++u) w *= spline_poly(dx[u], c[u]);
     }
     for (; j < J; ++j) {
-      const RSlot r = rs[j];
+      RSlot r;
+      r.plane = rs[j].plane;
+      r.f = rs[j].f;
       w *= spline_poly(r.f, stream_load<NT>(&sp[(size_t)(uint32_t)r.plane * M3_TE]));
     }
   }
   {
     const float2* __restrict__ tp = td.tf1 + lane;
-    const RSlot* __restrict__ rt = td.res + td.n_spl_slots;
+    const M3_GLOBAL RSlot* __restrict__ rt = as_global(td.res) + td.n_spl_slots;
     const uint32_t J = td.n_tf1_slots;
     uint32_t j = 0;
     for (; j + UNROLL <= J; j += UNROLL) {
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
-  const uint32_t* __restrict__ words = bd.words;
+  const M3_GLOBAL uint32_t* __restrict__ words = as_global(bd.words);
   const bool tab_in_lds = a.n_params <= kBrickLdsParams;  // kernel-uniform
 
   // all stage headers and the per-step parameter table in one round trip
@@ -553,25 +562,27 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 #pragma unroll
     for (int q = 0; q < kBrickEvPerLane; ++q) {
       const uint32_t e = lane * kBrickEvPerLane + q;
-      const uint16_t* __restrict__ st16 = reinterpret_cast<const uint16_t*>(words + h[5]);
+      const M3_GLOBAL uint16_t* __restrict__ st16 = (const M3_GLOBAL uint16_t*)(words + h[5]);
       ec_n[q] = (uint32_t)st16[e] | ((uint32_t)st16[e + 1] << 16);  // {start, end}; events past the last one get empty slices
     }
     if (kind == 0) {
-      const uint32_t* __restrict__ resp = words + h[4];
+      const M3_GLOBAL uint32_t* __restrict__ resp = words + h[4];
 #pragma unroll
       for (int u = 0; u < kBrickRespPerLane; ++u) {
         const uint32_t r = lane + u * kBrickThreads;
         m_n[u] = resp[r < n_resp ? r : last];
       }
-      const uint4* __restrict__ runs = reinterpret_cast<const uint4*>(words + h[3]);
+      const M3_GLOBAL uint32_t* __restrict__ runs = words + h[3];  // 4 words per run
       const uint32_t n_runs = h[2];
 #pragma unroll
       for (int u = 0; u < kBrickRunsPerLane; ++u) {
         const uint32_t r = lane + u * kBrickThreads;
-        rt_n[u] = runs[r < n_runs ? r : n_runs - 1];
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = *(const M3_GLOBAL u32x4_t*)(runs + 4 * (size_t)(r < n_runs ? r : n_runs - 1));
+        rt_n[u] = make_uint4(v.x, v.y, v.z, v.w);
       }
     } else {
-      const uint16_t* __restrict__ par = reinterpret_cast<const uint16_t*>(words + h[4]);
+      const M3_GLOBAL uint16_t* __restrict__ par = (const M3_GLOBAL uint16_t*)(words + h[4]);
 #pragma unroll
       for (int u = 0; u < kBrickRespPerLane; ++u) {
         const uint32_t r = lane + u * kBrickThreads;
