@@ -287,6 +287,8 @@ typedef struct {
   uint64_t alg_bytes_eval;  /* 16*S + 8*T + 4*E : algorithmic bytes of one spline-eval launch */
   uint64_t alg_bytes_fused; /* 16*S + 8*T + 8*E : ... of one fused reweight launch */
   int n_params, max_knots, n_bins, n_samples;
+  uint64_t n_tiles_padded;  /* uniform tiles that hold identity-padded ragged events (counted in n_tiles_uniform) */
+  uint64_t pad_responses;   /* identity responses added by that padding (TSpline3 + TF1); not in n_splines / n_tf1 */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

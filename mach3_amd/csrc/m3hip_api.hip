@@ -73,7 +73,7 @@ struct m3hip_ctx {
   int16_t* d_npts = nullptr;
   bool mono_open = false, mono_done = false;
   uint64_t E = 0, S = 0, T = 0, coeff_bytes = 0, E_pad = 0;
-  uint64_t n_uniform = 0, n_brick = 0;
+  uint64_t n_uniform = 0, n_brick = 0, n_padded = 0, pad_responses = 0;
   std::vector<Chunk> chunks;
   std::vector<TileDev> h_tiles;
   TileDev* d_tiles = nullptr;
@@ -334,7 +334,7 @@ void free_monolith(m3hip_handle h) {
   if (h->h_segs) { (void)hipHostFree(h->h_segs); h->h_segs = nullptr; }
   h->M = 0;
   h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
-  h->n_uniform = h->n_brick = 0;
+  h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
   h->parmap_set = false;
 }
@@ -548,6 +548,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   in.npe_tf1 = n_param_per_event_tf1;
   ChunkPlan plan;
   std::string err;
+  { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
   if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
   // host staging (pinned) -> device
@@ -620,6 +621,8 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   }
   h->n_uniform += plan.n_uniform;
   h->n_brick += plan.n_brick;
+  h->n_padded += plan.n_padded;
+  h->pad_responses += plan.pad_spl + plan.pad_tf1;
   h->E += n_events;
   h->S += n_splines;
   h->T += n_tf1;
@@ -1743,6 +1746,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   in.npe_tf1 = n_param_per_event_tf1;
   ChunkPlan plan;
   std::string err;
+  { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
   if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err)) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
   sizes[0] = plan.tiles.size();
   sizes[1] = plan.spl_float4;
@@ -1785,6 +1789,8 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
   out->max_knots = h->K;
   out->n_bins = h->n_bins;
   out->n_samples = h->n_samples;
+  out->n_tiles_padded = h->n_padded;
+  out->pad_responses = h->pad_responses;
   return M3HIP_OK;
 }
 

@@ -30,6 +30,38 @@ void parallel_for(uint64_t n, F&& body) {
 }
 
 // true when events [e0, e1) all carry the parameter lists of event e0
+// Ascending union of the tile's spline / TF1 parameters and the fill fraction of the padded tile.  Returns false
+// when an event does not list its parameters in ascending order (then the per-event merge below cannot keep
+// the event's own product order).
+bool tile_union(int n_params, const int16_t* npts, const ChunkInput& in, uint64_t e0, uint64_t e1, std::vector<int16_t>* us,
+                std::vector<int16_t>* ut, double* fill) {
+  std::vector<uint8_t> seen_s(size_t(n_params), 0), seen_t(size_t(n_params), 0);
+  double real_bytes = 0;
+  for (uint64_t e = e0; e < e1; ++e) {
+    const unsigned int c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
+    for (unsigned int i = 0; i < c; ++i) {
+      if (i && in.param_no[s0 + i] <= in.param_no[s0 + i - 1]) return false;
+      seen_s[size_t(in.param_no[s0 + i])] = 1;
+    }
+    const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+    for (unsigned int i = 0; i < ct; ++i) {
+      if (i && in.param_no_tf1[t0 + i] <= in.param_no_tf1[t0 + i - 1]) return false;
+      seen_t[size_t(in.param_no_tf1[t0 + i])] = 1;
+    }
+    real_bytes += 16.0 * c + 8.0 * ct;
+  }
+  us->clear();
+  ut->clear();
+  for (int p = 0; p < n_params; ++p) {
+    if (seen_s[size_t(p)]) us->push_back(int16_t(p));
+    if (seen_t[size_t(p)]) ut->push_back(int16_t(p));
+  }
+  (void)npts;
+  const double padded_bytes = double(e1 - e0) * (16.0 * double(us->size()) + 8.0 * double(ut->size()));
+  *fill = padded_bytes > 0 ? real_bytes / padded_bytes : 1.0;
+  return true;
+}
+
 bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
   const unsigned int c0 = in.npe[2 * e0], s0 = in.npe[2 * e0 + 1];
   const unsigned int t0c = in.npe_tf1[2 * e0], t0s = in.npe_tf1[2 * e0 + 1];
@@ -255,6 +287,8 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
 
 }  // namespace
 
+double g_pad_min_fill = kPadMinFillDefault;
+
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
                 std::string* err) {
   plan->tiles.clear();
@@ -296,15 +330,26 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
 
   // ---- tiles: classify per group of M3_GROUP events
   const uint64_t n_tiles = (in.n_events + M3_TE - 1) / M3_TE;
-  std::vector<uint8_t> uniform(n_tiles, 0);
+  std::vector<uint8_t> uniform(n_tiles, 0);  // 1: every event carries the same list; 2: paddable to the union list
+  std::vector<std::vector<int16_t>> uni_s(n_tiles), uni_t(n_tiles);
   parallel_for(n_tiles, [&](uint64_t t) {
     const uint64_t e0 = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, e0 + M3_TE);
-    uniform[t] = tile_is_uniform(in, e0, e1) ? 1 : 0;
+    if (tile_is_uniform(in, e0, e1)) {
+      uniform[t] = 1;
+      const unsigned int c = in.npe[2 * e0], s0 = in.npe[2 * e0 + 1], ct = in.npe_tf1[2 * e0], t0 = in.npe_tf1[2 * e0 + 1];
+      uni_s[t].assign(in.param_no + s0, in.param_no + s0 + c);
+      uni_t[t].assign(in.param_no_tf1 + t0, in.param_no_tf1 + t0 + ct);
+    } else {
+      double fill = 0;
+      if (tile_union(n_params, npts, in, e0, e1, &uni_s[t], &uni_t[t], &fill) && fill >= g_pad_min_fill) uniform[t] = 2;
+    }
   });
   const uint64_t n_groups = (in.n_events + M3_GROUP - 1) / M3_GROUP;
   const uint64_t tiles_per_group = M3_GROUP / M3_TE;
   plan->bricks.clear();
   plan->brick_words.clear();
+  plan->tile_params.clear();
+  plan->n_padded = plan->pad_spl = plan->pad_tf1 = 0;
   for (uint64_t g = 0; g < n_groups; ++g) {
     const uint64_t t0 = g * tiles_per_group, t1 = std::min<uint64_t>(n_tiles, t0 + tiles_per_group);
     bool all_uniform = true;
@@ -316,11 +361,21 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
         th.first_event = e0;
         th.n_events = uint32_t(e1 - e0);
         th.kind = kTileUniform;
-        th.n_spl_slots = in.npe[2 * e0];
-        th.n_tf1_slots = in.npe_tf1[2 * e0];
+        th.padded = uniform[t] == 2 ? 1u : 0u;
+        th.n_spl_slots = uint32_t(uni_s[t].size());
+        th.n_tf1_slots = uint32_t(uni_t[t].size());
+        th.list_off = plan->tile_params.size();
+        plan->tile_params.insert(plan->tile_params.end(), uni_s[t].begin(), uni_s[t].end());
+        plan->tile_params.insert(plan->tile_params.end(), uni_t[t].begin(), uni_t[t].end());
         uint64_t planes = 0;
-        const unsigned int s0 = in.npe[2 * e0 + 1];
-        for (uint32_t j = 0; j < th.n_spl_slots; ++j) planes += uint64_t(npts[in.param_no[s0 + j]] - 1);
+        for (uint32_t j = 0; j < th.n_spl_slots; ++j) planes += uint64_t(npts[uni_s[t][j]] - 1);
+        if (th.padded) {
+          plan->n_padded++;
+          for (uint64_t e = e0; e < e1; ++e) {
+            plan->pad_spl += th.n_spl_slots - in.npe[2 * e];
+            plan->pad_tf1 += th.n_tf1_slots - in.npe_tf1[2 * e];
+          }
+        }
         th.n_planes = planes;
         th.spl_off = plan->spl_float4;
         th.tf1_off = plan->tf1_float2;
@@ -352,8 +407,8 @@ void fill_chunk(int /*n_params*/, const int16_t* npts, const ChunkInput& in, con
     const TileHost& th = plan.tiles[t];
     if (th.kind != kTileUniform) return;
     const uint64_t e0 = th.first_event;
-    const unsigned int s0 = in.npe[2 * e0 + 1];
-    const unsigned int t0 = in.npe_tf1[2 * e0 + 1];
+    const int16_t* list_s = plan.tile_params.data() + th.list_off;
+    const int16_t* list_t = list_s + th.n_spl_slots;
     int32_t* m = meta + th.meta_off;
     float* tile_spl = spl + 4 * th.spl_off;
     float* tile_tf1 = tf1 + 2 * th.tf1_off;
@@ -361,27 +416,38 @@ void fill_chunk(int /*n_params*/, const int16_t* npts, const ChunkInput& in, con
     uint64_t plane0 = 0;
     std::vector<uint32_t> slot_plane(th.n_spl_slots), slot_nseg(th.n_spl_slots);
     for (uint32_t j = 0; j < th.n_spl_slots; ++j) {
-      const int p = in.param_no[s0 + j];
+      const int p = list_s[j];
       m[2 * j] = p;
       m[2 * j + 1] = int32_t(plane0);
       slot_plane[j] = uint32_t(plane0);
       slot_nseg[j] = uint32_t(npts[p] - 1);
       plane0 += slot_nseg[j];
     }
-    for (uint32_t j = 0; j < th.n_tf1_slots; ++j) m[2 * th.n_spl_slots + j] = in.param_no_tf1[t0 + j];
-    // coefficients: event-major AoS records -> [plane][lane] float4
+    for (uint32_t j = 0; j < th.n_tf1_slots; ++j) m[2 * th.n_spl_slots + j] = list_t[j];
+    static const float kIdentitySpl[4] = {1.f, 0.f, 0.f, 0.f};  // y = 1, b = c = d = 0: the cubic is exactly 1.0f
+    static const float kIdentityTf1[2] = {0.f, 1.f};            // a = 0, b = 1: fmaf(0, x, 1) is exactly 1.0f
+    // coefficients: event-major AoS records -> [plane][lane] float4.  The event's own list is merged into the
+    // tile's list (both ascending for a padded tile; identical for an exactly uniform one): a slot the event
+    // does not have gets the identity response, which leaves its float product bit for bit unchanged.
     for (uint32_t le = 0; le < uint32_t(M3_TE); ++le) {
       if (le < th.n_events) {
         const uint64_t e = e0 + le;
-        const unsigned int se = in.npe[2 * e + 1];
+        const unsigned int se = in.npe[2 * e + 1], ce = in.npe[2 * e];
+        unsigned int i = 0;
         for (uint32_t j = 0; j < th.n_spl_slots; ++j) {
-          const float* src = in.coeff_many + 4ull * in.nknots_arr[se + j];
           float* dst = tile_spl + (uint64_t(slot_plane[j]) * M3_TE + le) * 4;
-          for (uint32_t k = 0; k < slot_nseg[j]; ++k) std::memcpy(dst + uint64_t(k) * M3_TE * 4, src + 4 * k, 16);
+          const bool has = i < ce && in.param_no[se + i] == list_s[j];
+          const float* src = has ? in.coeff_many + 4ull * in.nknots_arr[se + i] : nullptr;
+          for (uint32_t k = 0; k < slot_nseg[j]; ++k) std::memcpy(dst + uint64_t(k) * M3_TE * 4, has ? src + 4 * k : kIdentitySpl, 16);
+          i += has;
         }
-        const unsigned int te = in.npe_tf1[2 * e + 1];
-        for (uint32_t j = 0; j < th.n_tf1_slots; ++j)
-          std::memcpy(tile_tf1 + (uint64_t(j) * M3_TE + le) * 2, in.coeff_tf1 + 2ull * (te + j), 8);
+        const unsigned int te = in.npe_tf1[2 * e + 1], cte = in.npe_tf1[2 * e];
+        i = 0;
+        for (uint32_t j = 0; j < th.n_tf1_slots; ++j) {
+          const bool has = i < cte && in.param_no_tf1[te + i] == list_t[j];
+          std::memcpy(tile_tf1 + (uint64_t(j) * M3_TE + le) * 2, has ? in.coeff_tf1 + 2ull * (te + i) : kIdentityTf1, 8);
+          i += has;
+        }
       } else {
         // padding lanes of the last tile: neutral response (weight 1)
         for (uint64_t pl = 0; pl < th.n_planes; ++pl) {

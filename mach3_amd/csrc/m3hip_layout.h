@@ -56,6 +56,11 @@ struct TileHost {
   uint32_t kind = kTileUniform;
   uint64_t n_planes = 0;  // spline planes in the tile (sum of segments over slots)
   uint64_t first_event = 0;  // chunk-local index of lane 0
+  // the tile's ordered slot lists (parameters), in ChunkPlan::tile_params: [n_spl_slots] then [n_tf1_slots].
+  // For an exactly uniform tile this is every event's own list; for a PADDED tile it is the ascending union
+  // over the tile's events, and an event that lacks a parameter gets the identity response in that slot.
+  uint64_t list_off = 0;
+  uint32_t padded = 0;
 };
 
 // Host-side brick descriptor.
@@ -93,7 +98,16 @@ struct ChunkPlan {
   uint64_t n_uniform = 0, n_brick = 0;
   std::vector<BrickHost> bricks;
   std::vector<uint32_t> brick_words;  // metadata streams of all bricks, concatenated
+  std::vector<int16_t> tile_params;   // slot lists of all uniform tiles, concatenated (TileHost::list_off)
+  uint64_t n_padded = 0, pad_spl = 0, pad_tf1 = 0;  // padded tiles and the identity responses they add
 };
+
+// A ragged group is laid out as identity-padded uniform tiles instead of a brick when the responses its events
+// really have fill at least this fraction of the padded slots.  Measured break-even on a 1e6-event, 128-parameter
+// sample (scripts/kbench5.py): at 90 % fill the padded tiles take 314 us against 371 us for bricks, at 75 % both
+// take ~313 us.  Settable for experiments (M3HIP_PAD_MIN_FILL; > 1 switches the padding off).
+constexpr double kPadMinFillDefault = 0.78;
+extern double g_pad_min_fill;
 
 // Validates the chunk against (n_params, npts) and sizes the tile store.
 // Returns false and sets err on inconsistent input.

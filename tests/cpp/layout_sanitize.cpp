@@ -18,7 +18,8 @@ struct Chunk {
   std::vector<int16_t> param_no, param_no_tf1;
 };
 
-static int run_case(uint64_t seed, uint64_t n_events, int n_params, double occupancy, bool mixed, bool uniform_lists) {
+static int run_case(uint64_t seed, uint64_t n_events, int n_params, double occupancy, bool mixed, bool uniform_lists, double pad_min_fill = kPadMinFillDefault) {
+  g_pad_min_fill = pad_min_fill;
   std::mt19937_64 rng(seed);
   std::uniform_real_distribution<double> U(0.0, 1.0);
   const int K = 7;
@@ -78,8 +79,9 @@ int main() {
   rc |= run_case(2, 777, 6, 1.0, true, true);         // uniform, mixed kinds, partial last tile
   rc |= run_case(3, 2048 + 300, 48, 0.2, true, false);  // ragged, three groups
   rc |= run_case(4, 1500, 40, 0.3, false, false);     // ragged, TSpline3 only
-  rc |= run_case(5, 1024, 200, 0.9, true, false);     // deep brick (many stages)
-  rc |= run_case(6, 1024, 700, 0.95, false, false);   // beyond the stage limit: must be refused cleanly
+  rc |= run_case(5, 1024, 200, 0.9, true, false, 2.0);     // deep brick (many stages; identity padding off)
+  rc |= run_case(6, 1024, 700, 0.95, false, false, 2.0);   // beyond the stage limit: must be refused cleanly
+  rc |= run_case(8, 2048 + 300, 60, 0.85, true, false);    // nearly uniform lists: identity-padded uniform tiles
   rc |= run_case(7, 3000, 16, 0.0, true, false);      // no responses at all
   std::printf("OK\n");
   return rc;

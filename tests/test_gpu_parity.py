@@ -509,12 +509,13 @@ def _eval_matches(engine, P, K, cx, npts, ch, rng, laps=3):
     return info
 
 
-@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick"])
-def test_extreme_shapes(fresh_engine, case):
+@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick", "padded"])
+def test_extreme_shapes(fresh_engine, case, monkeypatch):
     """Edges of the layout: a single event; ragged groups in which a third of the events carry no response
     at all (weight stays 1, SplineMonolith.cpp:798) and some carry TF1s only; a brick with ~190k responses
-    in its 1024 events (24+ stages, close to the 30-stage limit)."""
-    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3}[case])
+    in its 1024 events (24+ stages, close to the 30-stage limit); the same 80 %-occupied group laid out as
+    identity-padded uniform tiles (the default for groups that are at least 70 % full)."""
+    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3}[case])
     X7, X5, X3 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2]), np.array([-1.0, 0, 1])
     if case == "one_event":
         xs = {0: X7}
@@ -536,18 +537,24 @@ def test_extreme_shapes(fresh_engine, case):
         n_resp = sum(len(e) for e in events)
         assert 180_000 < n_resp < 200_000
         cx, npts, ch = make_monolith(P, 7, xs, events)
+        if case == "deep_brick":
+            monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "2")      # identity padding off: one brick
         info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng, laps=2)
-        assert info.n_tiles_brick == 1
+        if case == "deep_brick":
+            assert info.n_tiles_brick == 1 and info.n_tiles_padded == 0
+        else:
+            assert info.n_tiles_brick == 0 and info.n_tiles_uniform == 4 and info.n_tiles_padded == 4
+            assert 0.15 < info.pad_responses / (info.pad_responses + n_resp) < 0.25
 
 
 def test_brick_stage_limit_is_reported(fresh_engine):
-    """more responses in a 1024-event group than 30 stages hold: the upload is refused with a message,
+    """more responses in a sparse 1024-event group than 30 stages hold: the upload is refused with a message,
     nothing is silently truncated"""
     rng = np.random.default_rng(9)
-    P = 330
+    P = 480
     X3 = np.array([-1.0, 0, 1])
     xs = {p: X3 for p in range(P)}
-    events = _ragged_events(rng, 1024, P, 0.85, xs)
+    events = _ragged_events(rng, 1024, P, 0.6, xs)
     assert sum(len(e) for e in events) > 260_000
     cx, npts, ch = make_monolith(P, 3, xs, events)
     with pytest.raises(capi.M3HipError, match="stages"):

@@ -13,38 +13,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def check_uniform_tiles(n_params, K, npts, ch, lay):
+    """every uniform tile against the source arrays; an event that lacks a slot's parameter (identity-padded
+    tiles) must hold the identity response there: {1,0,0,0} / {0,1}"""
     spl, tf1, meta, desc = lay["spl"], lay["tf1"], lay["meta"], lay["desc"]
     cm = ch["coeff_many"].reshape(-1, 4)
     ct = ch["coeff_tf1"].reshape(-1, 2)
     npe = ch["npe"].reshape(-1, 2)
     npt = ch["npe_tf1"].reshape(-1, 2)
+    ident4, ident2 = np.array([1, 0, 0, 0], np.float32), np.array([0, 1], np.float32)
+    n_pad = 0
     for t, d in enumerate(desc):
         spl_off, tf1_off, meta_off, js, jt, nev, e0, nplanes = [int(v) for v in d]
         assert nev == min(TE, ch["n_events"] - e0)
         m = meta[meta_off: meta_off + 2 * js + jt]
+        # per event: parameter -> index of its response
+        own_s = [{int(ch["param_no"][s]): s for s in range(int(npe[e, 1]), int(npe[e, 1] + npe[e, 0]))} for e in range(e0, e0 + nev)]
+        own_t = [{int(ch["param_no_tf1"][s]): s for s in range(int(npt[e, 1]), int(npt[e, 1] + npt[e, 0]))} for e in range(e0, e0 + nev)]
         plane = 0
+        seen = [0] * nev
         for j in range(js):
             p = int(m[2 * j])
             assert int(m[2 * j + 1]) == plane
             nseg = int(npts[p]) - 1
-            lanes = np.arange(nev)
-            s = npe[e0 + lanes, 1] + j
-            assert (ch["param_no"][s] == p).all()
+            for le in range(nev):
+                s_idx = own_s[le].get(p)
+                for k in range(nseg):
+                    got = spl[spl_off + (plane + k) * TE + le]
+                    if s_idx is None:
+                        assert np.array_equal(got, ident4)
+                    else:
+                        exp = cm[int(ch["nknots_arr"][s_idx]) + k]
+                        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+                seen[le] += s_idx is not None
+                n_pad += s_idx is None
             for k in range(nseg):
-                got = spl[spl_off + (plane + k) * TE + lanes]
-                exp = cm[ch["nknots_arr"][s].astype(np.int64) + k]
-                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
                 pad = spl[spl_off + (plane + k) * TE + np.arange(nev, TE)]
-                assert (pad == np.array([1, 0, 0, 0], np.float32)).all()
+                assert (pad == ident4).all()
             plane += nseg
         assert plane == nplanes
+        assert seen == [len(o) for o in own_s]           # every response of every event sits in some slot
+        seen = [0] * nev
         for j in range(jt):
             p = int(m[2 * js + j])
-            lanes = np.arange(nev)
-            s = npt[e0 + lanes, 1] + j
-            assert (ch["param_no_tf1"][s] == p).all()
-            got = tf1[tf1_off + j * TE + lanes]
-            assert np.array_equal(got.view(np.uint32), ct[s].view(np.uint32))
+            for le in range(nev):
+                s_idx = own_t[le].get(p)
+                got = tf1[tf1_off + j * TE + le]
+                if s_idx is None:
+                    assert np.array_equal(got, ident2)
+                else:
+                    assert np.array_equal(got.view(np.uint32), ct[s_idx].view(np.uint32))
+                seen[le] += s_idx is not None
+                n_pad += s_idx is None
+        assert seen == [len(o) for o in own_t]
+    return n_pad
 
 
 @pytest.mark.parametrize("n_events,n_params", [(256, 8), (700, 5), (1, 3), (1024 + 17, 16)])
@@ -190,7 +211,7 @@ def test_mixed_uniform_and_ragged_groups():
         events.append([(p, "spl", quad()) if p % 3 else (p, "tf1", (0.1 * rng.standard_normal(), 1.0)) for p in range(P)])
     for e in range(900):
         events.append([(p, "spl", quad()) if p % 3 else (p, "tf1", (0.1 * rng.standard_normal(), 1.0))
-                       for p in range(P) if rng.random() < 0.9])
+                       for p in range(P) if rng.random() < 0.5])   # too sparse for identity padding: a brick
     cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P) if p % 3}, events)
     rc, err, lay = debug_layout(P, 7, npts, ch)
     assert rc == 0, err
@@ -211,11 +232,12 @@ def test_ragged_requires_ascending_parameters():
 
 
 def test_brick_stage_limit_is_reported():
-    """more responses in a 1024-event group than 30 stages of 8192 hold: refused with a message"""
+    """more responses in a sparse 1024-event group than 30 stages of 8192 hold: refused with a message
+    (a group this full but denser than 70 % would be identity-padded into uniform tiles instead)"""
     rng = np.random.default_rng(9)
-    P, X3 = 330, np.array([-1.0, 0, 1])
+    P, X3 = 480, np.array([-1.0, 0, 1])
     c = natural_cubic(X3, [0.9, 1.0, 1.2])
-    events = [[(p, "spl", c) for p in range(P) if rng.random() < 0.85] for _ in range(1024)]
+    events = [[(p, "spl", c) for p in range(P) if rng.random() < 0.6] for _ in range(1024)]
     assert sum(len(e) for e in events) > 260_000
     cx, npts, ch = make_monolith(P, 3, {p: X3 for p in range(P)}, events)
     rc, err, _ = debug_layout(P, 3, npts, ch)
@@ -235,3 +257,39 @@ def test_layout_under_sanitizers(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
     assert "stages exceed" in r.stdout and r.stdout.count("bricks") >= 5
+
+
+def test_nearly_uniform_groups_become_identity_padded_tiles(monkeypatch):
+    """Events of one interaction mode share their list of systematics, but the reference drops an event's flat
+    (one-knot) splines from the monolith (SplineMonolith.cpp:160-207), so the lists differ by a few entries.
+    Such groups are laid out as uniform tiles over the union list, with the identity response {1,0,0,0} / {0,1}
+    where an event lacks a parameter: its float product is unchanged bit for bit.  Sparse random lists stay bricks."""
+    rng = np.random.default_rng(17)
+    X7, X5 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2])
+    P = 30
+    xs = {p: (X7 if p % 2 else X5) for p in range(P) if p % 5}
+    events = []
+    for e in range(1024 + 700):
+        ev = []
+        for p in range(P):
+            if rng.random() < 0.12:
+                continue                                    # this event's response to p is flat: dropped
+            if p in xs:
+                ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))))
+            else:
+                ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
+        events.append(ev)
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0, err
+    assert lay["n_bricks"] == 0 and lay["n_tiles"] == 7
+    n_pad = check_uniform_tiles(P, 7, npts, ch, lay)
+    n_real = ch["n_splines"] + ch["n_tf1"]
+    assert 0.08 < n_pad / (n_pad + n_real) < 0.16
+    # with the padding switched off the same chunk is two bricks
+    monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "2")
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0 and lay["n_bricks"] == 2 and lay["n_tiles"] == 0
+    monkeypatch.delenv("M3HIP_PAD_MIN_FILL")
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0 and lay["n_bricks"] == 0
