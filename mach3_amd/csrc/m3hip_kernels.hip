@@ -691,6 +691,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 #pragma unroll
   for (int q = 0; q < kBrickEvPerLane; ++q) {
     const uint32_t e = lane * kBrickEvPerLane + q;
+    // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
+    // belong to somebody else's events and must touch nothing
+    if (e >= bd.n_events) continue;
     const uint64_t ev = (uint64_t)bd.first_event + e;
     if (MODE & kModeEval) a.spline_w[ev] = w[q];
     if (MODE & (kModeFill | kModeEventW)) {

@@ -344,17 +344,19 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
       if (tile_union(n_params, npts, in, e0, e1, &uni_s[t], &uni_t[t], &fill) && fill >= g_pad_min_fill) uniform[t] = 2;
     }
   });
-  const uint64_t n_groups = (in.n_events + M3_GROUP - 1) / M3_GROUP;
+  // Tiles that are uniform (exactly or after identity padding) stay tiles; every maximal run of the other
+  // tiles, cut at M3_GROUP events, becomes one brick.  (Mode blocks of a few thousand events therefore lose one
+  // 256-event tile at each boundary, not a whole 1024-event group.)
   const uint64_t tiles_per_group = M3_GROUP / M3_TE;
   plan->bricks.clear();
   plan->brick_words.clear();
   plan->tile_params.clear();
   plan->n_padded = plan->pad_spl = plan->pad_tf1 = 0;
-  for (uint64_t g = 0; g < n_groups; ++g) {
-    const uint64_t t0 = g * tiles_per_group, t1 = std::min<uint64_t>(n_tiles, t0 + tiles_per_group);
-    bool all_uniform = true;
-    for (uint64_t t = t0; t < t1; ++t) all_uniform = all_uniform && uniform[t];
-    if (all_uniform) {
+  for (uint64_t t0 = 0; t0 < n_tiles;) {
+    uint64_t t1 = t0 + 1;
+    if (!uniform[t0])
+      while (t1 < n_tiles && t1 - t0 < tiles_per_group && !uniform[t1]) ++t1;
+    if (uniform[t0]) {
       for (uint64_t t = t0; t < t1; ++t) {
         TileHost th;
         const uint64_t e0 = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, e0 + M3_TE);
@@ -387,7 +389,7 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
         plan->n_uniform++;
       }
     } else {
-      const uint64_t e0 = g * M3_GROUP, e1 = std::min<uint64_t>(in.n_events, e0 + M3_GROUP);
+      const uint64_t e0 = t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, t1 * M3_TE);
       BrickHost bh;
       if (!plan_brick(n_params, npts, in, e0, e1, &bh, &plan->brick_words, err)) return false;
       bh.spl_off = plan->spl_float4;
@@ -397,6 +399,7 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
       plan->bricks.push_back(std::move(bh));
       plan->n_brick++;
     }
+    t0 = t1;
   }
   return true;
 }

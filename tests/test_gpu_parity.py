@@ -509,19 +509,29 @@ def _eval_matches(engine, P, K, cx, npts, ch, rng, laps=3):
     return info
 
 
-@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick", "padded"])
+@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick", "padded", "mode_blocks"])
 def test_extreme_shapes(fresh_engine, case, monkeypatch):
     """Edges of the layout: a single event; ragged groups in which a third of the events carry no response
     at all (weight stays 1, SplineMonolith.cpp:798) and some carry TF1s only; a brick with ~190k responses
     in its 1024 events (24+ stages, close to the 30-stage limit); the same 80 %-occupied group laid out as
     identity-padded uniform tiles (the default for groups that are at least 70 % full)."""
-    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3}[case])
+    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3, "mode_blocks": 4}[case])
     X7, X5, X3 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2]), np.array([-1.0, 0, 1])
     if case == "one_event":
         xs = {0: X7}
         cx, npts, ch = make_monolith(1, 7, xs, [[(0, "spl", natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7)))]])
         info = _eval_matches(fresh_engine, 1, 7, cx, npts, ch, rng, laps=5)
         assert info.n_tiles_uniform == 1 and info.n_tiles_brick == 0
+    elif case == "mode_blocks":
+        # blocks of events sharing a list, boundaries off the 1024 grid: uniform tiles with small bricks in between
+        P = 10
+        quad = lambda: natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))
+        events = [[(p, "spl", quad()) for p in (0, 1, 2, 3, 4)] for _ in range(1000)]
+        events += [[(p, "spl", quad()) for p in (3, 4, 5, 6, 7, 8)] for _ in range(1300)]
+        events += [[(p, "spl", quad()) for p in range(P) if rng.random() < 0.3] for _ in range(1500)]
+        cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P)}, events)
+        info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng)
+        assert info.n_tiles_uniform == 7 and info.n_tiles_brick == 3
     elif case == "holes":
         P = 40
         xs = {p: (X7, X5, X3)[p % 3] for p in range(0, P, 2)}   # even parameters are TSpline3, odd are TF1

@@ -293,3 +293,26 @@ def test_nearly_uniform_groups_become_identity_padded_tiles(monkeypatch):
     monkeypatch.delenv("M3HIP_PAD_MIN_FILL")
     rc, err, lay = debug_layout(P, 7, npts, ch)
     assert rc == 0 and lay["n_bricks"] == 0
+
+
+def test_mode_blocks_keep_their_uniform_tiles():
+    """Blocks of events that share a list (interaction modes) whose boundaries do not fall on multiples of 1024:
+    only the 256-event tiles that straddle a boundary (or hold sparse events) become bricks; each run of such
+    tiles, cut at 1024 events, is one brick."""
+    rng = np.random.default_rng(23)
+    X7 = np.arange(-3.0, 4.0)
+    P = 10
+    quad = lambda: natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))
+    list_a, list_b = [0, 1, 2, 3, 4], [3, 4, 5, 6, 7, 8]
+    events = [[(p, "spl", quad()) for p in list_a] for _ in range(1000)]            # mode A: tiles 0-2 uniform, tile 3 mixed
+    events += [[(p, "spl", quad()) for p in list_b] for _ in range(1300)]           # mode B: tiles 4-7 uniform, tile 8 mixed
+    events += [[(p, "spl", quad()) for p in range(P) if rng.random() < 0.3] for _ in range(1500)]  # sparse tail
+    cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P)}, events)
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0, err
+    first = sorted(int(d[6]) for d in lay["desc"])
+    assert first == [0, 256, 512, 1024, 1280, 1536, 1792]                            # the seven uniform tiles
+    bricks = sorted((int(d[6]), int(d[5])) for d in lay["bdesc"])
+    assert bricks == [(768, 256), (2048, 1024), (3072, 728)]                         # (first event, events)
+    check_uniform_tiles(P, 7, npts, ch, lay)
+    check_bricks(npts, ch, lay)
