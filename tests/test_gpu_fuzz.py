@@ -83,7 +83,12 @@ def test_random_shape(fresh_engine, seed):
     osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc if c["use_osc"] else None, omono)
     osamp.set_test_statistic(c["stat"], c["update_w2"])
 
-    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    # the engine takes the monolith in event chunks (every chunk but the last a multiple of 1024 events)
+    chunks = [ch]
+    if E > 2048 and seed % 2:
+        cut = 1024 * int(rng.integers(1, E // 1024))
+        chunks = [make_monolith(P, 7, c["xs"], c["events"][:cut])[2], make_monolith(P, 7, c["xs"], c["events"][cut:])[2]]
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, chunks)
     mono.setSplinePointers(par)
     off = (np.arange(c["n_samples"] + 1) * c["nb"]).astype(np.int32)
     sh = SampleHandlerFD(fresh_engine, c["n_samples"], off, par, c["stat"], update_w2=c["update_w2"])
@@ -121,5 +126,83 @@ def test_random_shape(fresh_engine, seed):
     mono.SynchroniseMemTransfer()
     omono.evaluate()
     assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32)), tag
+    osamp.close()
+    omono.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_dynamic_binning(fresh_engine, seed):
+    """device-side FindGlobalBin with random mixes of uniform 1-D / 2-D and non-uniform (box) samples, scale and
+    offset shifts, cuts on binning and cut-only columns: bins integer-exact, fused LLH 1e-9, over several steps"""
+    rng = np.random.default_rng(5000 + seed)
+    E = int(rng.integers(300, 5000))
+    P = int(rng.integers(1, 6))
+    X7 = KNOTS[7]
+    ragged = bool(rng.random() < 0.5)
+    events = [[(p, "spl", natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))) for p in range(P) if not ragged or rng.random() < 0.6]
+              for _ in range(E)]
+    cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P)}, events)
+    n_samples = int(rng.integers(1, 4))
+    lib = ob.load("serial")
+    b = ob.OracleBinning(lib)
+    spec_bins, nb_tot = [], 0
+    for s_ in range(n_samples):
+        kind = rng.choice(["u1", "u2", "box"])
+        if kind == "u1":
+            e = np.sort(rng.uniform(0.0, 5.0, int(rng.integers(3, 40))))
+            e[0], e[-1] = 0.0, 5.0
+            b.add_uniform([e]); spec_bins.append([e]); nb_tot += len(e) - 1
+        elif kind == "u2":
+            ex, ey = np.linspace(0.0, 5.0, int(rng.integers(3, 30))), np.linspace(-1.0, 1.0, int(rng.integers(2, 12)))
+            b.add_uniform([ex, ey]); spec_bins.append([ex, ey]); nb_tot += (len(ex) - 1) * (len(ey) - 1)
+        else:
+            nx, ny = int(rng.integers(2, 8)), int(rng.integers(2, 6))
+            xs_ = np.sort(np.concatenate([[0.0, 5.0], rng.uniform(0.0, 5.0, nx - 1)]))
+            boxes = []
+            for i in range(nx):
+                ys_ = np.sort(np.concatenate([[-1.0, 1.0], rng.uniform(-1.0, 1.0, ny - 1)]))
+                boxes += [[[xs_[i], xs_[i + 1]], [ys_[j], ys_[j + 1]]] for j in range(ny) if rng.random() < 0.9]
+            boxes = np.array(boxes, np.float64)
+            assert b.add_nonuniform(boxes) == s_
+            spec_bins.append(boxes); nb_tot += len(boxes)
+    assert b.n_bins() == nb_tot
+    sample_id = rng.integers(0, n_samples, E).astype(np.int32)
+    kin = np.stack([rng.uniform(-0.3, 5.3, E), rng.uniform(-1.1, 1.1, E), rng.uniform(0.0, 10.0, E)], axis=1)
+    n_sh = int(rng.integers(0, 4))
+    par = np.zeros(P + 3)
+    opar = par.copy()
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    osamp = ob.OracleSample(lib, b, sample_id, kin, None, None, opar, None, None, omono)
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, n_samples, None, par, capi.kPoisson, bin_edges=spec_bins)
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    assert np.array_equal(sh.GetEventBins(0, E), osamp.event_bins()), seed
+    for k in range(n_sh):
+        smp, dim, kd, pi = int(rng.integers(-1, n_samples)), int(rng.integers(0, 2)), int(rng.integers(1, 3)), P + int(rng.integers(0, 3))
+        osamp.add_shift(smp, dim, kd, opar, pi)
+        sh.AddKinShift(smp, dim, kd, pi)
+    for k in range(int(rng.integers(0, 3))):
+        smp, col = int(rng.integers(-1, n_samples)), int(rng.integers(0, 3))
+        lo = float(rng.uniform(0.0, 2.0)) if col != 1 else float(rng.uniform(-1.0, 0.0))
+        hi = lo + (float(rng.uniform(1.0, 8.0)) if col != 1 else float(rng.uniform(0.3, 1.5)))
+        osamp.add_cut(smp, col, lo, hi)
+        sh.AddKinCut(smp, col, lo, hi)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in range(4):
+        par[:P] = rng.uniform(-3.2, 3.2, P)
+        par[P:] = rng.normal(0.0, 0.08, 3)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventBins(0, E), osamp.event_bins()), (seed, lap)
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), (seed, lap)
+        want = osamp.get_likelihood()
+        assert abs(llh - want) <= RTOL_LLH * max(abs(want), 1.0), (seed, lap, llh, want)
     osamp.close()
     omono.close()
