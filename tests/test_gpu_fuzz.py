@@ -206,3 +206,77 @@ def test_random_dynamic_binning(fresh_engine, seed):
         assert abs(llh - want) <= RTOL_LLH * max(abs(want), 1.0), (seed, lap, llh, want)
     osamp.close()
     omono.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_binned_spline_samples(fresh_engine, seed, monkeypatch):
+    """BinnedSplineHandler samples: both M3::float_t builds, events unordered / ordered by spline bin (ELL or shared
+    pointer lists), with and without functional-parameter re-binning (the double build runs it as a separate pass)."""
+    from helpers import make_binned, make_binned_events
+    from mach3_amd.engine import BinnedSplineHandler
+
+    rng = np.random.default_rng(9000 + seed)
+    float_t = np.float64 if seed % 2 else np.float32
+    variant = "serial_f64" if seed % 2 else "serial"
+    P, cells, E, n_norm = int(rng.integers(1, 12)), int(rng.integers(5, 300)), int(rng.integers(200, 6000)), int(rng.integers(0, 4))
+    bs = make_binned(P, cells, rng, float_t=float_t)
+    ordered = bool(rng.random() < 0.5)
+    w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=ordered, sort_by_cell=ordered)
+    if rng.random() < 0.25:
+        monkeypatch.setenv("M3HIP_BINNED_LISTS", "shared" if rng.random() < 0.5 else "ell")
+    nPar = P + n_norm + 1
+    par = np.zeros(nPar)
+    par[P:P + n_norm] = 1.0
+    opar = par.copy()
+    edges = np.linspace(0.0, 5.0, int(rng.integers(4, 120)))
+    nb = len(edges) - 1
+    kin = rng.gamma(3.0, 0.4, E)
+    sample_id = np.zeros(E, np.int32)
+    nn = rng.integers(0, 3, E) if n_norm else np.zeros(E, np.int64)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = (P + rng.integers(0, max(n_norm, 1), int(norm_off[-1]))).astype(np.int16)
+    osc_idx = rng.integers(-1, 30, E).astype(np.int32)
+    osc = rng.random(30).astype(float_t)
+    with_shift = bool(rng.random() < 0.5)
+
+    lib = ob.load(variant)
+    ob_binned = ob.OracleBinned(lib, bs)
+    ob_binned.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc, None)
+    osamp.set_binned(ob_binned, w_off, w_idx)
+    osamp.set_test_statistic(capi.kBarlowBeeston)
+
+    handler = BinnedSplineHandler(fresh_engine, E, bs)
+    handler.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 1, None, par, capi.kBarlowBeeston, bin_edges=[[edges]])
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    sh.SetupEvents(0, sh.GetEventBins(0, E), osc_idx, norm_off, norm_idx)
+    handler.SetEventSplines(0, w_off, w_idx)
+    sh.SetOscillationWeights(osc)
+    if with_shift:
+        osamp.add_shift(-1, 0, 1, opar, nPar - 1)
+        sh.AddKinShift(-1, 0, 1, nPar - 1)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    bits = np.uint64 if float_t == np.float64 else np.uint32
+    for lap in range(4):
+        par[:P] = rng.uniform(-3.4, 3.4, P)
+        par[P:P + n_norm] = 1 + 0.05 * rng.standard_normal(n_norm)
+        par[-1] = 0.05 * rng.standard_normal() if with_shift else 0.0
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(handler.GetWeights().view(bits), ob_binned.weights.view(bits)), (seed, lap)
+        assert np.array_equal(sh.GetEventBins(0, E), osamp.event_bins()), (seed, lap)
+        assert np.array_equal(sh.GetEventWeights(0, E, float_t).view(bits), osamp.event_weights().view(bits)), (seed, lap)
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), (seed, lap)
+        want = osamp.get_likelihood()
+        assert abs(llh - want) <= RTOL_LLH * max(abs(want), 1.0), (seed, lap, llh, want)
+    osamp.close()
+    ob_binned.close()
