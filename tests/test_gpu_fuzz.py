@@ -2,6 +2,8 @@
 anything, parameters with 3 / 5 / 7 knots or TF1 or nothing, uniform and ragged groups in one sample, events with
 no response, several samples, few and many bins, every test statistic, W2 frozen or updated.  The cases are
 deterministic (the seed is the test id); they are meant to find corner cases the hand-written tests miss."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL_BIN = 1e-12
 RTOL_LLH = 1e-9
+# M3_FUZZ_SCALE=N runs N times as many seeds (occasional deep sweeps; the default is what the suite runs)
+SCALE = int(os.environ.get("M3_FUZZ_SCALE", "1"))
 KNOTS = {3: np.array([-1.0, 0.0, 1.0]), 5: np.array([-2.0, -1.0, 0.0, 1.0, 2.0]), 7: np.arange(-3.0, 4.0)}
 
 
@@ -54,7 +58,7 @@ def _case(seed):
                 update_w2=bool(rng.random() < 0.3), use_osc=bool(rng.random() < 0.7), shape=str(shape))
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(64 * SCALE))
 def test_random_shape(fresh_engine, seed):
     c = _case(seed)
     rng, P, E = c["rng"], c["P"], c["E"]
@@ -130,7 +134,7 @@ def test_random_shape(fresh_engine, seed):
     omono.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_dynamic_binning(fresh_engine, seed):
     """device-side FindGlobalBin with random mixes of uniform 1-D / 2-D and non-uniform (box) samples, scale and
     offset shifts, cuts on binning and cut-only columns: bins integer-exact, fused LLH 1e-9, over several steps"""
@@ -208,7 +212,7 @@ def test_random_dynamic_binning(fresh_engine, seed):
     omono.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_random_binned_spline_samples(fresh_engine, seed, monkeypatch):
     """BinnedSplineHandler samples: both M3::float_t builds, events unordered / ordered by spline bin (ELL or shared
     pointer lists), with and without functional-parameter re-binning (the double build runs it as a separate pass)."""
