@@ -135,4 +135,30 @@ int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out
     return -1;
   }
 }
+
+// SMonolith::EventOrderByParameterList on a MasterSpline described by kind[e][p]: 0 none, 1 TSpline3 with 3 knots,
+// 2 TSpline3 with ONE knot (flat: dropped by PrepareForGPU), 3 TF1
+int facade_event_order(int n_events, int n_params, const int* kind, const int* is_tf1, unsigned int* order_out) {
+  try {
+    std::vector<RespFuncType> types;
+    for (int p = 0; p < n_params; ++p) types.push_back(is_tf1[p] ? kTF1_red : kTSpline3_red);
+    std::vector<std::vector<TResponseFunction_red*>> ms(static_cast<size_t>(n_events), std::vector<TResponseFunction_red*>(static_cast<size_t>(n_params), nullptr));
+    float X[3] = {-1.f, 0.f, 1.f}, Y[3] = {0.9f, 1.f, 1.1f}, Pf[9] = {0};
+    float tf[2] = {0.1f, 1.f};
+    for (int e = 0; e < n_events; ++e)
+      for (int p = 0; p < n_params; ++p) {
+        const int k = kind[size_t(e) * n_params + p];
+        if (k == 1) ms[size_t(e)][size_t(p)] = new TSpline3_red(X, Y, 3, Pf);
+        else if (k == 2) ms[size_t(e)][size_t(p)] = new TSpline3_red(X, Y, 1, Pf);
+        else if (k == 3) ms[size_t(e)][size_t(p)] = new TF1_red(2, tf);
+      }
+    const std::vector<uint32_t> order = SMonolith::EventOrderByParameterList(ms, types);
+    for (size_t i = 0; i < order.size(); ++i) order_out[i] = order[i];
+    for (auto& ev : ms)
+      for (auto* rf : ev) delete rf;
+    return int(order.size());
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
 }

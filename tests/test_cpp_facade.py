@@ -43,3 +43,39 @@ def test_cpp_facade_binned_double_build_and_box_bins():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-identical over 6 steps" in r.stdout and r.stdout.strip().endswith("OK")
+
+
+def test_event_order_by_parameter_list():
+    """SMonolith::EventOrderByParameterList groups events by the parameters they respond to (flat one-knot
+    splines do not count, as PrepareForGPU drops them); stable within a group; events without responses last"""
+    import ctypes as C
+    import numpy as np
+    so = os.path.join(ROOT, "build", "libm3facade_test.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    shim = C.CDLL(so)
+    shim.facade_event_order.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    E, P = 500, 6
+    is_tf1 = np.array([0, 0, 1, 0, 1, 0], np.int32)
+    modes = [np.array([1, 1, 3, 0, 0, 0]), np.array([0, 1, 3, 1, 3, 1]), np.array([0, 0, 0, 0, 0, 0]), np.array([1, 0, 0, 1, 3, 0])]
+    which = rng.integers(0, 4, E)
+    kind = np.stack([modes[m] for m in which]).astype(np.int32)
+    flat = (kind == 1) & (rng.random((E, P)) < 0.1)
+    kind[flat] = 2                                              # a tenth of the splines are flat
+    order = np.zeros(E, np.uint32)
+    n = shim.facade_event_order(E, P, kind.ctypes.data, is_tf1.ctypes.data, order.ctypes.data)
+    assert n == E and sorted(order.tolist()) == list(range(E))
+    key = [tuple(np.flatnonzero((kind[e] == 1) | (kind[e] == 3)).tolist()) for e in order]
+    # equal lists are contiguous, and in original order within a list
+    seen = {}
+    for i, k in enumerate(key):
+        seen.setdefault(k, []).append(i)
+    for k, pos in seen.items():
+        assert pos == list(range(pos[0], pos[0] + len(pos)))
+        ev = [int(order[i]) for i in pos]
+        assert ev == sorted(ev)
+    empties = [i for i, k in enumerate(key) if not k]
+    assert empties and empties == list(range(E - len(empties), E))
+    lens = [len(k) for k in key]
+    assert lens == sorted(lens, reverse=True)
