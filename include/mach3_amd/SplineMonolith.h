@@ -222,28 +222,24 @@ class SMonolith : public SplineBase {
       }
   }
 
-  /// Event order that puts events with the same list of responding parameters next to each other (stable;
-  /// events that respond to nothing last).  The engine keeps the order it is given and streams 256-event tiles
-  /// that share a list at ~83 % of the HBM peak (lists that differ by a few dropped flat splines are padded),
-  /// ragged stretches at ~57 %: building the MasterSpline -- and registering the events with SampleHandlerFD --
-  /// in this order puts a sample on the fast path.  Bins and likelihood do not depend on the order beyond fp64
-  /// summation order.  Call before the constructor, which consumes the MasterSpline.
-  static std::vector<uint32_t> EventOrderByParameterList(const std::vector<std::vector<TResponseFunction_red*>>& MasterSpline,
-                                                        const std::vector<RespFuncType>& SplineType) {
+  /// Event order that puts events with the same list of response objects next to each other (stable; events
+  /// without any response last).  The key is the set of parameters for which the event carries a response object
+  /// at all -- flat one-knot splines included: events of one interaction mode / channel share that set, and the
+  /// flat ones, which PrepareForGPU drops, then only leave holes that the engine pads with identity responses.
+  /// The engine keeps the order it is given and streams 256-event tiles with a common (padded) list at ~83 % of
+  /// the HBM peak, ragged stretches at ~57 %: building the MasterSpline -- and registering the events with
+  /// SampleHandlerFD -- in this order puts a sample on the fast path.  Bins and likelihood do not depend on the
+  /// order beyond fp64 summation order.  Call before the constructor, which consumes the MasterSpline.
+  static std::vector<uint32_t> EventOrderByParameterList(const std::vector<std::vector<TResponseFunction_red*>>& MasterSpline) {
     const size_t n = MasterSpline.size();
     std::vector<std::vector<short>> key(n);
     for (size_t e = 0; e < n; ++e)
-      for (size_t p = 0; p < MasterSpline[e].size(); ++p) {
-        TResponseFunction_red* rf = MasterSpline[e][p];  // (GetNp is not const in the reference's interface)
-        if (!rf) continue;
-        if (SplineType[p] == kTSpline3_red && static_cast<TSpline3_red*>(rf)->GetNp() <= 1) continue;  // flat: dropped
-        key[e].push_back(short(p));
-      }
+      for (size_t p = 0; p < MasterSpline[e].size(); ++p)
+        if (MasterSpline[e][p]) key[e].push_back(short(p));
     std::vector<uint32_t> order(n);
     for (size_t e = 0; e < n; ++e) order[e] = uint32_t(e);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
       if (key[a].empty() != key[b].empty()) return key[b].empty();
-      if (key[a].size() != key[b].size()) return key[a].size() > key[b].size();  // long lists first: their unions absorb the short ones
       return key[a] < key[b];
     });
     return order;

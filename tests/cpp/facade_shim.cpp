@@ -137,7 +137,7 @@ int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out
 }
 
 // SMonolith::EventOrderByParameterList on a MasterSpline described by kind[e][p]: 0 none, 1 TSpline3 with 3 knots,
-// 2 TSpline3 with ONE knot (flat: dropped by PrepareForGPU), 3 TF1
+// 2 TSpline3 with ONE knot (flat: dropped by PrepareForGPU, but still part of the event's mode signature), 3 TF1
 int facade_event_order(int n_events, int n_params, const int* kind, const int* is_tf1, unsigned int* order_out) {
   try {
     std::vector<RespFuncType> types;
@@ -152,7 +152,7 @@ int facade_event_order(int n_events, int n_params, const int* kind, const int* i
         else if (k == 2) ms[size_t(e)][size_t(p)] = new TSpline3_red(X, Y, 1, Pf);
         else if (k == 3) ms[size_t(e)][size_t(p)] = new TF1_red(2, tf);
       }
-    const std::vector<uint32_t> order = SMonolith::EventOrderByParameterList(ms, types);
+    const std::vector<uint32_t> order = SMonolith::EventOrderByParameterList(ms);
     for (size_t i = 0; i < order.size(); ++i) order_out[i] = order[i];
     for (auto& ev : ms)
       for (auto* rf : ev) delete rf;

@@ -46,8 +46,9 @@ def test_cpp_facade_binned_double_build_and_box_bins():
 
 
 def test_event_order_by_parameter_list():
-    """SMonolith::EventOrderByParameterList groups events by the parameters they respond to (flat one-knot
-    splines do not count, as PrepareForGPU drops them); stable within a group; events without responses last"""
+    """SMonolith::EventOrderByParameterList groups events by the parameters they carry a response object for
+    (flat one-knot splines included: they mark the event's mode even though PrepareForGPU drops them); stable
+    within a group; events without responses last"""
     import ctypes as C
     import numpy as np
     so = os.path.join(ROOT, "build", "libm3facade_test.so")
@@ -66,16 +67,10 @@ def test_event_order_by_parameter_list():
     order = np.zeros(E, np.uint32)
     n = shim.facade_event_order(E, P, kind.ctypes.data, is_tf1.ctypes.data, order.ctypes.data)
     assert n == E and sorted(order.tolist()) == list(range(E))
-    key = [tuple(np.flatnonzero((kind[e] == 1) | (kind[e] == 3)).tolist()) for e in order]
-    # equal lists are contiguous, and in original order within a list
-    seen = {}
-    for i, k in enumerate(key):
-        seen.setdefault(k, []).append(i)
-    for k, pos in seen.items():
-        assert pos == list(range(pos[0], pos[0] + len(pos)))
-        ev = [int(order[i]) for i in pos]
+    mode_of = which[order]
+    # each mode is one contiguous block, in original order inside it; the empty mode comes last
+    blocks = [m for i, m in enumerate(mode_of) if i == 0 or mode_of[i - 1] != m]
+    assert len(blocks) == 4 and blocks[-1] == 2
+    for m in range(4):
+        ev = [int(e) for e in order if which[e] == m]
         assert ev == sorted(ev)
-    empties = [i for i, k in enumerate(key) if not k]
-    assert empties and empties == list(range(E - len(empties), E))
-    lens = [len(k) for k in key]
-    assert lens == sorted(lens, reverse=True)
