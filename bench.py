@@ -72,6 +72,7 @@ def cpu_baseline(spec, budget_s=10.0, sample_events=200_000):
     from mach3_amd import synth
 
     n = min(sample_events, spec.n_events)
+    os.environ.setdefault("OMP_PROC_BIND", "close")  # SURVEY section 8d; read by libgomp when the library is loaded
     lib = ob.load("omp")
     cores = os.cpu_count() or 1
     lib.m3o_set_num_threads(min(cores, 16))
