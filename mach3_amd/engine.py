@@ -184,6 +184,22 @@ class SMonolith:
     def retPointer(self, event: int):
         return self.cpu_total_weights[event:event + 1]
 
+    # ---- the names pyMaCh3 gives the same operations (ref: python/splines.cpp:142-236, class EventSplineMonolith)
+    def evaluate(self):
+        self.Evaluate()
+
+    def sync_mem_transfer(self):
+        self.SynchroniseMemTransfer()
+
+    def get_event_weight(self, event: int) -> float:
+        return float(self.cpu_total_weights[event])
+
+    def set_param_value_array(self, array: np.ndarray):
+        """the array's entries become the spline parameters, read at evaluate() time (the binding stores pointers
+        into the numpy buffer, python/splines.cpp:97-131)"""
+        assert array.dtype == np.float64 and array.ndim == 1 and len(array) == self.nParams
+        self.setSplinePointers(array)
+
 
 class BinnedSplineHandler:
     """Bin-by-bin splines on the GPU: the per-step part of BinnedSplineHandler

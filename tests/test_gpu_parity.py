@@ -995,3 +995,26 @@ def test_kinematic_cuts_on_shifted_variables(fresh_engine):
     assert 0 < min(n_sel) < max(n_sel) < E and n_sel[0] == n_sel[-1]
     osamp.close()
     omono.close()
+
+
+def test_pymach3_style_names(fresh_engine):
+    """the reference's python binding drives the monolith as EventSplineMonolith.evaluate / sync_mem_transfer /
+    get_event_weight / set_param_value_array (python/splines.cpp:142-236); the harness answers to the same names"""
+    rng = np.random.default_rng(77)
+    E, P = 500, 5
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    opar = np.zeros(P)
+    omono.set_spline_pointers(opar)
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    arr = np.zeros(P)
+    mono.set_param_value_array(arr)
+    for _ in range(3):
+        arr[:] = rng.uniform(-3, 3, P)
+        opar[:] = arr
+        mono.evaluate()
+        mono.sync_mem_transfer()
+        omono.evaluate()
+        assert all(np.float32(mono.get_event_weight(e)) == omono.total_weights[e] for e in (0, 1, E // 2, E - 1))
+    omono.close()
