@@ -225,6 +225,9 @@ int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, c
                             const double* kin, int kin_stride);
 int m3hip_compute_bins(m3hip_handle h);
 int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index);
+/* kind 3: x[dim] += theta * (nominal value of kinematic column aux_column) -- e.g. E_rec = E_lep + E_had with a scale
+ * on the hadronic part only: keep E_had in a cut-only column and shift E_rec by theta * E_had */
+int m3hip_add_kin_shift_aux(m3hip_handle h, int sample, int dim, int aux_column, int param_index);
 int m3hip_clear_kin_shifts(m3hip_handle h);
 /* SampleHandlerFD::IsEventSelected (Samples/SampleHandlerFD.cpp:281-294): an event is kept while
  * lower <= x < upper for every cut of its sample; `column` addresses the kinematics array (binning

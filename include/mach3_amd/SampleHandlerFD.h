@@ -264,6 +264,11 @@ class SampleHandlerFD : public SampleHandlerBase {
     if (!device_binning) throw MaCh3Exception(__FILE__, __LINE__, "RegisterFunctionalParameter needs EnableDeviceBinning()");
     M3HIP_CALL(h, m3hip_add_kin_shift(h, Sample, Column, Kind, ParameterIndex));
   }
+  /// Kind 3 of that closed set: x[Column] += theta * (nominal value of column AuxColumn)
+  void RegisterFunctionalParameterAux(int Sample, int Column, int AuxColumn, int ParameterIndex) {
+    if (!device_binning) throw MaCh3Exception(__FILE__, __LINE__, "RegisterFunctionalParameterAux needs EnableDeviceBinning()");
+    M3HIP_CALL(h, m3hip_add_kin_shift_aux(h, Sample, Column, AuxColumn, ParameterIndex));
+  }
   /// Selection lo <= x < hi on kinematic column `Column`, evaluated on the shifted values
   /// (SampleHandlerFD::IsEventSelected, SampleHandlerFD.cpp:281-294)
   void AddSelection(int Sample, int Column, double Lo, double Hi) {

@@ -20,7 +20,7 @@ M3HIP_SYMBOLS = [
     "m3hip_set_data", "m3hip_set_test_statistic",
     "m3hip_binned_upload", "m3hip_binned_upload_events", "m3hip_get_binned_weights",
     "m3hip_binned_upload_f64", "m3hip_get_binned_weights_f64", "m3hip_set_osc_table_f64", "m3hip_get_event_weights_f64",
-    "m3hip_set_binning_edges", "m3hip_upload_kinematics", "m3hip_compute_bins", "m3hip_add_kin_shift",
+    "m3hip_set_binning_edges", "m3hip_upload_kinematics", "m3hip_compute_bins", "m3hip_add_kin_shift", "m3hip_add_kin_shift_aux",
     "m3hip_clear_kin_shifts", "m3hip_add_kin_cut", "m3hip_get_event_bins",
     "m3hip_binning_begin", "m3hip_binning_add_uniform", "m3hip_binning_add_nonuniform", "m3hip_binning_end",
     "m3hip_reweight", "m3hip_get_likelihood", "m3hip_step",
@@ -124,6 +124,7 @@ def load_m3hip():
         "m3hip_upload_kinematics": [vp, u64, u64, vp, vp, i32],
         "m3hip_compute_bins": [vp],
         "m3hip_add_kin_shift": [vp, i32, i32, i32, i32],
+        "m3hip_add_kin_shift_aux": [vp, i32, i32, i32, i32],
         "m3hip_clear_kin_shifts": [vp],
         "m3hip_add_kin_cut": [vp, i32, i32, C.c_double, C.c_double],
         "m3hip_get_event_bins": [vp, vp, u64, u64],

@@ -1212,21 +1212,31 @@ int m3hip_compute_bins(m3hip_handle h) {
   return M3HIP_OK;
 }
 
-int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index) {
-  if (!h) return M3HIP_EINVAL;
-  if (dim < 0 || dim >= M3_MAX_DIM || (kind != 1 && kind != 2) || param_index < 0 || sample < -1) return fail(h, M3HIP_EINVAL, "add_kin_shift: bad arguments");
+static int add_shift(m3hip_handle h, int sample, int dim, int kind, int aux, int param_index) {
+  if (dim < 0 || dim >= M3_MAX_DIM || kind < 1 || kind > 3 || aux < 0 || aux >= M3_MAX_DIM || param_index < 0 || sample < -1)
+    return fail(h, M3HIP_EINVAL, "add_kin_shift: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, wait_stream(h->stream));
   KinShift k;
-  k.sample = sample; k.dim = dim; k.kind = kind; k.param = param_index;
+  k.sample = sample; k.dim = dim; k.kind = kind | (aux << 8); k.param = param_index;
   h->h_shifts.push_back(k);
   dev_free(h->d_shifts);
-  dev_free(h->d_cuts);
   h->d_shifts = nullptr;
   int rc = dev_alloc(h, &h->d_shifts, h->h_shifts.size());
   if (rc) return rc;
   HIPCHK(h, hipMemcpy(h->d_shifts, h->h_shifts.data(), sizeof(KinShift) * h->h_shifts.size(), hipMemcpyHostToDevice));
   return M3HIP_OK;
+}
+
+int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index) {
+  if (!h) return M3HIP_EINVAL;
+  if (kind != 1 && kind != 2) return fail(h, M3HIP_EINVAL, "add_kin_shift: kind must be 1 (scale) or 2 (offset)");
+  return add_shift(h, sample, dim, kind, 0, param_index);
+}
+
+int m3hip_add_kin_shift_aux(m3hip_handle h, int sample, int dim, int aux_column, int param_index) {
+  if (!h) return M3HIP_EINVAL;
+  return add_shift(h, sample, dim, 3, aux_column, param_index);
 }
 
 int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, double upper) {

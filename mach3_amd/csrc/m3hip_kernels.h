@@ -70,7 +70,7 @@ struct BinSample {
 struct KinShift {      // closed set of functional-parameter shifts (stand-ins for the reference's
   int32_t sample;      // std::function callbacks, SampleHandlerFD.cpp:545-564); -1 = every sample
   int32_t dim;
-  int32_t kind;        // 1: x *= (1 + theta)   2: x += theta
+  int32_t kind;        // low byte 1: x *= (1 + theta)   2: x += theta   3: x += theta * kin[aux], aux = kind >> 8
   int32_t param;       // index into the global parameter vector
 };
 struct KinCut {        // SampleHandlerFD::IsEventSelected (SampleHandlerFD.cpp:281-294): keep lo <= x < hi

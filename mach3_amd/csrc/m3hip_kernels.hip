@@ -177,7 +177,9 @@ __device__ int d_event_bin(const BinArgs& a, uint64_t ev) {
     const KinShift sh = a.shifts[s];
     if (sh.dim < a.kin_stride && (sh.sample < 0 || sh.sample == sid)) {
       const double th = a.params[sh.param];
-      x[sh.dim] = sh.kind == 1 ? x[sh.dim] * (1.0 + th) : x[sh.dim] + th;
+      const int kind = sh.kind & 0xFF, aux = sh.kind >> 8;
+      // 1: x *= 1 + theta; 2: x += theta; 3: x += theta * (nominal value of column aux), e.g. scaling the hadronic part of E_rec
+      x[sh.dim] = kind == 1 ? x[sh.dim] * (1.0 + th) : (kind == 2 ? x[sh.dim] + th : x[sh.dim] + th * a.kin[ev * a.kin_stride + aux]);
     }
   }
   bool out = false;

@@ -318,6 +318,10 @@ class SampleHandlerFD:
     def AddKinShift(self, sample, dim, kind, param_index):
         self.eng._chk(self.eng.lib.m3hip_add_kin_shift(self.eng.h, int(sample), int(dim), int(kind), int(param_index)))
 
+    def AddKinShiftAux(self, sample, dim, aux_column, param_index):
+        """x[dim] += theta * (nominal value of column aux_column)"""
+        self.eng._chk(self.eng.lib.m3hip_add_kin_shift_aux(self.eng.h, sample, dim, aux_column, param_index))
+
     def AddKinCut(self, sample, column, lower, upper):
         self.eng._chk(self.eng.lib.m3hip_add_kin_cut(self.eng.h, int(sample), int(column), float(lower), float(upper)))
 

@@ -1107,7 +1107,8 @@ static void ApplyShifts(m3o_sample* s, uint64_t iEvent) {
     if (fp.dim >= s->kin_stride || (fp.sample >= 0 && fp.sample != ev.NominalSample)) continue;
     double& x = s->kin_shifted[iEvent * s->kin_stride + fp.dim];
     const double th = *fp.valuePtr;
-    x = fp.kind == 1 ? x * (1.0 + th) : x + th;
+    const int kind = fp.kind & 0xFF, aux = fp.kind >> 8;  // kind 3: the callback adds theta times another (nominal) variable
+    x = kind == 1 ? x * (1.0 + th) : (kind == 2 ? x + th : x + th * s->kin_nominal[iEvent * s->kin_stride + aux]);
   }
 }
 

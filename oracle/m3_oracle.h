@@ -168,7 +168,8 @@ void m3o_sample_destroy(m3o_sample* s);
  * w_off/w_idx of indices into weightvec_Monolith */
 void m3o_sample_set_binned(m3o_sample* s, m3o_binned* b, const uint64_t* w_off, const int32_t* w_idx);
 /* a functional-parameter shift of binning axis `dim` (ApplyShifts, SampleHandlerFD.cpp:545-564):
- * kind 1: x *= (1 + *value_ptr), kind 2: x += *value_ptr; sample -1 = every sample */
+ * kind 1: x *= (1 + *value_ptr), kind 2: x += *value_ptr, kind 3 | (aux << 8): x += *value_ptr * nominal[aux];
+ * sample -1 = every sample */
 /* a kinematic cut lower <= x < upper on column `column` (IsEventSelected, SampleHandlerFD.cpp:281-294);
  * m3o_sample_event_bins reports -1 for events that fail the selection */
 void m3o_sample_add_cut(m3o_sample* s, int sample, int column, double lower, double upper);

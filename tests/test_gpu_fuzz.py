@@ -184,16 +184,27 @@ def test_random_dynamic_binning(fresh_engine, seed):
     sh.SetupKinematics(0, sample_id, kin)
     sh.ComputeBins()
     assert np.array_equal(sh.GetEventBins(0, E), osamp.event_bins()), seed
-    for k in range(n_sh):
-        smp, dim, kd, pi = int(rng.integers(-1, n_samples)), int(rng.integers(0, 2)), int(rng.integers(1, 3)), P + int(rng.integers(0, 3))
-        osamp.add_shift(smp, dim, kd, opar, pi)
-        sh.AddKinShift(smp, dim, kd, pi)
-    for k in range(int(rng.integers(0, 3))):
-        smp, col = int(rng.integers(-1, n_samples)), int(rng.integers(0, 3))
-        lo = float(rng.uniform(0.0, 2.0)) if col != 1 else float(rng.uniform(-1.0, 0.0))
-        hi = lo + (float(rng.uniform(1.0, 8.0)) if col != 1 else float(rng.uniform(0.3, 1.5)))
-        osamp.add_cut(smp, col, lo, hi)
-        sh.AddKinCut(smp, col, lo, hi)
+    def add_shifts():
+        for k in range(n_sh):
+            smp, dim, kd, pi = int(rng.integers(-1, n_samples)), int(rng.integers(0, 2)), int(rng.integers(1, 4)), P + int(rng.integers(0, 3))
+            if kd == 3:                      # x += theta * (another nominal column), e.g. a scale on part of the energy
+                aux = int(rng.integers(0, 3))
+                osamp.add_shift(smp, dim, 3 | (aux << 8), opar, pi)
+                sh.AddKinShiftAux(smp, dim, aux, pi)
+            else:
+                osamp.add_shift(smp, dim, kd, opar, pi)
+                sh.AddKinShift(smp, dim, kd, pi)
+
+    def add_cuts():
+        for k in range(int(rng.integers(0, 3))):
+            smp, col = int(rng.integers(-1, n_samples)), int(rng.integers(0, 3))
+            lo = float(rng.uniform(0.0, 2.0)) if col != 1 else float(rng.uniform(-1.0, 0.0))
+            hi = lo + (float(rng.uniform(1.0, 8.0)) if col != 1 else float(rng.uniform(0.3, 1.5)))
+            osamp.add_cut(smp, col, lo, hi)
+            sh.AddKinCut(smp, col, lo, hi)
+
+    for f in ((add_shifts, add_cuts) if seed % 2 else (add_cuts, add_shifts)):   # either registration order
+        f()
     sh.Reweight()
     osamp.reweight()
     sh.AddData(osamp.mc)
