@@ -149,6 +149,9 @@ struct m3hip_ctx {
   std::map<std::vector<int32_t>, int32_t> bl_map;
   std::vector<int32_t> bl_off, bl_idx;
   int32_t *d_bl_id = nullptr, *d_bl_off = nullptr, *d_bl_idx = nullptr;
+  std::vector<int32_t> h_bl_id;   // host copy of the list ids (the processing order is derived from it)
+  uint32_t* d_perm = nullptr;     // processing order of a binned-only event space: events grouped by pointer list
+  bool perm_dirty = false;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
   BinSample* d_bin_samples = nullptr;
@@ -320,6 +323,9 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bl_id); h->d_bl_id = nullptr;
   dev_free(h->d_bl_off); h->d_bl_off = nullptr;
   dev_free(h->d_bl_idx); h->d_bl_idx = nullptr;
+  dev_free(h->d_perm); h->d_perm = nullptr;
+  h->h_bl_id.clear();
+  h->perm_dirty = false;
   h->bl_mode = -1;
   h->bl_map.clear(); h->bl_off.clear(); h->bl_idx.clear();
   h->b_M = h->b_U = h->b_C = 0;
@@ -379,6 +385,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.osc_table = h->d_osc_table;
   a.bwidx = h->d_bwidx;
   a.bl_id = h->bl_mode == 1 ? h->d_bl_id : nullptr;
+  a.perm = (h->bl_mode == 1 && h->S + h->T == 0) ? h->d_perm : nullptr;
   a.bl_off = h->d_bl_off;
   a.bl_idx = h->d_bl_idx;
   a.bw = h->d_b_w;
@@ -926,15 +933,19 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
       if (w_idx[k] < 0 || w_idx[k] >= h->b_M) return fail(h, M3HIP_EINVAL, "binned_upload_events: weight index out of range");
   }
   if (h->bl_mode < 0) {
-    // Events registered in spline-bin order carry the same pointer list as their neighbours: then one list id
-    // per event replaces 4 B of index per weight.  Unordered events keep the ELL form (two dependent random
-    // gathers per weight would cost more than they save).  M3HIP_BINNED_LISTS=ell|shared overrides the choice.
-    uint64_t same = 0;
-    for (uint64_t i = 1; i < n; ++i) {
-      const uint64_t c = w_off[i + 1] - w_off[i];
-      if (c == w_off[i] - w_off[i - 1] && (c == 0 || memcmp(w_idx + w_off[i], w_idx + w_off[i - 1], sizeof(int32_t) * c) == 0)) ++same;
+    // Events of one spline bin carry the same pointer list: when there are few distinct lists, each is stored once
+    // and an event keeps a list id (4 B instead of 4 B per weight); the events are then PROCESSED grouped by list
+    // (a permutation of the lanes, see ReweightArgs::perm), so that a wave gathers the same weights whatever order
+    // the MC was registered in.  With (nearly) one list per event the ELL form stays.  M3HIP_BINNED_LISTS=ell|shared
+    // overrides the choice.
+    // (decided on the first upload: when its events carry at most one distinct list per 8 events)
+    std::map<std::vector<int32_t>, int> seen;
+    std::vector<int32_t> key;
+    for (uint64_t i = 0; i < n && seen.size() * 8 <= n; ++i) {
+      key.assign(w_idx + w_off[i], w_idx + w_off[i + 1]);
+      seen.emplace(key, 0);
     }
-    h->bl_mode = (n > 1 && 2 * same >= n - 1) ? 1 : 0;
+    h->bl_mode = (n > 1 && seen.size() * 8 <= n) ? 1 : 0;
     if (const char* f = getenv("M3HIP_BINNED_LISTS")) h->bl_mode = (f[0] == 's') ? 1 : 0;
   }
   if (h->bl_mode == 1) {
@@ -966,6 +977,9 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
     HIPCHK(h, hipMemcpy(h->d_bl_off, h->bl_off.data(), sizeof(int32_t) * h->bl_off.size(), hipMemcpyHostToDevice));
     if (!h->bl_idx.empty()) HIPCHK(h, hipMemcpy(h->d_bl_idx, h->bl_idx.data(), sizeof(int32_t) * h->bl_idx.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_bl_id + event_offset, ids.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (h->h_bl_id.size() != h->E_pad) h->h_bl_id.assign(size_t(h->E_pad), -1);
+    std::copy(ids.begin(), ids.end(), h->h_bl_id.begin() + event_offset);
+    h->perm_dirty = true;
     return M3HIP_OK;
   }
   if (mx > h->Kb) {
@@ -1447,6 +1461,21 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
     } else if (!h->f64 && !h->osc_valid_f32) {
       launch_osc_convert(nullptr, h->d_osc_table_d, h->d_osc_table, h->n_osc, false, h->stream);
       h->osc_valid_f32 = true;
+    }
+  }
+  if (h->perm_dirty) {  // processing order of a binned-only event space: stable sort of the events by pointer list
+    h->perm_dirty = false;
+    if (h->bl_mode == 1 && h->S + h->T == 0) {
+      std::vector<uint32_t> perm(size_t(h->E_pad));
+      for (size_t i = 0; i < perm.size(); ++i) perm[i] = uint32_t(i);
+      const std::vector<int32_t>& id = h->h_bl_id;
+      std::stable_sort(perm.begin(), perm.begin() + h->E, [&](uint32_t x, uint32_t y) {
+        const uint32_t kx = uint32_t(id[x]), ky = uint32_t(id[y]);  // -1 (no list) sorts last
+        return kx < ky;
+      });
+      if (!h->d_perm && (rc = dev_alloc(h, &h->d_perm, perm.size()))) return rc;
+      HIPCHK(h, wait_stream(h->stream));
+      HIPCHK(h, hipMemcpy(h->d_perm, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice));
     }
   }
   ReweightArgs a = make_rw_args(h);

@@ -116,6 +116,9 @@ struct ReweightArgs {
   const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
   // ... or, when neighbouring events share their lists (MC ordered by spline bin), one list id per event into a
   // store of the distinct lists: the index traffic drops from 4 B per weight to 4 B per event
+  const uint32_t* perm;      // [E_pad] or null: lane `pos` of a tile works on event perm[pos] (binned-only event
+                             // spaces: events that share a pointer list are processed next to each other whatever
+                             // order they were registered in; every per-event array stays in the caller's order)
   const int32_t* bl_id;      // [E_pad] list of the event, -1 = none; null = the ELL form above is in use
   const int32_t* bl_off;     // [n_lists + 1]
   const int32_t* bl_idx;     // concatenated lists, each in pointer order

@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     }
   }
 
-  const uint64_t ev = (uint64_t)td.first_event + lane;
+  const uint64_t pos = (uint64_t)td.first_event + lane;
+  const uint64_t ev = a.perm ? (uint64_t)a.perm[pos] : pos;  // processing order -> event (identity unless a binned-only space was grouped)
   if (MODE & kModeEval) a.spline_w[ev] = w;  // cpu_total_weights[EventNum] (SplineMonolith.cpp:828)
 
   if (MODE & (kModeFill | kModeEventW)) {

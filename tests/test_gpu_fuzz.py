@@ -235,8 +235,9 @@ def test_random_binned_spline_samples(fresh_engine, seed, monkeypatch):
     variant = "serial_f64" if seed % 2 else "serial"
     P, cells, E, n_norm = int(rng.integers(1, 12)), int(rng.integers(5, 300)), int(rng.integers(200, 6000)), int(rng.integers(0, 4))
     bs = make_binned(P, cells, rng, float_t=float_t)
+    per_cell = bool(rng.random() < 0.6)
     ordered = bool(rng.random() < 0.5)
-    w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=ordered, sort_by_cell=ordered)
+    w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=per_cell, sort_by_cell=ordered)
     if rng.random() < 0.25:
         monkeypatch.setenv("M3HIP_BINNED_LISTS", "shared" if rng.random() < 0.5 else "ell")
     nPar = P + n_norm + 1

@@ -804,13 +804,14 @@ def test_functional_shifts_rebin_every_step(fresh_engine):
     omono.close()
 
 
-@pytest.mark.parametrize("lists", ["ell", "shared_sorted", "shared_forced"])
+@pytest.mark.parametrize("lists", ["ell", "shared_sorted", "shared_unsorted", "shared_forced"])
 def test_binned_splines_match_oracle(fresh_engine, lists, monkeypatch):
     """SURVEY 8f row 1: BinnedSplineHandler::Evaluate (segment search + clamped cubic per bin-spline)
     and the per-event gather of those weights into CalcWeightTotal, against the oracle: bin-spline
     weights and event weights bit-exact, bins 1e-12, LLH 1e-9.  The events' pointer lists reach the device
-    either as ELL planes (unordered MC) or as list ids into the distinct lists (MC ordered by spline bin;
-    also forced onto unordered events, where every event has a list of its own)."""
+    either as ELL planes (about one distinct list per event) or as list ids into the distinct lists (few distinct
+    lists, MC in spline-bin order or in any order -- the engine then processes the events grouped by list; also
+    forced onto events that each have a list of their own)."""
     from helpers import make_binned, make_binned_events
     from mach3_amd.engine import BinnedSplineHandler
 
@@ -819,6 +820,8 @@ def test_binned_splines_match_oracle(fresh_engine, lists, monkeypatch):
     bs = make_binned(P, cells, rng)
     if lists == "shared_sorted":
         w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=True, sort_by_cell=True)
+    elif lists == "shared_unsorted":   # few distinct lists, events in any order: the engine processes them grouped by list
+        w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=True, sort_by_cell=False)
     else:
         w_off, w_idx = make_binned_events(E, P, cells, rng)
     if lists == "shared_forced":
