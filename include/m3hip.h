@@ -292,6 +292,8 @@ typedef struct {
   int n_params, max_knots, n_bins, n_samples;
   uint64_t n_tiles_padded;  /* uniform tiles that hold identity-padded ragged events (counted in n_tiles_uniform) */
   uint64_t pad_responses;   /* identity responses added by that padding (TSpline3 + TF1); not in n_splines / n_tf1 */
+  uint64_t n_grouped_chunks; /* upload chunks whose events the engine grouped by parameter list (processing order only:
+                              * every per-event array and result keeps the caller's event order) */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

@@ -52,7 +52,7 @@ class Info(C.Structure):
         ("n_tiles_uniform", C.c_uint64), ("n_tiles_brick", C.c_uint64),
         ("coeff_bytes", C.c_uint64), ("alg_bytes_eval", C.c_uint64), ("alg_bytes_fused", C.c_uint64),
         ("n_params", C.c_int), ("max_knots", C.c_int), ("n_bins", C.c_int), ("n_samples", C.c_int),
-        ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64),
+        ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64),
     ]
 
 

@@ -150,8 +150,12 @@ struct m3hip_ctx {
   std::vector<int32_t> bl_off, bl_idx;
   int32_t *d_bl_id = nullptr, *d_bl_off = nullptr, *d_bl_idx = nullptr;
   std::vector<int32_t> h_bl_id;   // host copy of the list ids (the processing order is derived from it)
-  uint32_t* d_perm = nullptr;     // processing order of a binned-only event space: events grouped by pointer list
+  uint32_t* d_perm = nullptr;     // processing order: lane position -> event (binned-only spaces: grouped by pointer
+                                  // list; monoliths: chunks whose events were grouped by parameter list at upload)
   bool perm_dirty = false;
+  std::vector<uint32_t> h_perm;   // monolith grouping, built chunk by chunk
+  bool perm_monolith = false;     // some chunk was grouped
+  uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
   BinSample* d_bin_samples = nullptr;
@@ -324,6 +328,9 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bl_off); h->d_bl_off = nullptr;
   dev_free(h->d_bl_idx); h->d_bl_idx = nullptr;
   dev_free(h->d_perm); h->d_perm = nullptr;
+  h->h_perm.clear();
+  h->perm_monolith = false;
+  h->n_grouped_chunks = 0;
   h->h_bl_id.clear();
   h->perm_dirty = false;
   h->bl_mode = -1;
@@ -385,7 +392,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.osc_table = h->d_osc_table;
   a.bwidx = h->d_bwidx;
   a.bl_id = h->bl_mode == 1 ? h->d_bl_id : nullptr;
-  a.perm = (h->bl_mode == 1 && h->S + h->T == 0) ? h->d_perm : nullptr;
+  a.perm = (h->perm_monolith || (h->bl_mode == 1 && h->S + h->T == 0)) ? h->d_perm : nullptr;
   a.bl_off = h->d_bl_off;
   a.bl_idx = h->d_bl_idx;
   a.bw = h->d_b_w;
@@ -558,6 +565,63 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
   if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
+  // Grouping.  When a sizeable part of the chunk would end up in bricks, try the chunk with its events grouped by
+  // parameter list (stable sort): events of one interaction mode then sit together and form uniform (or padded)
+  // tiles.  Only the small {count,start} arrays are permuted -- they point into the flat response arrays, which
+  // stay as they are -- and the kernels map a lane position back to its event through the permutation, so every
+  // per-event array and every result keeps the caller's event order.
+  std::vector<uint32_t> order;
+  std::vector<unsigned int> npe_g, npe_tf1_g;
+  {
+    uint64_t ragged = 0;
+    for (const BrickHost& bh : plan.bricks) ragged += bh.n_events;
+    const char* f = getenv("M3HIP_GROUP_EVENTS");
+    const bool enabled = !(f && f[0] == '0');
+    if (enabled && ragged * 10 > n_events) {
+      std::vector<uint32_t> ord(n_events);
+      for (uint64_t e = 0; e < n_events; ++e) ord[e] = uint32_t(e);
+      auto less = [&](uint32_t x, uint32_t y) {  // lexicographic on (spline parameters, TF1 parameters)
+        const unsigned int cx = n_param_per_event[2 * x], sx = n_param_per_event[2 * x + 1];
+        const unsigned int cy = n_param_per_event[2 * y], sy = n_param_per_event[2 * y + 1];
+        if (std::lexicographical_compare(param_no + sx, param_no + sx + cx, param_no + sy, param_no + sy + cy)) return true;
+        if (std::lexicographical_compare(param_no + sy, param_no + sy + cy, param_no + sx, param_no + sx + cx)) return false;
+        const unsigned int tx = n_param_per_event_tf1[2 * x], ux = n_param_per_event_tf1[2 * x + 1];
+        const unsigned int ty = n_param_per_event_tf1[2 * y], uy = n_param_per_event_tf1[2 * y + 1];
+        return std::lexicographical_compare(param_no_tf1 + ux, param_no_tf1 + ux + tx, param_no_tf1 + uy, param_no_tf1 + uy + ty);
+      };
+      std::stable_sort(ord.begin(), ord.end(), less);
+      npe_g.resize(2 * n_events);
+      npe_tf1_g.resize(2 * n_events);
+      for (uint64_t pos = 0; pos < n_events; ++pos) {
+        const uint32_t e = ord[pos];
+        npe_g[2 * pos] = n_param_per_event[2 * e];
+        npe_g[2 * pos + 1] = n_param_per_event[2 * e + 1];
+        npe_tf1_g[2 * pos] = n_param_per_event_tf1[2 * e];
+        npe_tf1_g[2 * pos + 1] = n_param_per_event_tf1[2 * e + 1];
+      }
+      ChunkInput in_g = in;
+      in_g.npe = npe_g.data();
+      in_g.npe_tf1 = npe_tf1_g.data();
+      ChunkPlan plan_g;
+      std::string err_g;
+      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g)) {
+        uint64_t ragged_g = 0;
+        for (const BrickHost& bh : plan_g.bricks) ragged_g += bh.n_events;
+        if (ragged_g * 2 <= ragged) {  // at least halves what goes through bricks
+          in = in_g;
+          plan = std::move(plan_g);
+          order = std::move(ord);
+        }
+      }
+    }
+  }
+  h->h_perm.resize(size_t(h->E + n_events));
+  for (uint64_t pos = 0; pos < n_events; ++pos) h->h_perm[size_t(h->E + pos)] = uint32_t(h->E + (order.empty() ? pos : order[pos]));
+  if (!order.empty()) {
+    h->perm_monolith = true;
+    h->n_grouped_chunks++;
+  }
+
   // host staging (pinned) -> device
   float *s_spl = nullptr, *s_tf1 = nullptr;
   int32_t* s_meta = nullptr;
@@ -667,6 +731,13 @@ int m3hip_monolith_end(m3hip_handle h) {
   HIPCHK(h, hipMemset(h->d_bin, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: under/overflow
   HIPCHK(h, hipMemset(h->d_osc, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: no oscillation pointer
   HIPCHK(h, hipMemset(h->d_spline_w, 0, sizeof(float) * h->E_pad));
+  if (h->perm_monolith) {  // lane position -> event, identity over the padding and over the chunks that were not grouped
+    h->h_perm.resize(size_t(h->E_pad));
+    for (uint64_t i = h->E; i < h->E_pad; ++i) h->h_perm[size_t(i)] = uint32_t(i);
+    if ((rc = dev_alloc(h, &h->d_perm, size_t(h->E_pad)))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_perm, h->h_perm.data(), sizeof(uint32_t) * h->E_pad, hipMemcpyHostToDevice));
+  }
+  std::vector<uint32_t>().swap(h->h_perm);
   h->mono_open = false;
   h->mono_done = true;
   return M3HIP_OK;
@@ -1830,6 +1901,7 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
   out->n_samples = h->n_samples;
   out->n_tiles_padded = h->n_padded;
   out->pad_responses = h->pad_responses;
+  out->n_grouped_chunks = h->n_grouped_chunks;
   return M3HIP_OK;
 }
 

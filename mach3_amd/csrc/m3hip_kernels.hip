@@ -697,7 +697,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
     // belong to somebody else's events and must touch nothing
     if (e >= bd.n_events) continue;
-    const uint64_t ev = (uint64_t)bd.first_event + e;
+    const uint64_t pos = (uint64_t)bd.first_event + e;
+    const uint64_t ev = a.perm ? (uint64_t)a.perm[pos] : pos;  // processing order -> event
     if (MODE & kModeEval) a.spline_w[ev] = w[q];
     if (MODE & (kModeFill | kModeEventW)) {
       float tw = mul_norm_weights(1.0f, a, ev);  // CalcWeightTotal, as in k_reweight_uniform

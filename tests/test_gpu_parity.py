@@ -557,6 +557,86 @@ def test_extreme_shapes(fresh_engine, case, monkeypatch):
             assert 0.15 < info.pad_responses / (info.pad_responses + n_resp) < 0.25
 
 
+@pytest.mark.parametrize("grouping", ["on", "off"])
+def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkeypatch):
+    """Events of three interaction modes (each with its own parameter list, a tenth of the splines flat and dropped)
+    in RANDOM order: as they come, every 256-event tile mixes the lists and the chunk would be all bricks.  The
+    engine groups the events by list for processing -- uniform / padded tiles -- while every per-event array and
+    result keeps the caller's order: weights, bins and likelihood against the oracle in the original order."""
+    rng = np.random.default_rng(55)
+    X7, X5 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2])
+    P, E = 24, 5000
+    xs = {p: (X7 if p % 2 else X5) for p in range(P) if p % 4}
+    modes = [list(range(0, 12)), list(range(6, 20)), list(range(10, 24))]
+    which = rng.integers(0, 3, E)
+    events = []
+    for e in range(E):
+        ev = []
+        for p in modes[which[e]]:
+            if p in xs:
+                if rng.random() < 0.1:
+                    continue                                   # flat spline: dropped
+                ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))))
+            else:
+                ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
+        events.append(ev)
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    if grouping == "off":
+        monkeypatch.setenv("M3HIP_GROUP_EVENTS", "0")
+    n_norm = 3
+    par = np.zeros(P + n_norm)
+    par[P:] = 1.0
+    opar = par.copy()
+    edges = np.linspace(0.0, 5.0, 41)
+    kin = rng.gamma(3.0, 0.45, E)
+    sample_id = rng.integers(0, 2, E).astype(np.int32)
+    nn = rng.integers(0, 3, E)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = (P + rng.integers(0, n_norm, int(norm_off[-1]))).astype(np.int16)
+    osc_idx = rng.integers(-1, 20, E).astype(np.int32)
+    osc = rng.random(20).astype(np.float32)
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, P, 7, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx, osc, omono)
+    osamp.set_test_statistic(capi.kBarlowBeeston)
+
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    info = fresh_engine.info()
+    if grouping == "on":
+        assert info.n_grouped_chunks == 1 and info.n_tiles_uniform >= 14 and info.n_tiles_brick <= 3
+    else:
+        assert info.n_grouped_chunks == 0 and info.n_tiles_uniform == 0 and info.n_tiles_brick == 5
+    sh = SampleHandlerFD(fresh_engine, 2, np.array([0, 40, 80], np.int32), par, capi.kBarlowBeeston)
+    sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sample_id, 40), osc_idx, norm_off, norm_idx)
+    sh.SetOscillationWeights(osc)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in range(3):
+        par[:P] = rng.uniform(-3.3, 3.3, P)
+        par[P:] = 1 + 0.05 * rng.standard_normal(n_norm)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetSplineWeights(0, E).view(np.uint32), omono.total_weights.view(np.uint32))
+        assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    mono.Evaluate()
+    mono.SynchroniseMemTransfer()
+    omono.evaluate()
+    assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32))
+    osamp.close()
+    omono.close()
+
+
 def test_brick_stage_limit_is_reported(fresh_engine):
     """more responses in a sparse 1024-event group than 30 stages hold: the upload is refused with a message,
     nothing is silently truncated"""
