@@ -153,7 +153,7 @@ struct m3hip_ctx {
   uint32_t* d_perm = nullptr;     // processing order: lane position -> event (binned-only spaces: grouped by pointer
                                   // list; monoliths: chunks whose events were grouped by parameter list at upload)
   bool perm_dirty = false;
-  std::vector<uint32_t> h_perm;   // monolith grouping, built chunk by chunk
+  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> grouped;  // (first event, order) of every grouped chunk
   bool perm_monolith = false;     // some chunk was grouped
   uint64_t n_grouped_chunks = 0;
 
@@ -328,7 +328,7 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bl_off); h->d_bl_off = nullptr;
   dev_free(h->d_bl_idx); h->d_bl_idx = nullptr;
   dev_free(h->d_perm); h->d_perm = nullptr;
-  h->h_perm.clear();
+  h->grouped.clear();
   h->perm_monolith = false;
   h->n_grouped_chunks = 0;
   h->h_bl_id.clear();
@@ -615,11 +615,10 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
       }
     }
   }
-  h->h_perm.resize(size_t(h->E + n_events));
-  for (uint64_t pos = 0; pos < n_events; ++pos) h->h_perm[size_t(h->E + pos)] = uint32_t(h->E + (order.empty() ? pos : order[pos]));
   if (!order.empty()) {
     h->perm_monolith = true;
     h->n_grouped_chunks++;
+    h->grouped.emplace_back(h->E, std::move(order));
   }
 
   // host staging (pinned) -> device
@@ -732,12 +731,15 @@ int m3hip_monolith_end(m3hip_handle h) {
   HIPCHK(h, hipMemset(h->d_osc, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: no oscillation pointer
   HIPCHK(h, hipMemset(h->d_spline_w, 0, sizeof(float) * h->E_pad));
   if (h->perm_monolith) {  // lane position -> event, identity over the padding and over the chunks that were not grouped
-    h->h_perm.resize(size_t(h->E_pad));
-    for (uint64_t i = h->E; i < h->E_pad; ++i) h->h_perm[size_t(i)] = uint32_t(i);
+    std::vector<uint32_t> perm(size_t(h->E_pad));
+    for (size_t i = 0; i < perm.size(); ++i) perm[i] = uint32_t(i);
+    for (const auto& g : h->grouped)
+      for (size_t pos = 0; pos < g.second.size(); ++pos) perm[size_t(g.first) + pos] = uint32_t(g.first + g.second[pos]);
     if ((rc = dev_alloc(h, &h->d_perm, size_t(h->E_pad)))) return rc;
-    HIPCHK(h, hipMemcpy(h->d_perm, h->h_perm.data(), sizeof(uint32_t) * h->E_pad, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_perm, perm.data(), sizeof(uint32_t) * h->E_pad, hipMemcpyHostToDevice));
   }
-  std::vector<uint32_t>().swap(h->h_perm);
+  h->grouped.clear();
+  h->grouped.shrink_to_fit();
   h->mono_open = false;
   h->mono_done = true;
   return M3HIP_OK;
