@@ -88,6 +88,19 @@ int m3hip_free_pinned(m3hip_handle h, void* ptr);
  * Large monoliths (> 2^32 coefficients, which the reference's unsigned offsets cannot
  * address) are streamed in event-ordered chunks: begin / append / end.  Offsets inside a
  * chunk are chunk-local.  Every chunk but the last must hold a multiple of 1024 events.
+ *
+ * What the upload does with the events (none of it is visible through this interface: every per-event
+ * array handed over later, and every per-event result, is in the event order of the upload):
+ *   - 256 events that carry the same ordered parameter list form a "uniform tile" (the streaming fast path);
+ *   - lists that differ only by a few missing entries (the reference drops an event's flat one-knot splines)
+ *     are padded to their union with identity responses {1,0,0,0} / {0,1}, which leave the float product
+ *     unchanged bit for bit (at least 78 % of the padded slots must be real; M3HIP_PAD_MIN_FILL);
+ *   - a chunk whose events mix several lists (interaction modes in random order) is PROCESSED grouped by
+ *     list -- a lane permutation inside the kernels -- when that avoids the slow path (M3HIP_GROUP_EVENTS=0
+ *     switches it off);
+ *   - what remains ragged is laid out as "bricks" (requires ascending parameter order inside an event).
+ * m3hip_get_info reports the outcome (n_tiles_uniform, n_tiles_padded, pad_responses, n_tiles_brick,
+ * n_grouped_chunks).
  */
 int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x,
                          const int16_t* npts);
