@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -116,6 +117,9 @@ struct m3hip_ctx {
   int32_t* d_osc = nullptr;
   int16_t* d_nidx = nullptr;
   uint32_t M = 0;
+  // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
+  // index with them unguarded)
+  int64_t max_osc_idx = -1, max_norm_idx = -1, max_parmap = -1;
   float* d_spline_w = nullptr;
   float* d_event_w = nullptr;
   float* d_osc_table = nullptr;
@@ -229,6 +233,25 @@ int fail(m3hip_handle h, int code, const std::string& msg) {
       return fail(h, e_ == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP,                          \
                   std::string(#expr) + ": " + hipGetErrorString(e_));                                \
   } while (0)
+
+// No C++ exception may leave an extern "C" entry point (the callers are C, ctypes, cgo ...): every entry point is a
+// function-try-block whose handler lands here and turns what was thrown into an error code + message.
+int api_exception(m3hip_handle h) noexcept {
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc&) {
+      return fail(h, M3HIP_ENOMEM, "host allocation failed (std::bad_alloc)");
+    } catch (const std::exception& e) {
+      return fail(h, M3HIP_EINVAL, std::string("unexpected exception: ") + e.what());
+    } catch (...) {
+      return fail(h, M3HIP_EINVAL, "unexpected exception");
+    }
+  } catch (...) {  // the message itself could not be stored
+    return M3HIP_ENOMEM;
+  }
+}
+#define M3_API_CATCH(h) catch (...) { return api_exception(h); }
 
 template <class T>
 int dev_alloc(m3hip_handle h, T** p, size_t n) {
@@ -346,6 +369,7 @@ void free_monolith(m3hip_handle h) {
   if (h->h_vals) { (void)hipHostFree(h->h_vals); h->h_vals = nullptr; }
   if (h->h_segs) { (void)hipHostFree(h->h_segs); h->h_segs = nullptr; }
   h->M = 0;
+  h->max_osc_idx = h->max_norm_idx = h->max_parmap = -1;
   h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
   h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
@@ -419,7 +443,7 @@ const char* m3hip_version(void) { return "mach3_amd/m3hip 0.1 (gfx950)"; }
 
 const char* m3hip_last_error(m3hip_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
-int m3hip_create(int device_id, m3hip_handle* out) {
+int m3hip_create(int device_id, m3hip_handle* out) try {
   if (!out) return fail(nullptr, M3HIP_EINVAL, "out is NULL");
   *out = nullptr;
   int n = 0;
@@ -439,9 +463,9 @@ int m3hip_create(int device_id, m3hip_handle* out) {
   h->stream = h->own_stream;
   *out = h;
   return M3HIP_OK;
-}
+} M3_API_CATCH(nullptr)
 
-int m3hip_destroy(m3hip_handle h) {
+int m3hip_destroy(m3hip_handle h) try {
   if (!h) return M3HIP_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
@@ -466,44 +490,45 @@ int m3hip_destroy(m3hip_handle h) {
   dev_free(h->d_sample_off);
   dev_free(h->d_data);
   dev_free(h->d_hist);
+  dev_free(h->d_dbg_clock);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_stream(m3hip_handle h, void* hip_stream) {
+int m3hip_set_stream(m3hip_handle h, void* hip_stream) try {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes) {
+int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes) try {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemGetInfo(free_bytes, total_bytes));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes) {
+int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes) try {
   if (!h || !ptr) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_free_pinned(m3hip_handle h, void* ptr) {
+int m3hip_free_pinned(m3hip_handle h, void* ptr) try {
   if (!h) return M3HIP_EINVAL;
   if (ptr) HIPCHK(h, hipHostFree(ptr));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- monolith upload */
 
-int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x, const int16_t* npts) {
+int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x, const int16_t* npts) try {
   if (!h) return M3HIP_EINVAL;
   if (n_params <= 0 || n_params > 32767 || max_knots < 1 || !coeff_x || !npts)
     return fail(h, M3HIP_EINVAL, "monolith_begin: bad n_params / max_knots / NULL arrays");
@@ -534,12 +559,12 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   HIPCHK(h, hipMemcpy(h->d_parmap, ident.data(), sizeof(int32_t) * n_params, hipMemcpyHostToDevice));
   h->mono_open = true;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
                           const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                           const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
-                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) {
+                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_append before monolith_begin");
   if (h->E % M3_GROUP != 0) return fail(h, M3HIP_EINVAL, "only the last chunk may hold a non-multiple of 1024 events");
@@ -615,19 +640,17 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
       }
     }
   }
-  if (!order.empty()) {
-    h->perm_monolith = true;
-    h->n_grouped_chunks++;
-    h->grouped.emplace_back(h->E, std::move(order));
-  }
-
   // host staging (pinned) -> device
-  float *s_spl = nullptr, *s_tf1 = nullptr;
-  int32_t* s_meta = nullptr;
+  struct Pinned {  // released on every way out of this function
+    void* p = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+  } st_spl, st_tf1, st_meta;
   const size_t b_spl = size_t(plan.spl_float4) * 16, b_tf1 = size_t(plan.tf1_float2) * 8, b_meta = size_t(plan.meta_int32) * 4;
-  HIPCHK(h, hipHostMalloc((void**)&s_spl, b_spl ? b_spl : 16, hipHostMallocDefault));
-  HIPCHK(h, hipHostMalloc((void**)&s_tf1, b_tf1 ? b_tf1 : 16, hipHostMallocDefault));
-  HIPCHK(h, hipHostMalloc((void**)&s_meta, b_meta ? b_meta : 16, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc(&st_spl.p, b_spl ? b_spl : 16, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc(&st_tf1.p, b_tf1 ? b_tf1 : 16, hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc(&st_meta.p, b_meta ? b_meta : 16, hipHostMallocDefault));
+  float *s_spl = static_cast<float*>(st_spl.p), *s_tf1 = static_cast<float*>(st_tf1.p);
+  int32_t* s_meta = static_cast<int32_t*>(st_meta.p);
   fill_chunk(h->P, h->h_npts.data(), in, plan, s_spl, s_tf1, s_meta);
   const std::vector<int32_t> h_meta(s_meta, s_meta + plan.meta_int32);
 
@@ -639,12 +662,14 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   if (e == hipSuccess && b_words) e = hipMemcpy(c.d_words, plan.brick_words.data(), b_words, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
-  (void)hipHostFree(s_spl);
-  (void)hipHostFree(s_tf1);
-  (void)hipHostFree(s_meta);
   if (e != hipSuccess) {
     dev_free(c.d_spl); dev_free(c.d_tf1); dev_free(c.d_words);
     return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("monolith_append upload: ") + hipGetErrorString(e));
+  }
+  if (!order.empty()) {  // only now: a chunk that failed to upload leaves no trace
+    h->perm_monolith = true;
+    h->n_grouped_chunks++;
+    h->grouped.emplace_back(h->E, std::move(order));
   }
   h->chunks.push_back(c);
   for (const TileHost& th : plan.tiles) {
@@ -698,9 +723,9 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   h->T += n_tf1;
   h->coeff_bytes += b_spl + b_tf1;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_monolith_end(m3hip_handle h) {
+int m3hip_monolith_end(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_end before monolith_begin");
   HIPCHK(h, hipSetDevice(h->device));
@@ -743,24 +768,24 @@ int m3hip_monolith_end(m3hip_handle h) {
   h->mono_open = false;
   h->mono_done = true;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 int m3hip_upload_monolith(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* coeff_x,
                           const int16_t* npts, const float* coeff_many, uint64_t total_nknots,
                           const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                           const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
-                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) {
+                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) try {
   int rc = m3hip_monolith_begin(h, n_params, max_knots, coeff_x, npts);
   if (rc) return rc;
   rc = m3hip_monolith_append(h, n_events, coeff_many, total_nknots, nknots_arr, param_no, n_splines, coeff_tf1,
                              param_no_tf1, n_tf1, n_param_per_event, n_param_per_event_tf1);
   if (rc) return rc;
   return m3hip_monolith_end(h);
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- seam 2 per step */
 
-int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment, float* cpu_total_weights) {
+int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment, float* cpu_total_weights) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_done) return fail(h, M3HIP_ESTATE, "eval_splines before the monolith was uploaded");
   if (!vals || !segment) return fail(h, M3HIP_EINVAL, "eval_splines: NULL vals / segment");
@@ -807,32 +832,36 @@ int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment
   if (cpu_total_weights)  // gpuSplineUtils.cu:505 cudaMemcpyAsync(cpu_total_weights, gpu_total_weights, ...)
     HIPCHK(h, hipMemcpyAsync(cpu_total_weights, h->d_spline_w, sizeof(float) * h->E, hipMemcpyDeviceToHost, h->stream));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_sync(m3hip_handle h) {
+int m3hip_sync(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, wait_stream(h->stream));
   collect_timing(h);
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- seam 3 setup */
 
-int m3hip_set_spline_param_map(m3hip_handle h, const int32_t* global_index, int n_params) {
+int m3hip_set_spline_param_map(m3hip_handle h, const int32_t* global_index, int n_params) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_open && !h->mono_done) return fail(h, M3HIP_ESTATE, "set_spline_param_map before monolith_begin");
   if (!global_index || n_params != h->P) return fail(h, M3HIP_EINVAL, "set_spline_param_map: n_params mismatch");
-  for (int i = 0; i < n_params; ++i)
+  int64_t mx = -1;
+  for (int i = 0; i < n_params; ++i) {
     if (global_index[i] < 0) return fail(h, M3HIP_EINVAL, "set_spline_param_map: negative index");
+    mx = std::max<int64_t>(mx, global_index[i]);
+  }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_parmap, global_index, sizeof(int32_t) * n_params, hipMemcpyHostToDevice));
   h->parmap_set = true;
+  h->max_parmap = mx;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_offset) {
+int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_offset) try {
   if (!h) return M3HIP_EINVAL;
   if (n_samples <= 0 || !sample_bin_offset || sample_bin_offset[0] != 0) return fail(h, M3HIP_EINVAL, "set_binning: bad offsets");
   for (int s = 0; s < n_samples; ++s)
@@ -858,10 +887,10 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   h->first_w2 = true;
   h->w2_spread = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* bin_idx,
-                        const int32_t* osc_idx, const uint64_t* norm_off, const int16_t* norm_idx) {
+                        const int32_t* osc_idx, const uint64_t* norm_off, const int16_t* norm_idx) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_done) return fail(h, M3HIP_ESTATE, "upload_events before monolith_end");
   if (event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "upload_events: range exceeds the monolith's events");
@@ -873,8 +902,12 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
     for (uint64_t i = 0; i < n; ++i)
       if (bin_idx[i] < -1 || bin_idx[i] >= h->n_bins) return fail(h, M3HIP_EINVAL, "upload_events: bin index out of range");
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-  if (osc_idx) HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (osc_idx) {
+    for (uint64_t i = 0; i < n; ++i) h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
+    HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  }
   if (norm_off) {
+    if (norm_off[n] > norm_off[0] && !norm_idx) return fail(h, M3HIP_EINVAL, "upload_events: norm_idx is NULL");
     uint32_t mx = 0;
     for (uint64_t i = 0; i < n; ++i) {
       const uint64_t c = norm_off[i + 1] - norm_off[i];
@@ -898,13 +931,14 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
           const uint64_t c = norm_off[i + 1] - norm_off[i];
           plane[i] = (m < c) ? norm_idx[norm_off[i] + m] : int16_t(-1);
           if (m < c && plane[i] < 0) return fail(h, M3HIP_EINVAL, "upload_events: negative norm parameter index");
+          h->max_norm_idx = std::max<int64_t>(h->max_norm_idx, plane[i]);
         }
         HIPCHK(h, hipMemcpy(h->d_nidx + size_t(m) * h->E_pad + event_offset, plane.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice));
       }
     }
   }
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 // shared part of m3hip_binned_upload / _f64: validation, the empty event space, the index tables
 static int binned_upload_common(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
@@ -947,7 +981,7 @@ static int binned_upload_common(m3hip_handle h, uint64_t n_events, int n_params,
 
 int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts, const int16_t* npts,
                         int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
-                        const int32_t* uniquecoeffindices, int n_coeff, const float* xcoeff, const float* manycoeff) {
+                        const int32_t* uniquecoeffindices, int n_coeff, const float* xcoeff, const float* manycoeff) try {
   if (!h) return M3HIP_EINVAL;
   int rc = binned_upload_common(h, n_events, n_params, max_knots, xpts, npts, monolith_size, coeffindexvec, uniquesplinevec, n_unique,
                                 uniquecoeffindices, n_coeff, xcoeff, manycoeff);
@@ -962,11 +996,11 @@ int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max
   std::vector<float> ones(size_t(monolith_size), 1.0f);  // flat bin-splines keep weight 1 (BinnedSplineHandler.cpp:236)
   HIPCHK(h, hipMemcpy(h->d_b_w, ones.data(), sizeof(float) * monolith_size, hipMemcpyHostToDevice));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 int m3hip_binned_upload_f64(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const double* xpts, const int16_t* npts,
                             int monolith_size, const int32_t* coeffindexvec, const int32_t* uniquesplinevec, int n_unique,
-                            const int32_t* uniquecoeffindices, int n_coeff, const double* xcoeff, const double* manycoeff) {
+                            const int32_t* uniquecoeffindices, int n_coeff, const double* xcoeff, const double* manycoeff) try {
   if (!h) return M3HIP_EINVAL;
   if (!xpts || !npts || n_params <= 0 || max_knots <= 0) return fail(h, M3HIP_EINVAL, "binned_upload_f64: NULL / empty knot table");
   // the float knot table only feeds dx of event-by-event splines, of which this build has none
@@ -988,9 +1022,9 @@ int m3hip_binned_upload_f64(m3hip_handle h, uint64_t n_events, int n_params, int
   HIPCHK(h, hipMemcpy(h->d_b_w_d, ones.data(), sizeof(double) * monolith_size, hipMemcpyHostToDevice));
   h->f64 = true;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const uint64_t* w_off, const int32_t* w_idx) {
+int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const uint64_t* w_off, const int32_t* w_idx) try {
   if (!h) return M3HIP_EINVAL;
   if (h->b_M == 0) return fail(h, M3HIP_ESTATE, "binned_upload_events before binned_upload");
   if (event_offset + n > h->E || !w_off) return fail(h, M3HIP_EINVAL, "binned_upload_events: bad range / NULL");
@@ -1071,9 +1105,9 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
     HIPCHK(h, hipMemcpy(h->d_bwidx + size_t(k) * h->E_pad + event_offset, plane.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
   }
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_binned_weights_f64(m3hip_handle h, double* out, int monolith_size) {
+int m3hip_get_binned_weights_f64(m3hip_handle h, double* out, int monolith_size) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (monolith_size != h->b_M || h->b_M == 0) return fail(h, M3HIP_EINVAL, "get_binned_weights_f64: size mismatch");
   if (!h->f64) return fail(h, M3HIP_ESTATE, "get_binned_weights_f64: the bin-splines were uploaded as float");
@@ -1081,9 +1115,9 @@ int m3hip_get_binned_weights_f64(m3hip_handle h, double* out, int monolith_size)
   HIPCHK(h, wait_stream(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_b_w_d, sizeof(double) * monolith_size, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) {
+int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (monolith_size != h->b_M || h->b_M == 0) return fail(h, M3HIP_EINVAL, "get_binned_weights: size mismatch");
   if (h->f64) return fail(h, M3HIP_ESTATE, "get_binned_weights: the bin-splines were uploaded as double, use _f64");
@@ -1091,15 +1125,15 @@ int m3hip_get_binned_weights(m3hip_handle h, float* out, int monolith_size) {
   HIPCHK(h, wait_stream(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_b_w, sizeof(float) * monolith_size, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_binning_begin(m3hip_handle h) {
+int m3hip_binning_begin(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   h->bb_samples.clear(); h->bb_axes.clear(); h->bb_edges.clear(); h->bb_boxes.clear();
   h->bb_grid_off.clear(); h->bb_grid_list.clear(); h->bb_nbins.clear();
   h->binning_open = true;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 // one axis of a sample: edges appended to the shared table, stride = product of the earlier axes' bins
 // (SampleBinningInfo::InitialiseStrides, SampleStructs.h:648-659)
@@ -1114,7 +1148,7 @@ static void push_axis(m3hip_handle h, const double* e, int ne, int& stride) {
   stride *= ne - 1;
 }
 
-int m3hip_binning_add_uniform(m3hip_handle h, int n_dim, const int32_t* n_edges, const double* edges) {
+int m3hip_binning_add_uniform(m3hip_handle h, int n_dim, const int32_t* n_edges, const double* edges) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_add_uniform outside binning_begin/end");
   if (!n_edges || !edges) return fail(h, M3HIP_EINVAL, "binning_add_uniform: NULL arguments");
@@ -1142,9 +1176,9 @@ int m3hip_binning_add_uniform(m3hip_handle h, int n_dim, const int32_t* n_edges,
   h->bb_samples.push_back(bs);
   h->bb_nbins.push_back(stride);
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_binning_add_nonuniform(m3hip_handle h, int n_boxes, int n_dim, const double* extents) {
+int m3hip_binning_add_nonuniform(m3hip_handle h, int n_boxes, int n_dim, const double* extents) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_add_nonuniform outside binning_begin/end");
   if (!extents) return fail(h, M3HIP_EINVAL, "binning_add_nonuniform: NULL arguments");
@@ -1199,9 +1233,9 @@ int m3hip_binning_add_nonuniform(m3hip_handle h, int n_boxes, int n_dim, const d
   h->bb_samples.push_back(bs);
   h->bb_nbins.push_back(n_boxes);
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_binning_end(m3hip_handle h) {
+int m3hip_binning_end(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->binning_open) return fail(h, M3HIP_ESTATE, "binning_end without binning_begin");
   const int n_samples = int(h->bb_samples.size());
@@ -1235,9 +1269,9 @@ int m3hip_binning_end(m3hip_handle h) {
   for (const BinSample& s : h->bb_samples) h->h_sample_ndim.push_back(s.n_dim);
   h->bins_computed = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) {
+int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim, const int32_t* n_edges, const double* edges) try {
   if (!h) return M3HIP_EINVAL;
   if (n_samples <= 0 || !n_dim || !n_edges || !edges) return fail(h, M3HIP_EINVAL, "set_binning_edges: NULL / empty arguments");
   int rc = m3hip_binning_begin(h);
@@ -1251,9 +1285,9 @@ int m3hip_set_binning_edges(m3hip_handle h, int n_samples, const int32_t* n_dim,
   }
   if (rc) { h->binning_open = false; return rc; }
   return m3hip_binning_end(h);
-}
+} M3_API_CATCH(h)
 
-int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id, const double* kin, int kin_stride) {
+int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, const int32_t* sample_id, const double* kin, int kin_stride) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_done) return fail(h, M3HIP_ESTATE, "upload_kinematics before monolith_end");
   if (h->h_sample_ndim.empty()) return fail(h, M3HIP_ESTATE, "upload_kinematics before set_binning_edges");
@@ -1283,11 +1317,13 @@ int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, c
   HIPCHK(h, hipMemcpy(h->d_kin + event_offset * kin_stride, kin, sizeof(double) * n * kin_stride, hipMemcpyHostToDevice));
   h->bins_computed = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_compute_bins(m3hip_handle h) {
+int m3hip_compute_bins(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->d_kin || !h->d_bin_samples) return fail(h, M3HIP_ESTATE, "compute_bins needs set_binning_edges and upload_kinematics");
+  for (const KinCut& c : h->h_cuts)
+    if (c.column >= h->kin_stride) return fail(h, M3HIP_EINVAL, "compute_bins: a selection cut names a column beyond kin_stride");
   HIPCHK(h, hipSetDevice(h->device));
   BinArgs b = make_bin_args(h);
   b.compute_nominal = 1;
@@ -1297,7 +1333,7 @@ int m3hip_compute_bins(m3hip_handle h) {
   HIPCHK(h, wait_stream(h->stream));
   h->bins_computed = true;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 static int add_shift(m3hip_handle h, int sample, int dim, int kind, int aux, int param_index) {
   if (dim < 0 || dim >= M3_MAX_DIM || kind < 1 || kind > 3 || aux < 0 || aux >= M3_MAX_DIM || param_index < 0 || sample < -1)
@@ -1315,18 +1351,18 @@ static int add_shift(m3hip_handle h, int sample, int dim, int kind, int aux, int
   return M3HIP_OK;
 }
 
-int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index) {
+int m3hip_add_kin_shift(m3hip_handle h, int sample, int dim, int kind, int param_index) try {
   if (!h) return M3HIP_EINVAL;
   if (kind != 1 && kind != 2) return fail(h, M3HIP_EINVAL, "add_kin_shift: kind must be 1 (scale) or 2 (offset)");
   return add_shift(h, sample, dim, kind, 0, param_index);
-}
+} M3_API_CATCH(h)
 
-int m3hip_add_kin_shift_aux(m3hip_handle h, int sample, int dim, int aux_column, int param_index) {
+int m3hip_add_kin_shift_aux(m3hip_handle h, int sample, int dim, int aux_column, int param_index) try {
   if (!h) return M3HIP_EINVAL;
   return add_shift(h, sample, dim, 3, aux_column, param_index);
-}
+} M3_API_CATCH(h)
 
-int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, double upper) {
+int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, double upper) try {
   if (!h) return M3HIP_EINVAL;
   if (column < 0 || column >= M3_MAX_DIM || sample < -1 || !(lower <= upper)) return fail(h, M3HIP_EINVAL, "add_kin_cut: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1341,25 +1377,25 @@ int m3hip_add_kin_cut(m3hip_handle h, int sample, int column, double lower, doub
   HIPCHK(h, hipMemcpy(h->d_cuts, h->h_cuts.data(), sizeof(KinCut) * h->h_cuts.size(), hipMemcpyHostToDevice));
   if (h->bins_computed) return m3hip_compute_bins(h);  // the selection changes which events fill
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_clear_kin_shifts(m3hip_handle h) {
+int m3hip_clear_kin_shifts(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, wait_stream(h->stream));
   h->h_shifts.clear();
   if (h->bins_computed) return m3hip_compute_bins(h);  // back to the nominal bins
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, uint64_t n) {
+int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, uint64_t n) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_bins: bad range");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, wait_stream(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_bin + event_offset, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 static int osc_table_resize(m3hip_handle h, uint64_t n) {
   if (n == h->n_osc) return M3HIP_OK;
@@ -1400,7 +1436,7 @@ static int osc_upload(m3hip_handle h, const void* table, uint64_t n, size_t elem
   return M3HIP_OK;
 }
 
-int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
+int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) try {
   if (!h) return M3HIP_EINVAL;
   if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table: empty table");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1410,9 +1446,9 @@ int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) {
   h->osc_valid_f32 = true;
   h->osc_valid_f64 = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) {
+int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) try {
   if (!h) return M3HIP_EINVAL;
   if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_osc_table_f64: empty table");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1422,9 +1458,9 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) {
   h->osc_valid_f64 = true;
   h->osc_valid_f32 = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) {
+int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) try {
   if (!h) return M3HIP_EINVAL;
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "set_data before set_binning");
   if (!data || n_bins != h->n_bins) return fail(h, M3HIP_EINVAL, "set_data: n_bins mismatch");
@@ -1432,26 +1468,33 @@ int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->d_data, data, sizeof(double) * n_bins, hipMemcpyHostToDevice));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2) {
+int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2) try {
   if (!h) return M3HIP_EINVAL;
   if (kind < 0 || kind > 4) return fail(h, M3HIP_EINVAL, "set_test_statistic: unknown kind");
   h->teststat = kind;
   h->update_w2 = update_w2 != 0;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- seam 3 per step */
 
-int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
+int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_done) return fail(h, M3HIP_ESTATE, "reweight before the monolith was uploaded");
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "reweight before set_binning");
   if (!params || n_par <= 0) return fail(h, M3HIP_EINVAL, "reweight: empty parameter vector");
   if (!h->parmap_set && n_par < h->P) return fail(h, M3HIP_EINVAL, "reweight: parameter vector shorter than the spline parameters");
-  for (const KinShift& k : h->h_shifts)
+  if (h->parmap_set && h->max_parmap >= n_par) return fail(h, M3HIP_EINVAL, "reweight: the spline parameter map points past the parameter vector");
+  if (h->max_norm_idx >= n_par) return fail(h, M3HIP_EINVAL, "reweight: an event's norm parameter index points past the parameter vector");
+  if (h->max_osc_idx >= int64_t(h->n_osc))
+    return fail(h, M3HIP_EINVAL, "reweight: an event's oscillation index (" + std::to_string(h->max_osc_idx) + ") points past the oscillation table (" +
+                                     std::to_string(h->n_osc) + " entries; m3hip_set_osc_table)");
+  for (const KinShift& k : h->h_shifts) {
     if (k.param >= n_par) return fail(h, M3HIP_EINVAL, "reweight: a kinematic shift points past the parameter vector");
+    if (k.dim >= h->kin_stride || (k.kind >> 8) >= h->kin_stride) return fail(h, M3HIP_EINVAL, "reweight: a kinematic shift names a column beyond kin_stride");
+  }
   const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_param_capacity(h, n_par);
@@ -1606,9 +1649,9 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) {
   h->host_t[1] = t_c - t_b;
   h->host_t[2] = t_d - t_c;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) {
+int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) try {
   if (!h) return M3HIP_EINVAL;
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "get_likelihood before set_binning");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1663,15 +1706,15 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   if (per_sample)
     for (int s = 0; s < h->n_samples; ++s) per_sample[s] = h->h_out[1 + s];
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_step(m3hip_handle h, const double* params, int n_par, double* llh_total, double* per_sample) {
+int m3hip_step(m3hip_handle h, const double* params, int n_par, double* llh_total, double* per_sample) try {
   int rc = m3hip_reweight(h, params, n_par);
   if (rc) return rc;
   return m3hip_get_likelihood(h, llh_total, per_sample);
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) {
+int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) try {
   if (!h) return M3HIP_EINVAL;
   if (h->n_bins == 0 || n_bins != h->n_bins) return fail(h, M3HIP_EINVAL, "get_bins: n_bins mismatch");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1690,9 +1733,9 @@ int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) {
     if (w2) w2[i] = v;
   }
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) {
+int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_spline_weights: bad range");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1700,15 +1743,15 @@ int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, 
   collect_timing(h);
   HIPCHK(h, hipMemcpy(out, h->d_spline_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_record_event_weights(m3hip_handle h, int enable) {
+int m3hip_record_event_weights(m3hip_handle h, int enable) try {
   if (!h) return M3HIP_EINVAL;
   h->want_event_w = enable != 0;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) {
+int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, uint64_t n) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_weights: bad range");
   if (!h->d_event_w) return fail(h, M3HIP_ESTATE, "get_event_weights: call m3hip_record_event_weights(h, 1) before the reweight");
@@ -1717,9 +1760,9 @@ int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, u
   collect_timing(h);
   HIPCHK(h, hipMemcpy(out, h->d_event_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offset, uint64_t n) {
+int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offset, uint64_t n) try {
   if (!h || !out) return M3HIP_EINVAL;
   if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_weights_f64: bad range");
   if (!h->d_event_w_d) return fail(h, M3HIP_ESTATE, "get_event_weights_f64: needs m3hip_binned_upload_f64 and m3hip_record_event_weights(h, 1) before the reweight");
@@ -1728,9 +1771,9 @@ int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offs
   collect_timing(h);
   HIPCHK(h, hipMemcpy(out, h->d_event_w_d + event_offset, sizeof(double) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_params) {
+int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_params) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_done || n_params != h->P) return fail(h, M3HIP_EINVAL, "get_segments: n_params mismatch");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1738,20 +1781,20 @@ int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_par
   if (segments) HIPCHK(h, hipMemcpy(segments, h->d_seg, sizeof(int16_t) * n_params, hipMemcpyDeviceToHost));
   if (vals) HIPCHK(h, hipMemcpy(vals, h->d_pval, sizeof(float) * n_params, hipMemcpyDeviceToHost));
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- multi-GPU */
 
-int m3hip_comm_get_unique_id(void* out_id) {
+int m3hip_comm_get_unique_id(void* out_id) try {
   if (!out_id) return M3HIP_EINVAL;
   std::string err;
   if (!g_rccl.load(&err)) return fail(nullptr, M3HIP_ECOMM, err);
   int r = g_rccl.GetUniqueId(out_id);
   if (r != 0) return fail(nullptr, M3HIP_ECOMM, "ncclGetUniqueId failed");
   return M3HIP_OK;
-}
+} M3_API_CATCH(nullptr)
 
-int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks) {
+int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks) try {
   if (!h || !unique_id) return M3HIP_EINVAL;
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, M3HIP_EINVAL, "comm_init: bad rank / n_ranks");
   std::string err;
@@ -1767,9 +1810,9 @@ int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks
   h->rank = rank;
   h->n_ranks = n_ranks;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_comm_destroy(m3hip_handle h) {
+int m3hip_comm_destroy(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (h->comm) {
     (void)hipStreamSynchronize(h->stream);
@@ -1779,32 +1822,32 @@ int m3hip_comm_destroy(m3hip_handle h) {
   h->rank = 0;
   h->n_ranks = 1;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- test hooks */
 
-int m3hip_debug_set_knobs(m3hip_handle h, int unroll, int nt, int lds_pad) {
+int m3hip_debug_set_knobs(m3hip_handle h, int unroll, int nt, int lds_pad) try {
   if (!h) return M3HIP_EINVAL;
   h->knobs.unroll = unroll;
   h->knobs.nt = nt;
   h->knobs.lds_pad = lds_pad;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) {
+int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) try {
   if (!h || n < 1 || n > 64) return M3HIP_EINVAL;
   if (h->n_bins != 0) return fail(h, M3HIP_ESTATE, "set_hist_replicas must precede set_binning");
   h->hist_rep = n;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_debug_host_times(m3hip_handle h, double* out6) {
+int m3hip_debug_host_times(m3hip_handle h, double* out6) try {
   if (!h || !out6) return M3HIP_EINVAL;
   for (int i = 0; i < 6; ++i) out6[i] = h->host_t[i];
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us) {
+int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us) try {
   if (!h) return M3HIP_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   if (enable && !h->d_dbg_clock) {
@@ -1821,9 +1864,9 @@ int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us) {
     last_us[4] = h->host_abs[1] * 1e6;                 // ... when the completion flag was seen
   }
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins) {
+int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int n_bins) try {
   if (!h) return M3HIP_EINVAL;
   if (h->n_bins == 0 || n_bins != h->n_bins || !mc || !w2) return fail(h, M3HIP_EINVAL, "debug_set_bins: n_bins mismatch");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1833,7 +1876,7 @@ int m3hip_debug_set_bins(m3hip_handle h, const double* mc, const double* w2, int
   HIPCHK(h, hipMemcpy(h->d_hist + size_t(h->hist_rep) * n_bins, w2, sizeof(double) * n_bins, hipMemcpyHostToDevice));
   h->w2_spread = false;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- host-only layout probe */
 
@@ -1842,7 +1885,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
                        uint64_t n_splines, const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
                        const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1,
                        uint64_t* sizes, float* spl, float* tf1, int32_t* meta, uint64_t* tile_desc,
-                       uint64_t* brick_desc, uint32_t* brick_words) {
+                       uint64_t* brick_desc, uint32_t* brick_words) try {
   if (!npts || !sizes) return fail(nullptr, M3HIP_EINVAL, "debug_layout: NULL arguments");
   ChunkInput in;
   in.n_events = n_events;
@@ -1882,11 +1925,11 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   }
   if (!plan.brick_words.empty()) memcpy(brick_words, plan.brick_words.data(), plan.brick_words.size() * sizeof(uint32_t));
   return M3HIP_OK;
-}
+} M3_API_CATCH(nullptr)
 
 /* ---------------------------------------------------------------- introspection */
 
-int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
+int m3hip_get_info(m3hip_handle h, m3hip_info* out) try {
   if (!h || !out) return M3HIP_EINVAL;
   memset(out, 0, sizeof(*out));
   out->n_events = h->E;
@@ -1905,27 +1948,27 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) {
   out->pad_responses = h->pad_responses;
   out->n_grouped_chunks = h->n_grouped_chunks;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_timing_enable(m3hip_handle h, int enable) {
+int m3hip_timing_enable(m3hip_handle h, int enable) try {
   if (!h) return M3HIP_EINVAL;
   h->timing = enable > 0 ? enable : 0;
   h->timing_ctr = 0;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches) {
+int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches) try {
   if (!h || which < 0 || which > 1) return M3HIP_EINVAL;
   if (avg_ms) *avg_ms = h->cnt[which] ? h->acc_ms[which] / double(h->cnt[which]) : 0.0;
   if (n_launches) *n_launches = h->cnt[which];
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
-int m3hip_timing_reset(m3hip_handle h) {
+int m3hip_timing_reset(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   h->acc_ms[0] = h->acc_ms[1] = 0;
   h->cnt[0] = h->cnt[1] = 0;
   return M3HIP_OK;
-}
+} M3_API_CATCH(h)
 
 }  // extern "C"

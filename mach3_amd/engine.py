@@ -300,7 +300,7 @@ class SampleHandlerFD:
             self.eng.h, event_offset, n, _ptr(np.ascontiguousarray(bin_idx, np.int32), np.int32),
             _ptr(np.ascontiguousarray(osc_idx, np.int32), np.int32) if osc_idx is not None else None,
             _ptr(np.ascontiguousarray(norm_off, np.uint64), np.uint64) if norm_off is not None else None,
-            _ptr(np.ascontiguousarray(norm_idx, np.int16), np.int16) if norm_off is not None else None))
+            _ptr(np.ascontiguousarray(norm_idx, np.int16), np.int16) if norm_idx is not None else None))
 
     # ---- device-side binning (ref: Samples/BinningHandler.cpp:257-307, SampleStructs.h:577-613)
     def SetupKinematics(self, event_offset, sample_id, kin):

@@ -341,6 +341,25 @@ def test_api_error_paths(fresh_engine):
         sh.SetupEvents(0, np.full(300, 10, np.int32), None, None, None)   # bin index out of range
     with pytest.raises(capi.M3HipError):
         sh.AddData(np.zeros(9))
+    # indices the kernels use unguarded are checked against the table / vector sizes before anything is launched
+    bins = np.zeros(300, np.int32)
+    sh.SetupEvents(0, bins, np.full(300, 5, np.int32), None, None)
+    with pytest.raises(capi.M3HipError, match="oscillation"):
+        sh.Reweight()                                   # oscillation indices, no table
+    sh.SetOscillationWeights(np.ones(5, np.float32))
+    with pytest.raises(capi.M3HipError, match="oscillation"):
+        sh.Reweight()                                   # index 5 of a 5-entry table
+    sh.SetOscillationWeights(np.ones(6, np.float32))
+    sh.Reweight()
+    assert sh.GetMCArray().sum() > 0
+    with pytest.raises(capi.M3HipError, match="norm_idx"):
+        sh.SetupEvents(0, bins, None, np.arange(301, dtype=np.uint64), None)
+    sh.SetupEvents(0, bins, None, np.arange(301, dtype=np.uint64), np.full(300, len(par), np.int16))
+    with pytest.raises(capi.M3HipError, match="norm parameter"):
+        sh.Reweight()                                   # norm index == len(par)
+    mono.setSplinePointers(par, np.arange(4) + len(par) - 3)
+    with pytest.raises(capi.M3HipError, match="map"):
+        sh.Reweight()
 
 
 @pytest.mark.parametrize("cfg,n_events,n_params", [("c3", 5000, 96), ("c5", 3000, 512), ("c3", 1024 * 9 + 77, 512)])
