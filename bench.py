@@ -186,14 +186,20 @@ def main():
     comm_mode = "none"
     if (world > 1 or force_comm) and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
         # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
-        try:
-            uid = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init(uid[0], rank, world)
-            ok = torch.ones(1, device="cuda")
-        except Exception as e:  # keep the scaling run alive: exchange the bins through torch.distributed instead
-            log(f"rank {rank}: in-library RCCL init failed ({e}); falling back to torch.distributed all_reduce")
-            ok = torch.zeros(1, device="cuda")
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [eng.comm_unique_id()]
+            except Exception as e:
+                log(f"rank 0: ncclGetUniqueId failed ({e})")
+        dist.broadcast_object_list(uid, src=0)  # every rank takes part, whatever rank 0 got
+        ok = torch.zeros(1, device="cuda")
+        if uid[0] is not None:
+            try:
+                eng.comm_init(uid[0], rank, world)
+                ok = torch.ones(1, device="cuda")
+            except Exception as e:  # keep the scaling run alive: exchange the bins through torch.distributed instead
+                log(f"rank {rank}: in-library RCCL init failed ({e}); falling back to torch.distributed all_reduce")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) > 0:
             comm_mode = "rccl-allreduce(f64[n_bins]) in-library, one per step"

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
         b = a.bin[ev];
       }
       // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`
-      const bool fills = lane < td.n_events && tw > WT(0) && b >= 0;
+      const bool fills = lane < td.n_events && !(tw <= WT(0)) && b >= 0;  // written as the reference's test: a NaN weight fills
       const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
       if (!a.hist_lds) {  // many bins: straight into this workgroup's replica
         if (fills) {
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         } else {
           b = a.bin[ev];
         }
-        if (e < bd.n_events && tw > 0.f && b >= 0) {
+        if (e < bd.n_events && !(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
           if (a.hist_lds) {
             atomicAdd(&lds_hist[b], (double)tw);
             if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));

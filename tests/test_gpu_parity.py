@@ -277,6 +277,60 @@ def test_fill_semantics_on_device(fresh_engine):
     omono.close()
 
 
+def test_non_finite_weights_follow_the_reference(fresh_engine):
+    """`if (totalweight <= 0.) continue;` (SampleHandlerFD.cpp:432) lets a NaN weight through: its bin, and with it
+    the likelihood, turn NaN -- which is how a broken response shows up in a chain.  -inf is dropped, +inf fills."""
+    X7 = np.arange(-3.0, 4.0)
+    good = natural_cubic(X7, 1 + 0.1 * X7)
+    E = 700
+    events = []
+    special = {5: np.nan, 300: np.inf, 301: -np.inf, 650: np.nan}
+    for e in range(E):
+        c = good.copy()
+        if e in special:
+            c[:, 0] = special[e]
+        events.append([(0, "spl", c), (1, "spl", good)])
+    cx, npts, ch = make_monolith(2, 7, {0: X7, 1: X7}, events)
+    par = np.array([0.3, -0.4])
+    kin = np.linspace(0.01, 3.99, E)
+    edges = np.array([0.0, 1.0, 2.0, 3.0, 4.0])
+    lib = ob.load("serial")
+    omono = ob.OracleMonolith(lib, 2, 7, cx, npts, ch)
+    opar = par.copy()
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    sid = np.zeros(E, np.int32)
+    off0 = np.zeros(E + 1, np.uint64)
+    osamp = ob.OracleSample(lib, b, sid, kin, off0, np.zeros(0, np.int16), opar, np.full(E, -1, np.int32), np.ones(1, np.float32), omono)
+    bins = osamp.event_bins()
+    mono = SMonolith(fresh_engine, 2, 7, cx, npts, [ch])
+    mono.setSplinePointers(par, [0, 1])
+    sh = SampleHandlerFD(fresh_engine, 1, np.array([0, 4], np.int32), par, capi.kPoisson)
+    sh.SetupEvents(0, bins, None, None, None)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    ew, gw = osamp.event_weights(), sh.GetEventWeights(0, E)
+    assert np.isnan(ew[[5, 650]]).all() and ew[300] == np.inf and ew[301] == -np.inf
+    assert np.array_equal(np.isnan(gw), np.isnan(ew))
+    fin = ~np.isnan(ew)
+    assert np.array_equal(gw[fin].view(np.uint32), ew[fin].view(np.uint32))
+    mc, omc = sh.GetMCArray(), np.asarray(osamp.mc)
+    assert list(bins[[5, 300, 301, 650]]) == [0, 1, 1, 3]
+    assert np.isnan(omc[0]) and np.isnan(omc[3]) and omc[1] == np.inf and np.isfinite(omc[2])   # +inf filled, -inf was dropped
+    assert np.array_equal(np.isnan(mc), np.isnan(omc))
+    assert np.allclose(mc[~np.isnan(omc)], omc[~np.isnan(omc)], rtol=RTOL_BIN)
+    data = np.array([100.0, 150.0, 170.0, 120.0])
+    sh.AddData(data)
+    osamp.add_data(data)
+    got, want = sh.GetLikelihood(), osamp.get_likelihood()
+    assert (np.isnan(got) and np.isnan(want)) or got == want
+    assert np.isnan(want)
+    osamp.close()
+    omono.close()
+
+
 def test_mixed_uniform_tf1_and_short_splines(fresh_engine):
     """TSpline3 parameters with 3/7/5 knots and TF1 parameters in one uniform event list; the
     product order is splines (event order) then TF1s (ref: SplineMonolith.cpp:792-830)."""
