@@ -201,7 +201,17 @@ class MCMCBase {
  public:
   explicit MCMCBase(uint64_t seed = 12345) : random(seed) {}
   virtual ~MCMCBase() {}
-  void AddSampleHandler(SampleHandlerBase* sample) { samples.push_back(sample); }
+  /// non-owning; a sub-sample title may be registered once only (ref: Fitters/FitterBase.cpp:262-294)
+  void AddSampleHandler(SampleHandlerBase* sample) {
+    if (!sample) throw MaCh3Exception(__FILE__, __LINE__, "AddSampleHandler: null handler");
+    for (SampleHandlerBase* s : samples)
+      for (int i = 0; i < s->GetNsamples(); ++i)
+        for (int j = 0; j < sample->GetNsamples(); ++j)
+          if (s->GetSampleTitle(i) == sample->GetSampleTitle(j))
+            throw MaCh3Exception(__FILE__, __LINE__, "Duplicate sample title '" + sample->GetSampleTitle(j) + "' in handler " + sample->GetName() +
+                                                         ": same title exists in handler " + s->GetName());
+    samples.push_back(sample);
+  }
   void AddSystObj(ParameterHandlerBase* cov) { systematics.push_back(cov); }
 
   /// ref: MCMCBase.cpp:32-77

@@ -98,6 +98,22 @@ struct ToySample : public SampleHandlerBase {
 };
 }  // namespace
 
+// 1 when registering the same sub-sample title twice is refused (Fitters/FitterBase.cpp:262-279), else 0
+int facade_duplicate_title_refused() {
+  const std::vector<double> prefit = {0.0, 0.0, 0.0};
+  const std::vector<double> cov = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  ParameterHandlerBase ph("toy", prefit, cov, {-5, -5, -5}, {5, 5, 5}, {}, 1);
+  ToySample a(ph.RetPointer(0)), b(ph.RetPointer(0));
+  MR2T2 f(1);
+  f.AddSampleHandler(&a);
+  try {
+    f.AddSampleHandler(&b);
+  } catch (const MaCh3Exception& e) {
+    return std::string(e.what()).find("Duplicate sample title") != std::string::npos ? 1 : 0;
+  }
+  return 0;
+}
+
 int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out) {
   try {
     const std::vector<double> prefit = {0.0, 0.0, 0.0};

@@ -64,3 +64,8 @@ def test_adaption_repairs_a_poor_proposal(shim):
     # near the usual Metropolis range instead of ~1.
     r = run(shim, 2, 40000, 11)
     assert r["acc"] < 0.7
+
+
+def test_duplicate_sample_titles_are_refused(shim):
+    """FitterBase::AddSampleHandler throws when a sub-sample title is registered twice (FitterBase.cpp:262-279)"""
+    assert shim.facade_duplicate_title_refused() == 1
