@@ -31,7 +31,7 @@ class ParameterHandlerBase {
                        const std::vector<double>& up, const std::vector<bool>& flat_prior = {}, uint64_t seed = 0)
       : matrixName(std::move(name)), _fNumPar(int(prefit.size())), _fPreFitValue(prefit), _fCurrVal(prefit), _fPropVal(prefit), _fLowBound(low),
         _fUpBound(up), _fFlatPrior(flat_prior.empty() ? std::vector<bool>(prefit.size(), false) : flat_prior), _fIndivStepScale(prefit.size(), 1.0),
-        randParams(prefit.size(), 0.0), corr_throw(prefit.size(), 0.0), covMatrix(covariance), rng(seed ? seed : 0x5EEDull) {
+        fixed(prefit.size(), false), randParams(prefit.size(), 0.0), corr_throw(prefit.size(), 0.0), covMatrix(covariance), rng(seed ? seed : 0x5EEDull) {
     if (int(covariance.size()) != _fNumPar * _fNumPar || int(low.size()) != _fNumPar || int(up.size()) != _fNumPar)
       throw MaCh3Exception(__FILE__, __LINE__, "ParameterHandlerBase: inconsistent sizes");
     InvertCovMatrix = Invert(covMatrix, _fNumPar);
@@ -54,15 +54,83 @@ class ParameterHandlerBase {
   void SetIndivStepScale(int i, double s) { _fIndivStepScale[size_t(i)] = s; }
   bool GetDoAdaption() const { return use_adaptive; }
 
-  /// ref: ParameterHandlerBase.cpp:652-664, 690-707, 726-745
+  void SetSingleParameter(const int parNo, const double parVal) { SetParCurrProp(parNo, parVal); }  // ref: :629-636
+  /// flat prior: the parameter drops out of the penalty term (ref: :1063-1080)
+  void SetFlatPrior(const int i, const bool eL) {
+    if (i < 0 || i >= _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "SetFlatPrior: parameter index out of range");
+    _fFlatPrior[size_t(i)] = eL;
+  }
+  /// fixed parameters keep their value: no random throw, no correlated step (ref: :690-745, 960-1029; the reference
+  /// flags them through the sign of _fError)
+  bool IsParameterFixed(const int i) const { return fixed[size_t(i)]; }
+  void ToggleFixParameter(const int i) {
+    if (i < 0 || i >= _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "ToggleFixParameter: parameter index out of range");
+    fixed[size_t(i)] = !fixed[size_t(i)];
+  }
+  void SetFixParameter(const int i) { if (!IsParameterFixed(i)) ToggleFixParameter(i); }
+  void SetFreeParameter(const int i) { if (IsParameterFixed(i)) ToggleFixParameter(i); }
+  void SetFixAllParameters() { for (int i = 0; i < _fNumPar; ++i) SetFixParameter(i); }
+  void SetFreeAllParameters() { for (int i = 0; i < _fNumPar; ++i) SetFreeParameter(i); }
+  /// the two special proposals of EnableSpecialProposal (ref: :381-428; the YAML keys "CircularBounds" and
+  /// "FlipParameter" become two calls): wrap a cyclic parameter into [lo, up], mirror a parameter about a point
+  void EnableCircularBounds(const int index, const double LowBound, const double UpBound) {
+    if (index < 0 || index >= _fNumPar || !(LowBound < UpBound)) throw MaCh3Exception(__FILE__, __LINE__, "EnableCircularBounds: bad arguments");
+    // ref: :407-415 -- outside the physical bounds the chain never goes, so the circular range must lie inside them
+    if (LowBound < _fLowBound[size_t(index)] || UpBound > _fUpBound[size_t(index)])
+      throw MaCh3Exception(__FILE__, __LINE__, "EnableCircularBounds: the circular range exceeds the parameter's physical bounds");
+    doSpecialStepProposal = true;
+    CircularBoundsIndex.push_back(index);
+    CircularBoundsValues.emplace_back(LowBound, UpBound);
+  }
+  void EnableFlip(const int index, const double FlipPoint) {
+    if (index < 0 || index >= _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "EnableFlip: parameter index out of range");
+    doSpecialStepProposal = true;
+    FlipParameterIndex.push_back(index);
+    FlipParameterPoint.push_back(FlipPoint);
+  }
+  void CircularParBounds(const int index, const double LowBound, const double UpBound) {  // ref: :764-772
+    double& v = _fPropVal[size_t(index)];
+    if (v > UpBound) v = LowBound + std::fmod(v - UpBound, UpBound - LowBound);
+    else if (v < LowBound) v = UpBound - std::fmod(LowBound - v, UpBound - LowBound);
+  }
+  void FlipParameterValue(const int index, const double FlipPoint) {  // ref: :775-780
+    if (unif(rng) < 0.5) _fPropVal[size_t(index)] = 2 * FlipPoint - _fPropVal[size_t(index)];
+  }
+  void SpecialStepProposal() {  // ref: :667-684 "Step -> Circular Bounds -> Flip"
+    for (size_t i = 0; i < CircularBoundsIndex.size(); ++i)
+      if (!IsParameterFixed(CircularBoundsIndex[i])) CircularParBounds(CircularBoundsIndex[i], CircularBoundsValues[i].first, CircularBoundsValues[i].second);
+    for (size_t i = 0; i < FlipParameterIndex.size(); ++i)
+      if (!IsParameterFixed(FlipParameterIndex[i])) FlipParameterValue(FlipParameterIndex[i], FlipParameterPoint[i]);
+  }
+  /// start the chain somewhere else: every free parameter thrown within one prior sigma (or its range, if narrower)
+  /// of its prior value, inside its bounds (ref: :591-626)
+  void RandomConfiguration() {
+    for (int i = 0; i < _fNumPar; ++i) {
+      if (IsParameterFixed(i)) continue;
+      const double paramrange = _fUpBound[size_t(i)] - _fLowBound[size_t(i)];
+      const double sigma = std::sqrt(covMatrix[size_t(i) * _fNumPar + i]);
+      const double throwrange = paramrange < sigma ? paramrange : sigma;
+      int throws = 0;
+      do {
+        if (throws++ > 1000) throw MaCh3Exception(__FILE__, __LINE__, "RandomConfiguration: parameter " + std::to_string(i) + " cannot be thrown inside its bounds");
+        _fPropVal[size_t(i)] = _fPreFitValue[size_t(i)] + gaus(rng) * throwrange;
+      } while (_fPropVal[size_t(i)] > _fUpBound[size_t(i)] || _fPropVal[size_t(i)] < _fLowBound[size_t(i)]);
+      _fCurrVal[size_t(i)] = _fPropVal[size_t(i)];
+    }
+    SpecialStepProposal();
+  }
+
+  /// ref: ParameterHandlerBase.cpp:652-664 (ProposeStep), 690-707 (Randomize), 726-745 (CorrelateSteps)
   void ProposeStep() {
-    for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = gaus(rng);
+    for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
     for (int i = 0; i < _fNumPar; ++i) {  // corr_throw = L z, L lower triangular
       double s = 0.0;
       for (int j = 0; j <= i; ++j) s += throwMatrixCholDecomp[size_t(i) * _fNumPar + j] * randParams[size_t(j)];
       corr_throw[size_t(i)] = s;
     }
-    for (int i = 0; i < _fNumPar; ++i) _fPropVal[size_t(i)] = _fCurrVal[size_t(i)] + corr_throw[size_t(i)] * _fGlobalStepScale * _fIndivStepScale[size_t(i)];
+    for (int i = 0; i < _fNumPar; ++i)
+      if (!IsParameterFixed(i)) _fPropVal[size_t(i)] = _fCurrVal[size_t(i)] + corr_throw[size_t(i)] * _fGlobalStepScale * _fIndivStepScale[size_t(i)];
+    if (doSpecialStepProposal) SpecialStepProposal();
   }
   void AcceptStep() { _fCurrVal = _fPropVal; }  // ref: :748-761
 
@@ -186,10 +254,16 @@ class ParameterHandlerBase {
   std::vector<double> _fPreFitValue, _fCurrVal, _fPropVal, _fLowBound, _fUpBound;
   std::vector<bool> _fFlatPrior;
   std::vector<double> _fIndivStepScale;
+  std::vector<bool> fixed;
+  bool doSpecialStepProposal = false;
+  std::vector<int> CircularBoundsIndex, FlipParameterIndex;
+  std::vector<std::pair<double, double>> CircularBoundsValues;
+  std::vector<double> FlipParameterPoint;
   double _fGlobalStepScale = 1.0;
   std::vector<double> randParams, corr_throw, covMatrix, InvertCovMatrix, throwMatrixCholDecomp;
   std::mt19937_64 rng;
   std::normal_distribution<double> gaus{0.0, 1.0};
+  std::uniform_real_distribution<double> unif{0.0, 1.0};
   // adaption
   bool use_adaptive = false;
   int start_adaptive_update = 0, end_adaptive_update = 0, start_adaptive_throw = 0, adaptive_update_step = 1, total_steps = 0;

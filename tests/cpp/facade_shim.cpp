@@ -98,6 +98,83 @@ struct ToySample : public SampleHandlerBase {
 };
 }  // namespace
 
+// ParameterHandlerBase step-path semantics that need no sample: returns 0, or the number of the failing check
+int facade_parameter_handler_checks(unsigned long long seed) {
+  try {
+    const double pi = 3.14159265358979323846;
+    const std::vector<double> prefit = {0.0, 1.0, 0.5};
+    const std::vector<double> cov = {1.0, 0.3, 0.0, 0.3, 1.0, 0.0, 0.0, 0.0, 4.0};
+    ParameterHandlerBase ph("toy", prefit, cov, {-10, -10, -pi}, {10, 10, pi}, {}, seed);
+    // 1: a fixed parameter never moves, the others do, and it contributes no random number to their step
+    ph.SetFixParameter(1);
+    if (!ph.IsParameterFixed(1) || ph.IsParameterFixed(0)) return 1;
+    for (int s = 0; s < 200; ++s) {
+      ph.ProposeStep();
+      if (ph.GetParProp(1) != 1.0) return 1;
+      ph.AcceptStep();
+    }
+    if (ph.GetParCurr(0) == 0.0 || ph.GetParCurr(2) == 0.5) return 1;
+    ph.SetFreeParameter(1);
+    ph.ProposeStep();
+    if (ph.GetParProp(1) == 1.0) return 1;
+    // 2: circular bounds keep a cyclic parameter inside [-pi, pi] whatever the step (ref: CircularParBounds)
+    ph.EnableCircularBounds(2, -pi, pi);
+    ph.SetStepScale(3.0);
+    for (int s = 0; s < 2000; ++s) {
+      ph.ProposeStep();
+      if (ph.GetParProp(2) > pi || ph.GetParProp(2) < -pi) return 2;
+      ph.AcceptStep();
+    }
+    ph.SetParCurrProp(2, 3.0);
+    // the wrap itself: 3.0 + 0.5 -> -pi + (3.5 - pi)
+    {
+      ParameterHandlerBase q("q", {3.5}, {1.0}, {-pi}, {pi}, {}, 1);
+      q.CircularParBounds(0, -pi, pi);
+      if (std::fabs(q.GetParProp(0) - (-pi + (3.5 - pi))) > 1e-15) return 2;
+      q.SetParCurrProp(0, -4.0);
+      q.CircularParBounds(0, -pi, pi);
+      if (std::fabs(q.GetParProp(0) - (pi - (4.0 - pi))) > 1e-15) return 2;
+    }
+    // 3: circular range outside the physical bounds is refused
+    try {
+      ph.EnableCircularBounds(0, -20, 20);
+      return 3;
+    } catch (const MaCh3Exception&) {
+    }
+    // 4: the flip mirrors about the point in about half of the proposals (ref: FlipParameterValue)
+    {
+      ParameterHandlerBase f("f", {2.0}, {1e-12}, {-10}, {10}, {}, seed + 5);
+      f.EnableFlip(0, 0.0);
+      int flipped = 0;
+      for (int s = 0; s < 4000; ++s) {
+        f.SetParCurrProp(0, 2.0);
+        f.ProposeStep();
+        flipped += f.GetParProp(0) < 0;
+      }
+      if (flipped < 1800 || flipped > 2200) return 4;
+    }
+    // 5: flat prior drops the parameter from the penalty; out of bounds -> _LARGE_LOGL_ per parameter
+    ph.SetParCurrProp(0, 1.0); ph.SetParCurrProp(1, 1.0); ph.SetParCurrProp(2, 0.5);
+    const double with0 = ph.CalcLikelihood();   // d = (1,0,0): 0.5 * Vinv00 = 0.5 / (1 - 0.09)
+    if (std::fabs(with0 - 0.5 / 0.91) > 1e-12) return 5;
+    ph.SetFlatPrior(0, true);
+    if (ph.CalcLikelihood() != 0.0) return 5;
+    ph.SetParCurrProp(1, 11.0);
+    if (ph.GetLikelihood() != M3::_LARGE_LOGL_) return 5;
+    // 6: RandomConfiguration stays inside the bounds and leaves fixed parameters alone
+    ph.SetParCurrProp(1, 1.0);
+    ph.SetFixParameter(0);
+    const double before = ph.GetParCurr(0);
+    for (int s = 0; s < 100; ++s) {
+      ph.RandomConfiguration();
+      if (ph.GetParCurr(0) != before || ph.CheckBounds() != 0 || ph.GetParCurr(1) != ph.GetParProp(1)) return 6;
+    }
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 // 1 when registering the same sub-sample title twice is refused (Fitters/FitterBase.cpp:262-279), else 0
 int facade_duplicate_title_refused() {
   const std::vector<double> prefit = {0.0, 0.0, 0.0};

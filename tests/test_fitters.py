@@ -69,3 +69,11 @@ def test_adaption_repairs_a_poor_proposal(shim):
 def test_duplicate_sample_titles_are_refused(shim):
     """FitterBase::AddSampleHandler throws when a sub-sample title is registered twice (FitterBase.cpp:262-279)"""
     assert shim.facade_duplicate_title_refused() == 1
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_parameter_handler_step_semantics(shim, seed):
+    """fixed parameters, circular bounds, flips, flat priors, bounds, random start
+    (ref: Parameters/ParameterHandlerBase.cpp:591-626, 652-780, 816-867, 960-1080)"""
+    shim.facade_parameter_handler_checks.argtypes = [C.c_ulonglong]
+    assert shim.facade_parameter_handler_checks(seed) == 0
