@@ -286,6 +286,9 @@ class MCMCBase {
                                                          ": same title exists in handler " + s->GetName());
     samples.push_back(sample);
   }
+  /// simulated annealing: the likelihood difference is divided by exp(-step / T); T < 0 switches it off
+  /// (ref: Fitters/MCMCBase.cpp:19-26, the "AnnealTemp" setting)
+  void SetAnnealTemp(const double T) { AnnealTemp = T; anneal = !(T < 0); }
   void AddSystObj(ParameterHandlerBase* cov) { systematics.push_back(cov); }
 
   /// ref: MCMCBase.cpp:32-77
@@ -376,6 +379,8 @@ class MCMCBase {
   double logLCurr = 0.0, logLProp = 0.0;
   bool out_of_bounds = false, started = false;
   int step = 0, accCount = 0, oobCount = 0;
+  bool anneal = false;
+  double AnnealTemp = -999;
   std::mt19937_64 random;
   std::uniform_real_distribution<double> unif{0.0, 1.0};
   std::vector<double> StepStore, LogLStore, stepTime;
@@ -396,7 +401,10 @@ class MR2T2 : public MCMCBase {
     for (auto* s : systematics) s->ProposeStep();
     EvaluateProposal();
   }
-  double AcceptanceProbability() const { return std::min(1., std::exp(logLCurr - logLProp)); }  // :103-115 (no annealing)
+  double AcceptanceProbability() const {  // :103-115
+    if (anneal) return std::min(1., std::exp(-(logLProp - logLCurr) / (std::exp(-step / AnnealTemp))));
+    return std::min(1., std::exp(logLCurr - logLProp));
+  }
   double accProb = 0.0;
 };
 

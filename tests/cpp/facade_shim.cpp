@@ -200,6 +200,7 @@ int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out
     MR2T2 plain(seed);
     DelayedMR2T2 delayed(seed, 1.0, 0.3, 2, 0.1);
     MCMCBase* f = kind == 1 ? static_cast<MCMCBase*>(&delayed) : static_cast<MCMCBase*>(&plain);
+    if (kind == 3) plain.SetAnnealTemp(double(n_steps) / 8);  // hot at the start, cooling as the chain goes on
     if (kind == 2) {
       ph.SetThrowMatrix({0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.01});  // a poor starting proposal that adaption has to fix
       ph.InitialiseAdaption(200, n_steps, 2000, 500);

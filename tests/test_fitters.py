@@ -77,3 +77,14 @@ def test_parameter_handler_step_semantics(shim, seed):
     (ref: Parameters/ParameterHandlerBase.cpp:591-626, 652-780, 816-867, 960-1080)"""
     shim.facade_parameter_handler_checks.argtypes = [C.c_ulonglong]
     assert shim.facade_parameter_handler_checks(seed) == 0
+
+
+def test_annealing_follows_the_reference_formula(shim):
+    """MR2T2::AcceptanceProbability with AnnealTemp (Fitters/MR2T2.cpp:109-110): the likelihood difference is divided
+    by exp(-step / T), which goes from 1 towards 0 -- uphill moves die out and the chain settles at the minimum, so its
+    late spread is far below the posterior's and the acceptance rate falls below the plain chain's"""
+    plain, ann = np.zeros(16), np.zeros(16)
+    assert shim.facade_toy_chain(0, 40000, 11, plain.ctypes.data) == 0
+    assert shim.facade_toy_chain(3, 40000, 11, ann.ctypes.data) == 0
+    assert ann[0] < 0.6 * plain[0]                 # acceptance
+    assert (ann[6:9] < 0.5 * plain[6:9]).all()     # variances of the kept part of the chain
