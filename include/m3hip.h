@@ -7,7 +7,8 @@
  * names (SMonolithGPU, SMonolith, SampleHandlerFD) on top of exactly these calls.
  *
  * Conventions
- *   - every function returns 0 on success, a negative M3HIP_E* code otherwise;
+ *   - every function returns 0 on success, a negative M3HIP_E* code otherwise; no C++ exception leaves the
+ *     library (host allocation failures come back as M3HIP_ENOMEM);
  *     m3hip_last_error() gives the message (the reference logs + throws
  *     MaCh3Exception, Manager/MaCh3Exception.h:29-38; the facade rethrows).
  *   - host arrays are copied during the call; the caller keeps ownership.
@@ -260,7 +261,12 @@ int m3hip_set_data(m3hip_handle h, const double* data, int n_bins);
 int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2);
 
 /* SampleHandlerFD::Reweight() (SampleHandlerFD.cpp:316-343) for parameter vector
- * params[n_par] (the proposed values, ParameterHandlerBase.h:205).  Asynchronous. */
+ * params[n_par] (the proposed values, ParameterHandlerBase.h:205).  Asynchronous.
+ * Before anything is launched the indices the kernels use unguarded are checked against what they point into:
+ * the spline parameter map and the events' norm indices against n_par, the events' oscillation indices against
+ * the uploaded table, kinematic shift / cut columns against kin_stride (M3HIP_EINVAL, nothing runs).
+ * Non-finite weights behave as in the reference: `w <= 0` drops the event, so a NaN weight is filled and turns
+ * its bin and the likelihood NaN. */
 int m3hip_reweight(m3hip_handle h, const double* params, int n_par);
 /* SampleHandlerFD::GetLikelihood() (+ GetSampleLikelihood(i) into per_sample[n_samples],
  * may be NULL).  Runs the bin-LLH kernel, copies the result back and synchronises. */
