@@ -582,13 +582,13 @@ def _eval_matches(engine, P, K, cx, npts, ch, rng, laps=3):
     return info
 
 
-@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick", "padded", "mode_blocks"])
+@pytest.mark.parametrize("case", ["one_event", "holes", "deep_brick", "padded", "mode_blocks", "many_params"])
 def test_extreme_shapes(fresh_engine, case, monkeypatch):
     """Edges of the layout: a single event; ragged groups in which a third of the events carry no response
     at all (weight stays 1, SplineMonolith.cpp:798) and some carry TF1s only; a brick with ~190k responses
     in its 1024 events (24+ stages, close to the 30-stage limit); the same 80 %-occupied group laid out as
-    identity-padded uniform tiles (the default for groups that are at least 70 % full)."""
-    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3, "mode_blocks": 4}[case])
+    identity-padded uniform tiles (the default for groups that are at least 70 % full); 2 600 parameters."""
+    rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3, "mode_blocks": 4, "many_params": 5}[case])
     X7, X5, X3 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2]), np.array([-1.0, 0, 1])
     if case == "one_event":
         xs = {0: X7}
@@ -605,6 +605,16 @@ def test_extreme_shapes(fresh_engine, case, monkeypatch):
         cx, npts, ch = make_monolith(P, 7, {p: X7 for p in range(P)}, events)
         info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng)
         assert info.n_tiles_uniform == 7 and info.n_tiles_brick == 3
+    elif case == "many_params":
+        # more parameters than the kernels keep in LDS (1 024) and more runs than one brick stage holds (1 024): the
+        # per-step tables are then read from global memory and the stages are cut by run count
+        P = 2600
+        xs = {p: (X3, X5)[p % 2] for p in range(P) if p % 5 != 4}   # four fifths TSpline3, one fifth TF1
+        events = _ragged_events(rng, 1400, P, 0.012, xs, empty_frac=0.02)
+        cx, npts, ch = make_monolith(P, 7, xs, events)
+        info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng)
+        assert info.n_tiles_brick == 2 and info.n_tiles_uniform == 0
+        assert len(np.unique(ch["param_no"][: int(ch["npe"].reshape(-1, 2)[:1024, 0].sum())])) > 1024   # > 1 024 runs in the first brick
     elif case == "holes":
         P = 40
         xs = {p: (X7, X5, X3)[p % 3] for p in range(0, P, 2)}   # even parameters are TSpline3, odd are TF1

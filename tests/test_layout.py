@@ -199,6 +199,34 @@ def test_ragged_brick_layout(n_events, cfg):
     check_bricks(npts, ch, lay)
 
 
+def test_more_runs_than_a_stage_holds():
+    """2 600 parameters in 1 400 sparse events: a brick sees more than 1 024 distinct spline parameters, so its
+    TSpline3 stages are cut by run count (the resolved run table of a stage lives in LDS), not by responses."""
+    rng = np.random.default_rng(5)
+    X3, X5 = np.array([-1.0, 0, 1]), np.array([-2.0, -1, 0, 1, 2])
+    P = 2600
+    xs = {p: (X3, X5)[p % 2] for p in range(P) if p % 5 != 4}
+    events = []
+    for _ in range(1400):
+        ev = []
+        for p in range(P):
+            if rng.random() < 0.012:
+                ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))) if p in xs
+                          else (p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
+        events.append(ev)
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    rc, err, lay = debug_layout(P, 7, npts, ch)
+    assert rc == 0, err
+    assert lay["n_bricks"] == 2 and lay["n_tiles"] == 0
+    w = lay["words"]
+    w0 = int(lay["bdesc"][0][2])
+    stages = [w[w0 + 1 + 8 * s: w0 + 9 + 8 * s] for s in range(int(w[w0]))]
+    spl_stages = [h for h in stages if int(h[0]) == 0]
+    assert len(spl_stages) >= 2 and all(int(h[2]) <= 1024 for h in spl_stages) and sum(int(h[2]) for h in spl_stages) > 1024
+    assert all(int(h[1]) < 8192 for h in spl_stages)        # none of them is full: the run count made the cut
+    check_bricks(npts, ch, lay)
+
+
 def test_mixed_uniform_and_ragged_groups():
     """A chunk whose first 1024 events are dense and whose tail is ragged: uniform tiles and a
     brick side by side, stages split at the 8192-response cap."""
