@@ -640,6 +640,25 @@ def test_extreme_shapes(fresh_engine, case, monkeypatch):
             assert 0.15 < info.pad_responses / (info.pad_responses + n_resp) < 0.25
 
 
+def test_many_distinct_uniform_lists(fresh_engine):
+    """90 uniform tiles, each with its own list of 104 parameters: 9 360 distinct slots, more than k_prep resolves
+    inline (8 192), so the per-step slot resolution runs as its own kernel (k_resolve)."""
+    rng = np.random.default_rng(77)
+    X7 = np.arange(-3.0, 4.0)
+    P, T, L = 200, 90, 100
+    xs = {p: X7 for p in range(0, P, 50)}             # parameters 0, 50, 100, 150 are TSpline3, the rest TF1
+    quads = [natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7)) for _ in range(64)]
+    events = []
+    for t in range(T):
+        plist = sorted(set(range(t, t + L)) | set(xs))
+        for _ in range(256):
+            events.append([(p, "spl", quads[int(rng.integers(0, 64))]) if p in xs else (p, "tf1", (0.02 * rng.standard_normal(), 1.0))
+                           for p in plist])
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng, laps=4)
+    assert info.n_tiles_uniform == T and info.n_tiles_brick == 0 and info.n_tiles_padded == 0
+
+
 @pytest.mark.parametrize("grouping", ["on", "off"])
 def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkeypatch):
     """Events of three interaction modes (each with its own parameter list, a tenth of the splines flat and dropped)
