@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <limits>
 #include <memory>
 #include <string>
@@ -220,7 +221,8 @@ class SampleHandlerFD : public SampleHandlerBase {
   /// the oscillation-weight table (-1: no oscillation weight, e.g. NC; ref:
   /// Samples/SampleHandlerFD.cpp:637-663, 1108-1133).
   void AddEvent(unsigned int iEvent, int Sample, const std::vector<double>& KinVars, const std::vector<int16_t>& NormParams, int OscIndex) {
-    if (iEvent != n_added) throw MaCh3Exception(__FILE__, __LINE__, "events must be added in order");
+    if (iEvent != n_added || iEvent >= nEvents) throw MaCh3Exception(__FILE__, __LINE__, "events must be added in order, one per event of the spline handler");
+    if (Sample < 0 || Sample >= Binning->GetNSamples()) throw MaCh3Exception(__FILE__, __LINE__, "AddEvent: sample index out of range");
     // the first GetNDim(Sample) entries are the binning axes; further entries are cut-only columns (AddSelection)
     const size_t nd = size_t(Binning->GetNDim(Sample));
     if (KinVars.size() < nd) throw MaCh3Exception(__FILE__, __LINE__, "fewer kinematic variables than binning axes");
