@@ -56,3 +56,11 @@ build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/
 	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 .PHONY: examples
+
+# calibration programs behind the ceilings quoted in DESIGN.md / profiles/README.md (run on an MI355X)
+TOOLS = build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/fetch_size_widths
+tools: $(TOOLS)
+build/%: tools/%.hip
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+.PHONY: tools
