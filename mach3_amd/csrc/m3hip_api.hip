@@ -190,7 +190,9 @@ struct m3hip_ctx {
   int32_t* d_sample_off = nullptr;
   double* d_data = nullptr;
   double* d_hist = nullptr;  // [2][hist_rep][n_bins]
-  int hist_rep = 32;
+  double* d_llh_partial = nullptr;  // split form of k_llh (many bins): [groups][n_samples]
+  int hist_rep = 32;      // flush replicas of the bin vector in use (chosen at set_binning)
+  int hist_rep_cfg = 32;  // ... as configured
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
   bool w2_spread = false;  // w2 currently lives spread over the flush replicas (not yet folded into replica 0)
@@ -490,6 +492,7 @@ int m3hip_destroy(m3hip_handle h) try {
   dev_free(h->d_sample_off);
   dev_free(h->d_data);
   dev_free(h->d_hist);
+  dev_free(h->d_llh_partial);
   dev_free(h->d_dbg_clock);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -870,12 +873,23 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   if (nb <= 0) return fail(h, M3HIP_EINVAL, "set_binning: no bins");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist);
+  dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist); dev_free(h->d_llh_partial);
+  h->d_sample_off = nullptr; h->d_data = nullptr; h->d_hist = nullptr; h->d_llh_partial = nullptr;
+  // The replicas exist to spread the once-per-workgroup flushes of LDS-privatised bin vectors (thousands of
+  // workgroups, a few hundred addresses).  A bin vector too large for LDS is filled event by event instead, the
+  // adds spread over thousands of addresses by themselves, and every replica would only cost the per-step reset
+  // and the fold in k_llh (both one workgroup, linear in replicas x bins: 118 us of a 132 us step at 7 200 bins
+  // with 32 replicas).
+  h->hist_rep = sizeof(double) * size_t(nb) <= size_t(M3_HIST_LDS_MAX_BYTES) ? h->hist_rep_cfg : std::max(1, std::min(h->hist_rep_cfg, 8192 / nb));
   if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
   int rc;
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
   if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2 * h->hist_rep))) return rc;
+  if (nb > M3_LLH_SPLIT_BINS) {
+    const size_t groups = (size_t(nb) + M3_LLH_SPLIT_LANES - 1) / M3_LLH_SPLIT_LANES;
+    if ((rc = dev_alloc(h, &h->d_llh_partial, groups * size_t(n_samples)))) return rc;
+  }
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
   HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
@@ -1666,6 +1680,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   // W2 that was frozen by the last reweight is folded in place once; while UpdateW2 keeps accumulating it is summed on the fly
   l.w2_mode = !h->w2_spread ? kW2Replica0 : (h->update_w2 ? kW2Fold : kW2FoldInPlace);
   l.out = h->d_out;
+  l.partial = h->d_llh_partial;
   // completion is signalled through host memory: k_llh writes the results, then this ticket
   volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(h->h_out + 1 + h->n_samples);
   l.done_flag = reinterpret_cast<volatile uint64_t*>(h->d_out + 1 + h->n_samples);
@@ -1837,7 +1852,7 @@ int m3hip_debug_set_knobs(m3hip_handle h, int unroll, int nt, int lds_pad) try {
 int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) try {
   if (!h || n < 1 || n > 64) return M3HIP_EINVAL;
   if (h->n_bins != 0) return fail(h, M3HIP_ESTATE, "set_hist_replicas must precede set_binning");
-  h->hist_rep = n;
+  h->hist_rep = h->hist_rep_cfg = n;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

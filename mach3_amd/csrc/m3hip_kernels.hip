@@ -934,13 +934,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-__device__ double block_sum_256(double v, double* scratch /*[4]*/) {
+// sum over the workgroup (NT = 256 or 1024 lanes), fixed order: wave sums, then a pairwise tree over the waves
+template <int NT>
+__device__ double block_sum(double v, double* scratch /*[NT / 64]*/) {
   v = wave_sum(v);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) scratch[wave] = v;
   __syncthreads();
-  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  double t[NT / 64];
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) t[i] = scratch[i];
+#pragma unroll
+  for (int n = NT / 64; n > 1; n >>= 1)
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
+  return t[0];
 }
 
 // fold the flush replicas into replica 0 (same fixed order as k_llh), so that the multi-GPU
@@ -978,8 +987,11 @@ __device__ __forceinline__ double fold_replicas(const double* base, int hist_rep
   return m;
 }
 
-__global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
-  __shared__ double scratch[4];
+// NT lanes: 256 for the usual few hundred bins, 1024 when a 2-D sample brings thousands (every pass over the bins is a
+// chain of dependent loads, so fewer passes is what counts)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_llh(LlhArgs a) {
+  __shared__ double scratch[NT / 64];
   const double* mc = a.hist;
   double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
   // GetLikelihood() = sum over samples of GetSampleLikelihood(s) = sum over the sample's bins of
@@ -989,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
   for (int s = 0; s < a.n_samples; ++s) {
     const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
     double sacc = 0.0;
-    for (int i = b0 + threadIdx.x; i < b1; i += 256) {
+    for (int i = b0 + threadIdx.x; i < b1; i += NT) {
       const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
       double v;
       if (a.w2_mode == kW2Replica0) {
@@ -1003,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_llh(LlhArgs a) {
       }
       sacc += d_test_stat_llh(a.kind, a.data[i], m, v);
     }
-    const double st = block_sum_256(sacc, scratch);
+    const double st = block_sum<NT>(sacc, scratch);
     if (threadIdx.x == 0) a.out[1 + s] = st;
     total += st;
   }
@@ -1030,6 +1042,75 @@ void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t
   else hipLaunchKernelGGL(k_osc_narrow, dim3(g), dim3(256), 0, s, f64, reinterpret_cast<float*>(dst), n);
 }
 
-void launch_llh(const LlhArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_llh, dim3(1), dim3(256), 0, s, a); }
+// Split form for thousands of bins (2-D samples): workgroup g evaluates bins [g * 1024, (g + 1) * 1024) -- one bin per
+// lane, one round of loads instead of a pass per 1024 bins -- and leaves the sums of its bins per sample;
+// k_llh_final adds them per sample in workgroup order (fixed, so the result is reproducible), then the samples.
+__global__ __launch_bounds__(M3_LLH_SPLIT_LANES) void k_llh_partial(LlhArgs a) {
+  constexpr int NT = M3_LLH_SPLIT_LANES;
+  __shared__ double scratch[NT / 64];
+  const double* mc = a.hist;
+  double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
+  const int lo = (int)blockIdx.x * NT, hi = lo + NT < a.n_bins ? lo + NT : a.n_bins;
+  const int i = lo + (int)threadIdx.x;
+  double term = 0.0;
+  if (i < hi) {
+    const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
+    double v;
+    if (a.w2_mode == kW2Replica0) {
+      v = w2[i];
+    } else {
+      v = fold_replicas(w2 + i, a.hist_rep, a.n_bins);
+      if (a.w2_mode == kW2FoldInPlace) {
+        w2[i] = v;
+        for (int r = 1; r < a.hist_rep; ++r) w2[(size_t)r * a.n_bins + i] = 0.0;
+      }
+    }
+    term = d_test_stat_llh(a.kind, a.data[i], m, v);
+  }
+  for (int s = 0; s < a.n_samples; ++s) {
+    const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
+    double st = 0.0;
+    if (b1 > lo && b0 < hi) st = block_sum<NT>((i >= b0 && i < b1 && i < hi) ? term : 0.0, scratch);  // workgroup-uniform test
+    if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * a.n_samples + s] = st;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_llh_final(LlhArgs a, int n_groups) {
+  __shared__ double per_sample[256];
+  double total = 0.0;
+  for (int s0 = 0; s0 < a.n_samples; s0 += 256) {  // (more than 256 samples: in rounds)
+    const int s = s0 + (int)threadIdx.x;
+    double st = 0.0;
+    if (s < a.n_samples) {
+      for (int g = 0; g < n_groups; ++g) st += a.partial[(size_t)g * a.n_samples + s];
+      a.out[1 + s] = st;
+    }
+    per_sample[threadIdx.x] = st;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 256 && s0 + k < a.n_samples; ++k) total += per_sample[k];  // sample order, as GetLikelihood sums them
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.out[0] = total;
+    if (a.dbg_clock) a.dbg_clock[1] = wall_clock64();
+    if (a.done_flag) {
+      __threadfence_system();
+      *a.done_flag = a.ticket;
+    }
+  }
+}
+
+void launch_llh(const LlhArgs& a, hipStream_t s) {
+  if (a.n_bins > M3_LLH_SPLIT_BINS && a.partial) {
+    const int n_groups = (a.n_bins + M3_LLH_SPLIT_LANES - 1) / M3_LLH_SPLIT_LANES;
+    hipLaunchKernelGGL(k_llh_partial, dim3(n_groups), dim3(M3_LLH_SPLIT_LANES), 0, s, a);
+    hipLaunchKernelGGL(k_llh_final, dim3(1), dim3(256), 0, s, a, n_groups);
+  } else if (a.n_bins > 1024) {
+    hipLaunchKernelGGL(k_llh<1024>, dim3(1), dim3(1024), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_llh<256>, dim3(1), dim3(256), 0, s, a);
+  }
+}
 
 }  // namespace m3hip

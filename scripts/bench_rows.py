@@ -17,6 +17,34 @@ def timeit(fn, n=200, spin=0.7):
 
 rng=np.random.default_rng(5)
 only = sys.argv[1] if len(sys.argv) > 1 else "all"
+# ---- many bins: 2-D samples whose bin vector is too large for LDS (direct global atomics, k_llh over thousands of bins)
+def bins_row(E, nx, ny, n_samples):
+    spec = synth.CONFIGS["c1"].scaled(E)
+    eng, mono, sh0, par = build_from_synth(spec)
+    ev = synth.events_chunk(spec, 0, E)
+    ex, ey = np.linspace(0.0, 5.0, nx + 1), np.linspace(-1.0, 1.0, ny + 1)
+    sid = rng.integers(0, n_samples, E).astype(np.int32)
+    kin = np.stack([ev["erec"], rng.uniform(-1.0, 1.0, E)], axis=1)
+    sh = SampleHandlerFD(eng, n_samples, None, par, capi.kBarlowBeeston, bin_edges=[[ex, ey]] * n_samples)
+    sh.SetupKinematics(0, sid, kin); sh.ComputeBins()
+    sh.SetupEvents(0, sh.GetEventBins(0, E), ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+    sh.SetOscillationWeights(synth.osc_table(spec))
+    sh.Reweight(); sh.AddData(sh.GetMCArray())
+    def step():
+        par[:] = synth.params(spec, int(rng.integers(1, 60))); return sh.Step()
+    t = timeit(step)
+    eng.lib.m3hip_debug_device_span(eng.h, 1, None)
+    import ctypes as C
+    dev = []
+    for _ in range(100):
+        step(); d = (C.c_double * 5)(); eng.lib.m3hip_debug_device_span(eng.h, 0, C.cast(d, C.POINTER(C.c_double))); dev.append(d[0])
+    print(f"many bins: E={E}, {n_samples} x {nx} x {ny} = {n_samples*nx*ny} bins: step {t:.1f} us (device span k_prep start -> k_llh end {np.median(dev):.1f} us)", flush=True)
+    eng.close()
+if only == "bins":
+    bins_row(100000, 20, 10, 1)
+    bins_row(100000, 60, 40, 3)
+    bins_row(100000, 100, 80, 4)
+    sys.exit(0)
 # ---- binned splines: 1e6 events, 50 unique parameters, 1e6 bin-splines, ~30 weights per event; both M3::float_t builds
 def binned_row(float_t, sort_by_cell=False):
     P, cells, E = 50, 20000, 1_000_000

@@ -490,25 +490,29 @@ def test_oscillation_weights_change_every_step(fresh_engine):
     omono.close()
 
 
-@pytest.mark.parametrize("cfg,n_params", [("c2", 24), ("c3", 96)])
-def test_thousands_of_bins(fresh_engine, cfg, n_params):
-    """Bin vectors too large to privatise in LDS (2-D samples: here 3 x 60 x 40 = 7200 global bins): the fill goes
-    straight into the workgroup's global replica; uniform tiles (c2 shape) and bricks (c3 shape), device-side
-    2-D binning, Barlow-Beeston with W2 accumulated on the first step only."""
+@pytest.mark.parametrize("cfg,n_params,shape", [("c2", 24, (3, 60, 40)), ("c3", 96, (3, 60, 40)), ("c2", 24, (4, 100, 80)), ("c2", 24, (2, 50, 30))])
+def test_thousands_of_bins(fresh_engine, cfg, n_params, shape):
+    """Bin vectors too large to privatise in LDS (2-D samples: 3 x 60 x 40 = 7 200 and 4 x 100 x 80 = 32 000 global
+    bins; 2 x 50 x 30 = 3 000 for the sizes in between): the fill goes straight into the workgroup's global replica
+    (few replicas: the adds spread over the bins by themselves), the bin likelihood runs as one workgroup per 1 024
+    bins + a final sum beyond 4 096 bins (sample boundaries fall inside workgroups) and as one 1 024-lane workgroup
+    below; uniform tiles (c2 shape) and bricks (c3 shape), device-side 2-D binning, Barlow-Beeston with W2
+    accumulated on the first step only."""
     E = 9000
+    n_samp, nx, ny = shape
     spec = synth.CONFIGS[cfg].scaled(E, n_params=n_params)
     cx, npts = synth.knots(spec)
     ch = synth.monolith_chunk(spec, 0, E)
     ev = synth.events_chunk(spec, 0, E)
     rng = np.random.default_rng(12)
-    ex, ey = np.linspace(0.0, 5.0, 61), np.linspace(-1.0, 1.0, 41)
-    sample_id = rng.integers(0, 3, E).astype(np.int32)
+    ex, ey = np.linspace(0.0, 5.0, nx + 1), np.linspace(-1.0, 1.0, ny + 1)
+    sample_id = rng.integers(0, n_samp, E).astype(np.int32)
     kin = np.stack([ev["erec"], rng.uniform(-1.05, 1.05, E)], axis=1)
     lib = ob.load("serial")
     b = ob.OracleBinning(lib)
-    for _ in range(3):
+    for _ in range(n_samp):
         b.add_uniform([ex, ey])
-    assert b.n_bins() == 7200
+    assert b.n_bins() == n_samp * nx * ny
     par = synth.params(spec, 0)
     opar = par.copy()
     omono = ob.OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
@@ -520,7 +524,7 @@ def test_thousands_of_bins(fresh_engine, cfg, n_params):
     mono.setSplinePointers(par)
     info = fresh_engine.info()
     assert (info.n_tiles_brick > 0) == (cfg == "c3")
-    sh = SampleHandlerFD(fresh_engine, 3, None, par, capi.kBarlowBeeston, bin_edges=[[ex, ey]] * 3)
+    sh = SampleHandlerFD(fresh_engine, n_samp, None, par, capi.kBarlowBeeston, bin_edges=[[ex, ey]] * n_samp)
     sh.SetupKinematics(0, sample_id, kin)
     sh.ComputeBins()
     bins = sh.GetEventBins(0, E)
@@ -541,8 +545,10 @@ def test_thousands_of_bins(fresh_engine, cfg, n_params):
         assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
         assert np.allclose(sh.GetW2Array(), osamp.w2, rtol=RTOL_BIN, atol=0)
         _llh_close(llh, osamp.get_likelihood())
-        per = [sh.GetSampleLikelihood(i) for i in range(3)]
+        per = [sh.GetSampleLikelihood(i) for i in range(n_samp)]
         assert np.isclose(sum(per), llh, rtol=1e-12)
+        for i in range(n_samp):
+            _llh_close(per[i], osamp.get_sample_likelihood(i), scale=max(1.0, abs(llh)))
     osamp.close()
     omono.close()
 
