@@ -192,7 +192,8 @@ struct m3hip_ctx {
   double* d_hist = nullptr;  // [2][hist_rep][n_bins]
   double* d_llh_partial = nullptr;  // split form of k_llh (many bins): [groups][n_samples]
   int hist_rep = 32;      // flush replicas of the bin vector in use (chosen at set_binning)
-  int hist_rep_cfg = 32;  // ... as configured
+  int hist_rep_cfg = 32;  // ... upper limit
+  bool hist_rep_forced = false;  // m3hip_debug_set_hist_replicas: use exactly that many
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
   bool w2_spread = false;  // w2 currently lives spread over the flush replicas (not yet folded into replica 0)
@@ -875,13 +876,11 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   HIPCHK(h, hipStreamSynchronize(h->stream));
   dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist); dev_free(h->d_llh_partial);
   h->d_sample_off = nullptr; h->d_data = nullptr; h->d_hist = nullptr; h->d_llh_partial = nullptr;
-  // The replicas exist to spread the once-per-workgroup flushes of LDS-privatised bin vectors (thousands of
-  // workgroups, a few hundred addresses).  A bin vector too large for LDS is filled event by event instead, the
-  // adds spread over thousands of addresses by themselves, and every replica would only cost the per-step reset
-  // and the fold in k_llh (both one workgroup, linear in replicas x bins: 118 us of a 132 us step at 7 200 bins
-  // with 32 replicas).
-  h->hist_rep = sizeof(double) * size_t(nb) <= size_t(M3_HIST_LDS_MAX_BYTES) ? h->hist_rep_cfg : std::max(1, std::min(h->hist_rep_cfg, 8192 / nb));
-  if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
+  // The replicas spread the adds of thousands of workgroups over more addresses than one bin vector has: 32
+  // copies at 200 bins = 6 400 addresses measured as fast as no contention at all.  More bins spread the adds by
+  // themselves, while the per-step reset (k_prep) and the fold (k_llh) are linear in replicas x bins (118 us of a
+  // 132 us step at 7 200 bins with 32 replicas): keep the number of addresses, not the number of replicas.
+  if (!h->hist_rep_forced) h->hist_rep = std::max(1, std::min(h->hist_rep_cfg, 6400 / nb));
   int rc;
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
@@ -1648,7 +1647,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
     // fold the 32 flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins), and w2
     // only travels while it is still being accumulated
-    launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, h->first_w2 ? 1 : 0, h->stream);
+    if (h->hist_rep > 1) launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, h->first_w2 ? 1 : 0, h->stream);  // one replica: nothing to fold
     if (h->first_w2) h->w2_spread = false;
     int r = g_rccl.AllReduce(h->d_hist, h->d_hist, size_t(h->n_bins), /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
     if (r == 0 && h->first_w2) {
@@ -1853,6 +1852,7 @@ int m3hip_debug_set_hist_replicas(m3hip_handle h, int n) try {
   if (!h || n < 1 || n > 64) return M3HIP_EINVAL;
   if (h->n_bins != 0) return fail(h, M3HIP_ESTATE, "set_hist_replicas must precede set_binning");
   h->hist_rep = h->hist_rep_cfg = n;
+  h->hist_rep_forced = true;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

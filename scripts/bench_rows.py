@@ -42,6 +42,10 @@ def bins_row(E, nx, ny, n_samples):
     eng.close()
 if only == "bins":
     bins_row(100000, 20, 10, 1)
+    bins_row(100000, 40, 20, 1)
+    bins_row(100000, 50, 40, 1)
+    bins_row(1000000, 20, 10, 1)
+    bins_row(1000000, 50, 40, 1)
     bins_row(100000, 60, 40, 3)
     bins_row(100000, 100, 80, 4)
     sys.exit(0)
