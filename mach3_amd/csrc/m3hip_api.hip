@@ -190,7 +190,7 @@ struct m3hip_ctx {
   int32_t* d_sample_off = nullptr;
   double* d_data = nullptr;
   double* d_hist = nullptr;  // [2][hist_rep][n_bins]
-  double* d_llh_partial = nullptr;  // split form of k_llh (many bins): [groups][n_samples]
+  double* d_llh_terms = nullptr;  // split form of k_llh (many bins): per-bin terms [n_bins]
   int hist_rep = 32;      // flush replicas of the bin vector in use (chosen at set_binning)
   int hist_rep_cfg = 32;  // ... upper limit
   bool hist_rep_forced = false;  // m3hip_debug_set_hist_replicas: use exactly that many
@@ -493,7 +493,7 @@ int m3hip_destroy(m3hip_handle h) try {
   dev_free(h->d_sample_off);
   dev_free(h->d_data);
   dev_free(h->d_hist);
-  dev_free(h->d_llh_partial);
+  dev_free(h->d_llh_terms);
   dev_free(h->d_dbg_clock);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -874,8 +874,8 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   if (nb <= 0) return fail(h, M3HIP_EINVAL, "set_binning: no bins");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist); dev_free(h->d_llh_partial);
-  h->d_sample_off = nullptr; h->d_data = nullptr; h->d_hist = nullptr; h->d_llh_partial = nullptr;
+  dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist); dev_free(h->d_llh_terms);
+  h->d_sample_off = nullptr; h->d_data = nullptr; h->d_hist = nullptr; h->d_llh_terms = nullptr;
   // The replicas spread the adds of thousands of workgroups over more addresses than one bin vector has: 32
   // copies at 200 bins = 6 400 addresses measured as fast as no contention at all.  More bins spread the adds by
   // themselves, while the per-step reset (k_prep) and the fold (k_llh) are linear in replicas x bins (118 us of a
@@ -885,10 +885,7 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
   if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2 * h->hist_rep))) return rc;
-  if (nb > M3_LLH_SPLIT_BINS) {
-    const size_t groups = (size_t(nb) + M3_LLH_SPLIT_LANES - 1) / M3_LLH_SPLIT_LANES;
-    if ((rc = dev_alloc(h, &h->d_llh_partial, groups * size_t(n_samples)))) return rc;
-  }
+  if (nb > M3_LLH_SPLIT_BINS && (rc = dev_alloc(h, &h->d_llh_terms, size_t(nb)))) return rc;
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
   HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
@@ -1679,7 +1676,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   // W2 that was frozen by the last reweight is folded in place once; while UpdateW2 keeps accumulating it is summed on the fly
   l.w2_mode = !h->w2_spread ? kW2Replica0 : (h->update_w2 ? kW2Fold : kW2FoldInPlace);
   l.out = h->d_out;
-  l.partial = h->d_llh_partial;
+  l.terms = h->d_llh_terms;
   // completion is signalled through host memory: k_llh writes the results, then this ticket
   volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(h->h_out + 1 + h->n_samples);
   l.done_flag = reinterpret_cast<volatile uint64_t*>(h->d_out + 1 + h->n_samples);

@@ -201,8 +201,8 @@ struct BinnedArgs {
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s);
 
 enum LlhW2Mode : int { kW2Replica0 = 0, kW2Fold = 1, kW2FoldInPlace = 2 };
-// bin vectors beyond this many bins are evaluated by one 1024-lane workgroup per 1024 bins plus a small final
-// kernel, instead of one workgroup walking all of them
+// bin vectors beyond this many bins are evaluated one lane per bin across workgroups (k_llh_terms) and summed by a
+// second small kernel (k_llh_sum), instead of one workgroup walking all of them with its terms in LDS
 constexpr int M3_LLH_SPLIT_BINS = 4096;
 constexpr int M3_LLH_SPLIT_LANES = 1024;
 
@@ -217,7 +217,7 @@ struct LlhArgs {
   int32_t w2_mode;  // kW2Replica0: w2 sits folded in replica 0; kW2Fold: sum the replicas (read only);
                     // kW2FoldInPlace: sum them, store the sum in replica 0 and clear the others (at the freeze)
   double* out;  // [1 + n_samples] (device pointer, may be mapped pinned host memory)
-  double* partial;  // [ceil(n_bins / M3_LLH_SPLIT_LANES)][n_samples]: per-workgroup sample sums of the split form (many bins)
+  double* terms;  // [n_bins] per-bin terms of the split form (more than M3_LLH_SPLIT_BINS bins), else unused
   uint64_t* dbg_clock;           // optional: [1] <- wall_clock64() at k_llh end
   volatile uint64_t* done_flag;  // mapped pinned host word; set to `ticket` after `out` is written
   uint64_t ticket;

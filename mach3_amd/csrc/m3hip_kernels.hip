@@ -934,24 +934,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// sum over the workgroup (NT = 256 or 1024 lanes), fixed order: wave sums, then a pairwise tree over the waves
-template <int NT>
-__device__ double block_sum(double v, double* scratch /*[NT / 64]*/) {
-  v = wave_sum(v);
-  const int wave = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
-  __syncthreads();
-  double t[NT / 64];
-#pragma unroll
-  for (int i = 0; i < NT / 64; ++i) t[i] = scratch[i];
-#pragma unroll
-  for (int n = NT / 64; n > 1; n >>= 1)
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
-  return t[0];
-}
-
 // fold the flush replicas into replica 0 (same fixed order as k_llh), so that the multi-GPU
 // all-reduce moves n_bins doubles instead of hist_rep * n_bins
 __global__ __launch_bounds__(256) void k_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2) {
@@ -987,45 +969,96 @@ __device__ __forceinline__ double fold_replicas(const double* base, int hist_rep
   return m;
 }
 
-// NT lanes: 256 for the usual few hundred bins, 1024 when a 2-D sample brings thousands (every pass over the bins is a
-// chain of dependent loads, so fewer passes is what counts)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_llh(LlhArgs a) {
-  __shared__ double scratch[NT / 64];
+// GetTestStatLLH of bin i on the bin vectors as the reweight kernels left them (read from the flush replicas;
+// W2 folded in place once, at its freeze)
+__device__ __forceinline__ double llh_term(const LlhArgs& a, int i) {
   const double* mc = a.hist;
   double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
-  // GetLikelihood() = sum over samples of GetSampleLikelihood(s) = sum over the sample's bins of
-  // GetTestStatLLH (SampleHandlerFD.cpp:1262-1300).  The bin vectors are read straight from the flush
-  // replicas: nothing is written back, so the call can be repeated.
-  double total = 0.0;
-  for (int s = 0; s < a.n_samples; ++s) {
-    const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
-    double sacc = 0.0;
-    for (int i = b0 + threadIdx.x; i < b1; i += NT) {
-      const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
-      double v;
-      if (a.w2_mode == kW2Replica0) {
-        v = w2[i];
-      } else {
-        v = fold_replicas(w2 + i, a.hist_rep, a.n_bins);
-        if (a.w2_mode == kW2FoldInPlace) {  // W2 was frozen by this reweight: keep it as one plain vector
-          w2[i] = v;
-          for (int r = 1; r < a.hist_rep; ++r) w2[(size_t)r * a.n_bins + i] = 0.0;
-        }
-      }
-      sacc += d_test_stat_llh(a.kind, a.data[i], m, v);
+  const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
+  double v;
+  if (a.w2_mode == kW2Replica0) {
+    v = w2[i];
+  } else {
+    v = fold_replicas(w2 + i, a.hist_rep, a.n_bins);
+    if (a.w2_mode == kW2FoldInPlace) {  // W2 was frozen by this reweight: keep it as one plain vector
+      w2[i] = v;
+      for (int r = 1; r < a.hist_rep; ++r) w2[(size_t)r * a.n_bins + i] = 0.0;
     }
-    const double st = block_sum<NT>(sacc, scratch);
-    if (threadIdx.x == 0) a.out[1 + s] = st;
-    total += st;
   }
-  if (threadIdx.x == 0) a.out[0] = total;
-  // publish: results first, then the ticket the host is spinning on (system scope: host memory)
-  if (threadIdx.x == 0 && a.dbg_clock) a.dbg_clock[1] = wall_clock64();
-  if (threadIdx.x == 0 && a.done_flag) {
+  return d_test_stat_llh(a.kind, a.data[i], m, v);
+}
+
+// GetLikelihood() = sum over samples of GetSampleLikelihood(s) = sum over the sample's bins of GetTestStatLLH
+// (SampleHandlerFD.cpp:1262-1300), from the per-bin terms: the waves take the samples round-robin, the lanes of a
+// wave stride over the sample's bins (8 loads in flight), wave tree, then the samples in order -- a fixed order
+// throughout, so the result is reproducible; its cost does not grow with the number of samples beyond their bins
+// (a workgroup-wide reduction per sample cost 2.6 us each: 78 us at 30 samples).  Returns the total in thread 0.
+template <int NT>
+__device__ double sum_by_sample(const LlhArgs& a, const double* terms, double* sums /*[NT], LDS*/) {
+  constexpr int NW = NT / 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double total = 0.0;
+  for (int s0 = 0; s0 < a.n_samples; s0 += NT) {  // rounds of NT samples: in practice one
+    const int s1 = s0 + NT < a.n_samples ? s0 + NT : a.n_samples;
+    for (int s = s0 + wave; s < s1; s += NW) {
+      const int b1 = a.sample_off[s + 1];
+      int i = a.sample_off[s] + lane;
+      double acc = 0.0;
+      for (; i + 7 * 64 < b1; i += 8 * 64) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = terms[i + u * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+      }
+      for (; i < b1; i += 64) acc += terms[i];
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        sums[s - s0] = acc;
+        a.out[1 + s] = acc;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < s1 - s0; ++k) total += sums[k];
+    __syncthreads();
+  }
+  return total;
+}
+
+// results first, then the ticket the host is spinning on (system scope: host memory)
+__device__ __forceinline__ void publish_llh(const LlhArgs& a, double total) {
+  a.out[0] = total;
+  if (a.dbg_clock) a.dbg_clock[1] = wall_clock64();
+  if (a.done_flag) {
     __threadfence_system();
     *a.done_flag = a.ticket;
   }
+}
+
+// Up to M3_LLH_SPLIT_BINS bins: one workgroup, the terms pass through LDS.  NT lanes: 256 for the usual few hundred
+// bins, 1024 beyond 1 024 (every pass over the bins is a chain of dependent loads: fewer passes is what counts).
+// Nothing is written back to the bin vectors, so the call can be repeated.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_llh(LlhArgs a) {
+  __shared__ double terms[M3_LLH_SPLIT_BINS];
+  __shared__ double sums[NT];
+  for (int i = threadIdx.x; i < a.n_bins; i += NT) terms[i] = llh_term(a, i);
+  __syncthreads();
+  const double total = sum_by_sample<NT>(a, terms, sums);
+  if (threadIdx.x == 0) publish_llh(a, total);
+}
+
+// Beyond that (2-D samples with thousands of bins): one lane per bin across as many workgroups as it takes, the
+// terms pass through global memory, and a second small kernel sums them.
+__global__ __launch_bounds__(M3_LLH_SPLIT_LANES) void k_llh_terms(LlhArgs a) {
+  const int i = (int)blockIdx.x * M3_LLH_SPLIT_LANES + (int)threadIdx.x;
+  if (i < a.n_bins) a.terms[i] = llh_term(a, i);
+}
+__global__ __launch_bounds__(M3_LLH_SPLIT_LANES) void k_llh_sum(LlhArgs a) {
+  __shared__ double sums[M3_LLH_SPLIT_LANES];
+  const double total = sum_by_sample<M3_LLH_SPLIT_LANES>(a, a.terms, sums);
+  if (threadIdx.x == 0) publish_llh(a, total);
 }
 
 // oscillation-weight table in the other precision of M3::float_t (widening is exact; narrowing is what a
@@ -1042,70 +1075,11 @@ void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t
   else hipLaunchKernelGGL(k_osc_narrow, dim3(g), dim3(256), 0, s, f64, reinterpret_cast<float*>(dst), n);
 }
 
-// Split form for thousands of bins (2-D samples): workgroup g evaluates bins [g * 1024, (g + 1) * 1024) -- one bin per
-// lane, one round of loads instead of a pass per 1024 bins -- and leaves the sums of its bins per sample;
-// k_llh_final adds them per sample in workgroup order (fixed, so the result is reproducible), then the samples.
-__global__ __launch_bounds__(M3_LLH_SPLIT_LANES) void k_llh_partial(LlhArgs a) {
-  constexpr int NT = M3_LLH_SPLIT_LANES;
-  __shared__ double scratch[NT / 64];
-  const double* mc = a.hist;
-  double* w2 = const_cast<double*>(a.hist) + (size_t)a.hist_rep * a.n_bins;
-  const int lo = (int)blockIdx.x * NT, hi = lo + NT < a.n_bins ? lo + NT : a.n_bins;
-  const int i = lo + (int)threadIdx.x;
-  double term = 0.0;
-  if (i < hi) {
-    const double m = fold_replicas(mc + i, a.hist_rep, a.n_bins);
-    double v;
-    if (a.w2_mode == kW2Replica0) {
-      v = w2[i];
-    } else {
-      v = fold_replicas(w2 + i, a.hist_rep, a.n_bins);
-      if (a.w2_mode == kW2FoldInPlace) {
-        w2[i] = v;
-        for (int r = 1; r < a.hist_rep; ++r) w2[(size_t)r * a.n_bins + i] = 0.0;
-      }
-    }
-    term = d_test_stat_llh(a.kind, a.data[i], m, v);
-  }
-  for (int s = 0; s < a.n_samples; ++s) {
-    const int b0 = a.sample_off[s], b1 = a.sample_off[s + 1];
-    double st = 0.0;
-    if (b1 > lo && b0 < hi) st = block_sum<NT>((i >= b0 && i < b1 && i < hi) ? term : 0.0, scratch);  // workgroup-uniform test
-    if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * a.n_samples + s] = st;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_llh_final(LlhArgs a, int n_groups) {
-  __shared__ double per_sample[256];
-  double total = 0.0;
-  for (int s0 = 0; s0 < a.n_samples; s0 += 256) {  // (more than 256 samples: in rounds)
-    const int s = s0 + (int)threadIdx.x;
-    double st = 0.0;
-    if (s < a.n_samples) {
-      for (int g = 0; g < n_groups; ++g) st += a.partial[(size_t)g * a.n_samples + s];
-      a.out[1 + s] = st;
-    }
-    per_sample[threadIdx.x] = st;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int k = 0; k < 256 && s0 + k < a.n_samples; ++k) total += per_sample[k];  // sample order, as GetLikelihood sums them
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    a.out[0] = total;
-    if (a.dbg_clock) a.dbg_clock[1] = wall_clock64();
-    if (a.done_flag) {
-      __threadfence_system();
-      *a.done_flag = a.ticket;
-    }
-  }
-}
-
 void launch_llh(const LlhArgs& a, hipStream_t s) {
-  if (a.n_bins > M3_LLH_SPLIT_BINS && a.partial) {
+  if (a.n_bins > M3_LLH_SPLIT_BINS) {
     const int n_groups = (a.n_bins + M3_LLH_SPLIT_LANES - 1) / M3_LLH_SPLIT_LANES;
-    hipLaunchKernelGGL(k_llh_partial, dim3(n_groups), dim3(M3_LLH_SPLIT_LANES), 0, s, a);
-    hipLaunchKernelGGL(k_llh_final, dim3(1), dim3(256), 0, s, a, n_groups);
+    hipLaunchKernelGGL(k_llh_terms, dim3(n_groups), dim3(M3_LLH_SPLIT_LANES), 0, s, a);
+    hipLaunchKernelGGL(k_llh_sum, dim3(1), dim3(M3_LLH_SPLIT_LANES), 0, s, a);
   } else if (a.n_bins > 1024) {
     hipLaunchKernelGGL(k_llh<1024>, dim3(1), dim3(1024), 0, s, a);
   } else {

@@ -40,6 +40,35 @@ def bins_row(E, nx, ny, n_samples):
         step(); d = (C.c_double * 5)(); eng.lib.m3hip_debug_device_span(eng.h, 0, C.cast(d, C.POINTER(C.c_double))); dev.append(d[0])
     print(f"many bins: E={E}, {n_samples} x {nx} x {ny} = {n_samples*nx*ny} bins: step {t:.1f} us (device span k_prep start -> k_llh end {np.median(dev):.1f} us)", flush=True)
     eng.close()
+# ---- many samples / many norm parameters per event: the loops over samples in k_llh and over norm slots in the epilogue
+def samples_row(E, n_samples, n_norm):
+    spec = synth.CONFIGS["c1"].scaled(E)
+    eng, mono, sh0, par0 = build_from_synth(spec)
+    ev = synth.events_chunk(spec, 0, E)
+    par = np.concatenate([par0, np.ones(n_norm)])
+    mono.setSplinePointers(par)
+    ex = np.linspace(0.0, 5.0, 101)
+    sid = rng.integers(0, n_samples, E).astype(np.int32)
+    sh = SampleHandlerFD(eng, n_samples, None, par, capi.kBarlowBeeston, bin_edges=[[ex]] * n_samples)
+    sh.SetupKinematics(0, sid, ev["erec"]); sh.ComputeBins()
+    cnt = rng.integers(max(0, n_norm - 3), n_norm + 1, E) if n_norm else np.zeros(E, np.int64)
+    norm_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    norm_idx = np.concatenate([len(par0) + np.sort(rng.choice(n_norm, c, replace=False)) for c in cnt]).astype(np.int16) if n_norm else np.zeros(0, np.int16)
+    sh.SetupEvents(0, sh.GetEventBins(0, E), ev["osc_idx"], norm_off, norm_idx)
+    sh.SetOscillationWeights(synth.osc_table(spec))
+    sh.Reweight(); sh.AddData(sh.GetMCArray())
+    def step():
+        par[:len(par0)] = synth.params(spec, int(rng.integers(1, 60))); par[len(par0):] = 1 + 0.05 * rng.standard_normal(n_norm); return sh.Step()
+    t = timeit(step)
+    print(f"samples/norms: E={E}, {n_samples} samples x 100 bins, up to {n_norm} norm parameters per event: step {t:.1f} us", flush=True)
+    eng.close()
+if only == "samples":
+    samples_row(100000, 1, 3)
+    samples_row(100000, 30, 3)
+    samples_row(100000, 1, 24)
+    samples_row(1000000, 1, 3)
+    samples_row(1000000, 1, 24)
+    sys.exit(0)
 if only == "bins":
     bins_row(100000, 20, 10, 1)
     bins_row(100000, 40, 20, 1)
