@@ -1,5 +1,6 @@
 """Soak: many fused steps in one process; reports latency percentiles per block of steps and the process RSS, to catch
-leaks (host command lists, events) and drifts.  usage: soak.py [events] [steps]"""
+leaks (host command lists, events) and drifts.  usage: soak.py [events] [steps] [config] [samples nx ny]
+(with the last three: 2-D samples, device-side binning, Barlow-Beeston -- the many-bins form of the fill and of k_llh)"""
 import sys, os, time, resource
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT)
@@ -8,8 +9,21 @@ from mach3_amd import synth
 from mach3_amd.engine import build_from_synth
 ev = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
-spec = synth.CONFIGS["c2"].scaled(ev, n_params=32)
+cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"
+spec = synth.CONFIGS[cfg].scaled(ev, n_params=32 if cfg == "c2" else 96)
 eng, mono, sh, par = build_from_synth(spec)
+if len(sys.argv) > 6:
+    from mach3_amd import capi
+    from mach3_amd.engine import SampleHandlerFD
+    n_samp, nx, ny = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    rng = np.random.default_rng(3)
+    evs = synth.events_chunk(spec, 0, ev)
+    ex, ey = np.linspace(0.0, 5.0, nx + 1), np.linspace(-1.0, 1.0, ny + 1)
+    sh = SampleHandlerFD(eng, n_samp, None, par, capi.kBarlowBeeston, bin_edges=[[ex, ey]] * n_samp)
+    sh.SetupKinematics(0, rng.integers(0, n_samp, ev).astype(np.int32), np.stack([evs["erec"], rng.uniform(-1.0, 1.0, ev)], axis=1))
+    sh.ComputeBins()
+    sh.SetupEvents(0, sh.GetEventBins(0, ev), evs["osc_idx"], evs["norm_off"], evs["norm_idx"])
+    sh.SetOscillationWeights(synth.osc_table(spec))
 sh.Reweight(); sh.AddData(sh.GetMCArray())
 laps=[synth.params(spec,i+1) for i in range(64)]
 def rss_mb():
