@@ -1209,3 +1209,35 @@ def test_pymach3_style_names(fresh_engine):
         omono.evaluate()
         assert all(np.float32(mono.get_event_weight(e)) == omono.total_weights[e] for e in (0, 1, E // 2, E - 1))
     omono.close()
+
+
+def test_two_sample_handlers_interleaved():
+    """A fitter with two sample handlers calls Reweight() on both and then GetLikelihood() on both
+    (Fitters/MR2T2.cpp:66-76).  Each handler owns an engine handle (its own stream), so the two reweights overlap on
+    the device; results must equal what each handler gives on its own."""
+    spec_a = synth.CONFIGS["c2"].scaled(6000, n_params=20)
+    spec_b = synth.CONFIGS["c3"].scaled(5000, n_params=64)
+    eng_a, mono_a, sh_a, par_a = build_from_synth(spec_a)
+    eng_b, mono_b, sh_b, par_b = build_from_synth(spec_b)
+    try:
+        for sh in (sh_a, sh_b):
+            sh.Reweight()
+            sh.AddData(sh.GetMCArray())
+        alone = []
+        for lap in (1, 2, 3):
+            par_a[:] = synth.params(spec_a, lap)
+            par_b[:] = synth.params(spec_b, lap)
+            alone.append((sh_a.Step(), sh_b.Step(), sh_a.GetMCArray(), sh_b.GetMCArray()))
+        for rep in range(3):
+            for lap in (1, 2, 3):
+                par_a[:] = synth.params(spec_a, lap)
+                par_b[:] = synth.params(spec_b, lap)
+                sh_a.Reweight()
+                sh_b.Reweight()
+                la, lb = sh_a.GetLikelihood(), sh_b.GetLikelihood()
+                ea, eb, mca, mcb = alone[lap - 1]
+                assert la == pytest.approx(ea, rel=1e-12) and lb == pytest.approx(eb, rel=1e-12)
+                assert np.allclose(sh_a.GetMCArray(), mca, rtol=1e-12) and np.allclose(sh_b.GetMCArray(), mcb, rtol=1e-12)
+    finally:
+        eng_a.close()
+        eng_b.close()
