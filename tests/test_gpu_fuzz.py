@@ -60,7 +60,21 @@ def _case(seed):
 
 @pytest.mark.parametrize("seed", range(64 * SCALE))
 def test_random_shape(fresh_engine, seed):
-    c = _case(seed)
+    _run_case(fresh_engine, _case(seed), seed)
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_random_shape_many_bins_and_samples(fresh_engine, seed):
+    """the same sweep with the bin space of 2-D / atmospheric analyses: up to 24 samples, up to 9 600 bins (the
+    replica count, the LDS / global form of the fill and the one- / two-kernel form of the bin likelihood all
+    depend on these two numbers)"""
+    c = _case(1000 + seed)
+    c["n_samples"] = int([1, 2, 5, 24][seed % 4])
+    c["nb"] = int([40, 400, 1100, 2600, 4800][(seed // 2) % 5] if c["n_samples"] < 5 else [40, 200, 400][seed % 3])
+    _run_case(fresh_engine, c, 1000 + seed)
+
+
+def _run_case(fresh_engine, c, seed):
     rng, P, E = c["rng"], c["P"], c["E"]
     cx, npts, ch = make_monolith(P, 7, c["xs"], c["events"])
     nPar = P + c["n_norm"]
