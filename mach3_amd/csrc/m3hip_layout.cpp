@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <thread>
 
 namespace m3hip {
@@ -20,13 +21,20 @@ void parallel_for(uint64_t n, F&& body) {
   }
   if (nt > n) nt = unsigned(n);
   std::vector<std::thread> th;
+  std::vector<std::exception_ptr> failed(nt);  // an exception must not leave a thread: it is rethrown in the caller
   th.reserve(nt);
   for (unsigned t = 0; t < nt; ++t) {
     th.emplace_back([&, t]() {
-      for (uint64_t i = t; i < n; i += nt) body(i);
+      try {
+        for (uint64_t i = t; i < n; i += nt) body(i);
+      } catch (...) {
+        failed[t] = std::current_exception();
+      }
     });
   }
   for (auto& x : th) x.join();
+  for (const std::exception_ptr& f : failed)
+    if (f) std::rethrow_exception(f);
 }
 
 // true when events [e0, e1) all carry the parameter lists of event e0
@@ -352,10 +360,31 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
   plan->brick_words.clear();
   plan->tile_params.clear();
   plan->n_padded = plan->pad_spl = plan->pad_tf1 = 0;
+  // the bricks first, each on its own (the inverted index and the metadata stream of a brick are the expensive part
+  // of planning a ragged chunk, and bricks do not depend on one another) ...
+  struct BrickJob { uint64_t t0, t1; BrickHost bh; std::vector<uint32_t> words; std::string err; bool ok = true; };
+  std::vector<BrickJob> jobs;
   for (uint64_t t0 = 0; t0 < n_tiles;) {
     uint64_t t1 = t0 + 1;
-    if (!uniform[t0])
+    if (!uniform[t0]) {
       while (t1 < n_tiles && t1 - t0 < tiles_per_group && !uniform[t1]) ++t1;
+      jobs.emplace_back();
+      jobs.back().t0 = t0;
+      jobs.back().t1 = t1;
+    }
+    t0 = t1;
+  }
+  parallel_for(jobs.size(), [&](uint64_t j) {
+    BrickJob& job = jobs[j];
+    const uint64_t e0 = job.t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, job.t1 * M3_TE);
+    job.ok = plan_brick(n_params, npts, in, e0, e1, &job.bh, &job.words, &job.err);
+  });
+  for (const BrickJob& job : jobs)
+    if (!job.ok) { *err = job.err; return false; }  // the first failing brick in event order
+  // ... then tiles and bricks take their places in the stores in event order
+  size_t next_job = 0;
+  for (uint64_t t0 = 0; t0 < n_tiles;) {
+    uint64_t t1 = t0 + 1;
     if (uniform[t0]) {
       for (uint64_t t = t0; t < t1; ++t) {
         TileHost th;
@@ -389,9 +418,12 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
         plan->n_uniform++;
       }
     } else {
-      const uint64_t e0 = t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, t1 * M3_TE);
-      BrickHost bh;
-      if (!plan_brick(n_params, npts, in, e0, e1, &bh, &plan->brick_words, err)) return false;
+      BrickJob& job = jobs[next_job++];
+      t1 = job.t1;
+      BrickHost& bh = job.bh;
+      bh.words_off = plan->brick_words.size();
+      plan->brick_words.insert(plan->brick_words.end(), job.words.begin(), job.words.end());
+      std::vector<uint32_t>().swap(job.words);
       bh.spl_off = plan->spl_float4;
       bh.tf1_off = plan->tf1_float2;
       plan->spl_float4 += bh.n_spl_f4;
