@@ -25,6 +25,12 @@ $(LIBDIR)/libm3synth.so: mach3_amd/synth/m3synth.c mach3_amd/synth/m3synth.h
 oracle:
 	$(MAKE) -C oracle
 
+# diagnostic build of the engine with phase stamps in the brick kernel (scripts/brick_stamps.py)
+stamps: build/libm3hip_stamps.so
+build/libm3hip_stamps.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_STAMPS -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+
 isa: $(CSRC)/m3hip_kernels.hip
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage \
@@ -34,7 +40,7 @@ clean:
 	rm -f $(LIBDIR)/*.so build/*
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean isa
+.PHONY: all oracle clean isa stamps
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
 examples: build/mr2t2_dragrace build/facade_check build/libm3facade_test.so
@@ -58,7 +64,7 @@ build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/
 .PHONY: examples
 
 # calibration programs behind the ceilings quoted in DESIGN.md / profiles/README.md (run on an MI355X)
-TOOLS = build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths
+TOOLS = build/sector_fetch build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths
 tools: $(TOOLS)
 build/%: tools/%.hip
 	@mkdir -p build

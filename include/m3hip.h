@@ -346,8 +346,9 @@ int m3hip_debug_host_times(m3hip_handle h, double* out6);
  * clock at k_prep start, at k_llh end, host clock at the k_prep launch, at completion seen}. */
 int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us);
 
-/* Host-only probe of the upload re-layout (no device needed): sizes[6] = {n_tiles,
- * spline store in float4, TF1 store in float2, slot-meta in int32, n_bricks, brick words};
+/* Host-only probe of the upload re-layout (no device needed): sizes[8] = {n_tiles,
+ * spline store in float4, TF1 store in float2, slot-meta in int32, n_bricks, brick words,
+ * first word of the bricks' TF1 parameter dictionary inside the brick words, its entries};
  * with non-NULL output buffers of those sizes it also fills them,
  * tile_desc[n_tiles][8] = {spl_off, tf1_off, meta_off, n_spl_slots, n_tf1_slots, n_events,
  * first_event, n_planes} and brick_desc[n_bricks][8] = {spl_off, tf1_off, words_off,

@@ -84,6 +84,7 @@ struct m3hip_ctx {
   std::map<std::vector<int32_t>, uint32_t> list_index;
   std::vector<int32_t> u_param, u_plane0;
   std::vector<uint32_t> tile_res_off;
+  std::vector<uint32_t> brick_res_off;  // per brick: first resolved slot of its chunk's TF1 dictionary
   int32_t* d_u_param = nullptr;
   int32_t* d_u_plane0 = nullptr;
   RSlot* d_resolved = nullptr;
@@ -322,7 +323,7 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_u_param); h->d_u_param = nullptr;
   dev_free(h->d_u_plane0); h->d_u_plane0 = nullptr;
   dev_free(h->d_resolved); h->d_resolved = nullptr;
-  h->list_index.clear(); h->u_param.clear(); h->u_plane0.clear(); h->tile_res_off.clear();
+  h->list_index.clear(); h->u_param.clear(); h->u_plane0.clear(); h->tile_res_off.clear(); h->brick_res_off.clear();
   h->n_res = 0;
   dev_free(h->d_coeff_x); h->d_coeff_x = nullptr;
   dev_free(h->d_npts); h->d_npts = nullptr;
@@ -659,10 +660,12 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   const std::vector<int32_t> h_meta(s_meta, s_meta + plan.meta_int32);
 
   Chunk c;
-  hipError_t e = hipMalloc(&c.d_spl, b_spl ? b_spl : 16);
-  if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 ? b_tf1 : 16);
+  // + 256 B: idle lanes of the brick kernel read (and drop) one element at a row's first slot, which for the last row
+  // of the last brick may be the slot right behind the store
+  hipError_t e = hipMalloc(&c.d_spl, b_spl + 256);
+  if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 + 256);
   const size_t b_words = plan.brick_words.size() * sizeof(uint32_t);
-  if (e == hipSuccess && b_words) e = hipMalloc((void**)&c.d_words, b_words);
+  if (e == hipSuccess && b_words) e = hipMalloc((void**)&c.d_words, b_words + 256);
   if (e == hipSuccess && b_words) e = hipMemcpy(c.d_words, plan.brick_words.data(), b_words, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
@@ -707,15 +710,40 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     }
     h->tile_res_off.push_back(off);
   }
+  // The bricks' TF1 codes step through the chunk's dictionary of TF1 parameters; the parameter VALUE of every entry is
+  // resolved once per step next to the uniform tiles' slot lists (k_prep / k_resolve: RSlot::f), so a brick fetches
+  // its table with one load per lane.  Chunks with the same dictionary share the resolved entries.
+  uint32_t dict_res = 0;
+  if (!plan.bricks.empty() && !plan.tf1_dict.empty()) {
+    std::vector<int32_t> key(plan.tf1_dict.begin(), plan.tf1_dict.end());
+    key.push_back(-2);  // cannot collide with a tile's list (those end in their TSpline3 slot count >= 0)
+    auto it = h->list_index.find(key);
+    if (it == h->list_index.end()) {
+      dict_res = uint32_t(h->u_param.size());
+      for (uint16_t p : plan.tf1_dict) {
+        h->u_param.push_back(int32_t(p));
+        h->u_plane0.push_back(-1);
+      }
+      h->list_index.emplace(std::move(key), dict_res);
+    } else {
+      dict_res = it->second;
+    }
+  }
   for (const BrickHost& bh : plan.bricks) {
+    h->brick_res_off.push_back(dict_res);
     BrickDev bd;
     bd.spl = reinterpret_cast<const float4*>(c.d_spl) + bh.spl_off;
     bd.tf1 = reinterpret_cast<const float2*>(c.d_tf1) + bh.tf1_off;
     bd.words = c.d_words + bh.words_off;
+    bd.tf1_x = nullptr;  // set in monolith_end once the resolved slots are allocated
     bd.n_events = bh.n_events;
     bd.first_event = uint32_t(h->E + bh.first_event);
-    bd.n_hdr_words = 1 + uint32_t(M3_STAGE_HDR) * plan.brick_words[bh.words_off];
-    bd.pad_ = 0;
+    const uint32_t* bw = plan.brick_words.data() + bh.words_off;
+    bd.n_stages = bw[0];
+    bd.off_tf1 = bw[1];
+    for (int i = 0; i < 4; ++i) bd.st0[i] = bd.n_stages ? bw[M3_BRICK_HDR0 + i] : 0u;
+    bd.n_dict = uint32_t(plan.tf1_dict.size());
+    bd.pad_[0] = bd.pad_[1] = bd.pad_[2] = 0;
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;
@@ -747,6 +775,7 @@ int m3hip_monolith_end(m3hip_handle h) try {
     HIPCHK(h, hipMemset(h->d_resolved, 0, sizeof(RSlot) * h->n_res));
   }
   for (uint64_t t = 0; t < n_tiles; ++t) h->h_tiles[t].res = h->d_resolved + h->tile_res_off[t];
+  for (size_t b = 0; b < h->h_bricks.size(); ++b) h->h_bricks[b].tf1_x = h->d_resolved + h->brick_res_off[b];
   h->list_index.clear();
   if ((rc = dev_alloc(h, &h->d_bricks, h->h_bricks.size()))) return rc;
   if (!h->h_bricks.empty())
@@ -1921,6 +1950,8 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   sizes[3] = plan.meta_int32;
   sizes[4] = plan.bricks.size();
   sizes[5] = plan.brick_words.size();
+  sizes[6] = plan.dict_off;          // first word of the bricks' TF1 dictionary inside brick_words
+  sizes[7] = plan.tf1_dict.size();
   if (!spl || !tf1 || !meta || !tile_desc || !brick_desc || !brick_words) return M3HIP_OK;  // plan only
   fill_chunk(n_params, npts, in, plan, spl, tf1, meta);
   for (size_t t = 0; t < plan.tiles.size(); ++t) {

@@ -40,15 +40,19 @@ struct TileDev {
   uint32_t first_event;  // padded global index of lane 0
 };
 
-// Device-side descriptor of one brick (ragged 1024-event group), see m3hip_layout.h
+// Device-side descriptor of one brick (ragged group of <= 1024 events), see m3hip_layout.h.  Read with scalar loads.
 struct BrickDev {
   const float4* spl;
   const float2* tf1;
-  const uint32_t* words;  // metadata stream
+  const uint32_t* words;      // metadata stream
+  const RSlot* tf1_x;         // the chunk's TF1 parameter dictionary, resolved per step: tf1_x[k].f = value of entry k
   uint32_t n_events;
   uint32_t first_event;
-  uint32_t n_hdr_words;   // 1 + 8 * n_stages
-  uint32_t pad_;
+  uint32_t n_stages;          // TSpline3 stages
+  uint32_t off_tf1;           // word offset of the TF1 section
+  uint32_t st0[4];            // copy of stage 0's header: its metadata is requested without waiting for the header
+  uint32_t n_dict;
+  uint32_t pad_[3];
 };
 
 // ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307

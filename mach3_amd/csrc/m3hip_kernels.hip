@@ -308,8 +308,7 @@ __device__ __forceinline__ WT mul_binned_weights(WT tw, const ReweightArgs& a, u
 }
 
 template <class WT>
-__device__ __forceinline__ WT mul_norm_weights(WT tw, const ReweightArgs& a, uint64_t ev) {
-  uint32_t m = 0;
+__device__ __forceinline__ WT mul_norm_weights(WT tw, const ReweightArgs& a, uint64_t ev, uint32_t m = 0) {
   for (; m + 4 <= a.n_norm_slots; m += 4) {
     int idx[4];
     double v[4];
@@ -491,231 +490,364 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
 }
 
 // ------------------------------------------------------------------------------------
-// k_reweight_brick: one workgroup per brick (<= 1024 events with ragged parameter lists).
+// k_reweight_brick: one 1024-lane workgroup per brick (<= 1024 events with ragged parameter lists), lane = event.
 //
-// Stage by stage (<= 8192 responses each): phase A evaluates the stage's responses
-// lane-per-response in PARAMETER-major order -- a run's active segment plane is contiguous,
-// so the float4 loads coalesce -- and scatters each weight to its event-major slot of an LDS
-// staging array; phase B lets every event multiply its slice in ascending parameter order.
-// HBM bytes per TSpline3 response: 16 (quad) + 4 (run/dst word); per TF1: 8 + 2.
+// TSpline3 responses, stage by stage (<= M3_STAGE_CAP responses): phase A evaluates the stage's responses
+// lane-per-response in PARAMETER-major order -- a run's active segment plane is contiguous, so the float4 loads
+// coalesce -- and scatters each weight to ell[rank][event] in LDS; phase B lets every event multiply its column
+// ell[0..n)[event], ascending parameter = the reference's order.  TF1 responses are read lane-per-event from the wave's
+// jagged rows straight into the register product (no segment to select, so no regrouping and no LDS).
+// HBM bytes per TSpline3 response: 16 (quad) + 2 (word) (+ the padding of the run's plane to a 128-B line);
+// per TF1 response: 8 + 1; per run: 8; per event: 1 + the sample side.
+//
+// Latency structure.  The coefficient loads of stage s+1 are issued BEFORE phase B of stage s (right after the barrier
+// that publishes the stage's resolved run table), so a workgroup has quads in flight through its barriers and LDS
+// phases; everything those loads need -- response words, run entries -- is requested one stage earlier still, and the
+// parameters' {segment, dx} sit in LDS, so no dependent round trip lies between two stages' coefficient loads.
 // ------------------------------------------------------------------------------------
-constexpr int kBrickThreads = 1024;                              // one event per lane; 2 workgroups per CU = 8 waves per SIMD
-constexpr int kBrickBatchDefault = 4;                             // coefficient loads in flight per lane: 8 would need > 64 VGPRs (spills)
-constexpr int kBrickEvPerLane = M3_GROUP / kBrickThreads;         // events per lane in phase B
-constexpr int kBrickRespPerLane = M3_BRICK_CAP / kBrickThreads;   // responses per lane and stage
-constexpr int kBrickMaxStages = M3_BRICK_MAX_STAGES;
-static_assert(1 + M3_STAGE_HDR * kBrickMaxStages <= kBrickThreads, "the stage headers are fetched by one load per lane");
-constexpr int kBrickLdsParams = 1024;                             // per-step parameter table kept in LDS up to this P
-constexpr int kBrickRunsPerLane = M3_BRICK_MAX_RUNS / kBrickThreads;
+constexpr int kBrickThreads = 1024;                                // one event per lane; 2 workgroups per CU = 8 waves per SIMD
+constexpr int kBrickRPL = M3_STAGE_CAP / kBrickThreads;            // responses per lane and stage = coefficient loads in flight per lane
+constexpr int kBrickHdrWords = M3_BRICK_HDR0 + M3_STAGE_HDR * (M3_BRICK_MAX_STAGES + 2);  // + 2: look-ahead reads past the last stage see zeros
+constexpr int kBrickLdsParams = 1024;                              // per-step parameter table {segment, dx} kept in LDS up to this P
+constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 1, kBrickGrpSlots = M3_STAGE_CAP / 64;
+constexpr int kBrickTf1Batch = 16;                                 // TF1 rows in flight per lane (the registers the quads held)
+static_assert(M3_STAGE_CAP % kBrickThreads == 0, "a stage is a whole number of responses per lane");
+static_assert(kBrickHdrWords <= kBrickThreads, "the stage headers are fetched by one load per lane");
+static_assert(M3_STAGE_MAX_RUNS <= kBrickThreads && M3_STAGE_CAP / 64 <= kBrickThreads, "run entries and group entries: one per lane");
+static_assert(M3_GROUP == kBrickThreads, "lane = event");
 
-struct RRun {      // per-step resolved run: address = base + r, dx of the run's parameter
-  int32_t base;    // coef_off + seg * n_run - start_r   (float4 units from the brick's store)
+// Diagnostic build only (-DM3_BRICK_STAMPS, `make stamps`): lane 0 of every brick records the 100 MHz wall clock at the
+// kernel's phase boundaries into a device array read back with m3hip_debug_read_stamps.  The production build carries
+// none of this.
+#ifdef M3_BRICK_STAMPS
+constexpr int kStampSlots = 16, kStampBricks = 16384;
+__device__ unsigned long long g_brick_stamps[kStampBricks * kStampSlots];
+#define M3_STAMP(k)                                                                                       \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBricks) g_brick_stamps[blockIdx.x * kStampSlots + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int m3hip_debug_read_stamps(unsigned long long* out, unsigned long long n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_brick_stamps), sizeof(unsigned long long) * n_words, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define M3_STAMP(k) do {} while (0)
+#endif
+
+struct RRun {      // per-step resolved run: quad address = base + r, dx of the run's parameter
+  int32_t base;    // coef_off - start_r + seg * stride   (float4 units from the brick's store)
   float dx;
 };
 
-// Latency structure.  Per stage only the coefficient loads sit on the critical path, kBrickBatch per
-// lane in flight at once (4: two round trips for a full stage of 8 responses per lane).  With one event per
-// lane the kernel fits 64 VGPRs, so two 1024-lane workgroups give every SIMD its full 8 waves: the loads of
-// one wave hide behind the LDS phases and barriers of the others (512-lane workgroups at 122 VGPRs, i.e. 4
-// waves per SIMD, were 9-12 % slower).  Everything a stage
-// needs before it can issue them -- its response words, event slices and run entries -- is requested
-// right after the previous stage's loads were consumed and arrives under that stage's barrier and
-// phase B; the run entries are resolved against the per-step parameter table, which lives in LDS, so
-// no second global round trip hides in the resolution.
-template <int MODE, bool NT, int kBrickBatch, bool DYN = false>
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+
+// BIGP: more spline parameters than the LDS tables hold (kBrickLdsParams): {segment, dx} and the TF1 parameter values are
+// then read from global memory where they are needed -- a dependent round trip per stage and per TF1 response; a
+// separate instantiation, because a run-time branch around those loads would cost the common case its counted waits
+template <int MODE, bool NT, bool DYN = false, bool BIGP = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
-  __shared__ float stage_w[M3_BRICK_CAP];
-  __shared__ RRun lds_runs[2][M3_BRICK_MAX_RUNS];
-  __shared__ uint32_t lds_hdr[1 + M3_STAGE_HDR * kBrickMaxStages];
+  __shared__ float ell[M3_ELL_ROWS * M3_GROUP];
+  __shared__ RRun lds_runs[2 * kBrickRunSlots];   // two stages; + 1 slot each: lanes past a stage's last response index one run further
+  __shared__ uint16_t lds_grp[2 * kBrickGrpSlots];
+  __shared__ uint32_t lds_hdr[kBrickHdrWords];
+  __shared__ uint8_t lds_cnt[M3_GROUP];
   __shared__ PTab lds_ptab[kBrickLdsParams];
-  __shared__ float lds_pval[kBrickLdsParams];
+  __shared__ float lds_tf1x[kBrickLdsParams];  // parameter value per entry of the TF1 dictionary
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
+  const uint32_t wave_base = __builtin_amdgcn_readfirstlane(lane & ~63u);  // first lane of this wave
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
   const M3_GLOBAL uint32_t* __restrict__ words = as_global(bd.words);
-  const bool tab_in_lds = a.n_params <= kBrickLdsParams;  // kernel-uniform
+  const M3_GLOBAL PTab* __restrict__ ptab = as_global(a.ptab);
+  const uint32_t n_stages = bd.n_stages;
+  constexpr bool tab_in_lds = !BIGP;
 
-  // all stage headers and the per-step parameter table in one round trip
-  if (lane < 1 + M3_STAGE_HDR * kBrickMaxStages) lds_hdr[lane] = words[lane < bd.n_hdr_words ? lane : 0];
-  if (tab_in_lds) {
-    for (int p = lane; p < a.n_params; p += kBrickThreads) {
-      lds_ptab[p] = a.ptab[p];
-      lds_pval[p] = a.pval[p];
+  // what one stage's coefficient loads need, requested ahead of time (global loads only, nothing here waits)
+  struct Meta {
+    u16x2_t w[(kBrickRPL + 1) / 2];  // response words (0 past the stage's end), two per register
+    uint32_t grp;                    // lanes < n_groups: run of the group's first response
+  };
+  // NOTE: no branch may enclose a vector-memory instruction between the prologue and the last stage: hipcc's wait-count
+  // insertion falls back to vmcnt(0) at control-flow joins with loads pending, which would drain the quads in flight at
+  // every table build.  Hence clamped addresses instead of predicated loads, also for stages that do not exist (their
+  // header reads as zeros and the loads fetch the brick's first words).
+  auto fetch_meta = [&](uint32_t h0, uint32_t off_grp, uint32_t off_resp, Meta& m) {
+    const uint32_t n_resp = h0 & 0xFFFFu;
+    const uint32_t last = n_resp ? n_resp - 1 : 0u;
+    // SGPR base + 32-bit lane offset; lanes past the end re-read the last word (one line) and drop it
+    const M3_GLOBAL char* __restrict__ resp = (const M3_GLOBAL char*)(words + off_resp);
+#pragma unroll
+    for (int u = 0; u < kBrickRPL; ++u) {
+      const uint32_t r = lane + u * kBrickThreads;
+      const uint16_t v = *(const M3_GLOBAL uint16_t*)(resp + 2u * (r < n_resp ? r : last));
+      m.w[u / 2][u % 2] = r < n_resp ? v : (uint16_t)0;
     }
-  }
+    if (kBrickRPL & 1) m.w[kBrickRPL / 2][1] = 0;
+    const M3_GLOBAL char* __restrict__ grp = (const M3_GLOBAL char*)(words + off_grp);
+    const uint32_t n_grp = (n_resp + 63u) >> 6;
+    m.grp = *(const M3_GLOBAL uint16_t*)(grp + 2u * (lane < n_grp ? lane : 0u));
+  };
+  auto fetch_run = [&](uint32_t h0, uint32_t off_runs) -> u32x2_t {  // lanes < n_runs: the raw entry of run `lane`
+    const uint32_t n_runs = h0 >> 16;
+    const M3_GLOBAL char* __restrict__ runs = (const M3_GLOBAL char*)(words + off_runs);
+    return *(const M3_GLOBAL u32x2_t*)(runs + 8u * (lane < n_runs ? lane : 0u));
+  };
+
+  M3_STAMP(0);
+  // ---- prologue.  Round trip 1: the stage headers, stage 0's metadata (its header travels in the descriptor), the
+  // parameter table, and everything the TF1 side needs later
+  uint32_t hdr_w = 0;
+  if (lane < kBrickHdrWords) hdr_w = lane < M3_BRICK_HDR0 + M3_STAGE_HDR * n_stages ? words[lane] : 0u;
+  Meta m_cur;
+  u32x2_t re_cur;
+  fetch_meta(bd.st0[0], bd.st0[2], bd.st0[3], m_cur);
+  re_cur = fetch_run(bd.st0[0], bd.st0[1]);
+  const M3_GLOBAL uint32_t* __restrict__ tf1h = words + bd.off_tf1;
+  const uint32_t tf1_cnt = (tf1h[32 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;  // codes of this lane's event
+  uint32_t tf1_cbase = __builtin_amdgcn_readfirstlane(tf1h[wave_base >> 6]);       // this wave's first slot / code dword
+  uint32_t tf1_dbase = __builtin_amdgcn_readfirstlane(tf1h[16 + (wave_base >> 6)]);
+  const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
+  constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
+  float x_own = 0.f;
+  if (x_in_lds && lane < bd.n_dict) x_own = tf1x[lane].f;
+  lds_cnt[lane] = 0;
   if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
-  __syncthreads();
+  if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
+  if (x_in_lds && lane < bd.n_dict) lds_tf1x[lane] = x_own;
+  if (tab_in_lds && lane < (uint32_t)a.n_params) {
+    PTab t;
+    t.dx = ptab[lane].dx;
+    t.seg = ptab[lane].seg;
+    lds_ptab[lane] = t;
+  }
+  __syncthreads();  // headers and the parameter table visible
+  M3_STAMP(1);
+  auto hdr = [&](uint32_t s) -> const uint32_t* { return lds_hdr + M3_BRICK_HDR0 + M3_STAGE_HDR * s; };
 
-  float w[kBrickEvPerLane];
-#pragma unroll
-  for (int q = 0; q < kBrickEvPerLane; ++q) w[q] = 1.0f;  // SplineMonolith.cpp:798
-
-  const uint32_t n_stages = lds_hdr[0];
-  // what the NEXT stage needs before its coefficient loads can be issued
-  uint32_t ec_n[kBrickEvPerLane];
-  uint32_t m_n[kBrickRespPerLane];   // kind 0: {run:16 | dst:16} words, kind 1: the TF1's parameter
-  uint4 rt_n[kBrickRunsPerLane];     // kind 0: raw run entries {coef_off, n_run, start_r, param}
-
-  auto prefetch_issue = [&](uint32_t s) {  // global loads only: nothing here waits
-    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
-    const uint32_t kind = h[0], n_resp = h[1], last = n_resp - 1;
-#pragma unroll
-    for (int q = 0; q < kBrickEvPerLane; ++q) {
-      const uint32_t e = lane * kBrickEvPerLane + q;
-      const M3_GLOBAL uint16_t* __restrict__ st16 = (const M3_GLOBAL uint16_t*)(words + h[5]);
-      ec_n[q] = (uint32_t)st16[e] | ((uint32_t)st16[e + 1] << 16);  // {start, end}; events past the last one get empty slices
+  auto publish = [&](uint32_t s, uint32_t h0, uint32_t grp, u32x2_t e) {  // stage s's run table and group table -> LDS
+    if (lane < (h0 >> 16)) {
+      const uint32_t p = e.y >> 16;
+      PTab t;
+      if (tab_in_lds) {
+        t = lds_ptab[p];
+      } else {  // more parameters than the table holds: a dependent global round trip per stage
+        t.dx = ptab[p].dx;
+        t.seg = ptab[p].seg;
+      }
+      RRun rr;
+      rr.base = (int32_t)e.x + t.seg * (int32_t)(e.y & 0xFFFFu);
+      rr.dx = t.dx;
+      lds_runs[(s & 1u) * kBrickRunSlots + lane] = rr;
     }
-    if (kind == 0) {
-      const M3_GLOBAL uint32_t* __restrict__ resp = words + h[4];
+    if (lane < (uint32_t)kBrickGrpSlots) lds_grp[(s & 1u) * kBrickGrpSlots + lane] = (uint16_t)grp;
+  };
+  // stage 1's metadata is requested BEFORE stage 0's coefficient loads: vector memory returns in order, so whatever a
+  // stage's tables need has to be older than the quads that are in flight while the tables are built
+  Meta m_nxt;
+  u32x2_t re_nxt;
+  {
+    const uint32_t* h1 = hdr(1);
+    fetch_meta(h1[0], h1[2], h1[3], m_nxt);
+    re_nxt = fetch_run(h1[0], h1[1]);
+  }
+  publish(0, bd.st0[0], m_cur.grp, re_cur);
+  __syncthreads();  // stage 0's tables visible
+  M3_STAMP(2);
+
+  float4 c[kBrickRPL];
+  float dx[kBrickRPL];
+  const M3_GLOBAL char* __restrict__ spl_bytes = (const M3_GLOBAL char*)as_global(bd.spl);
+  // coefficient load of response lane + u * 1024 of stage s (tables of stage s visible)
+  auto issue_quad = [&](int u, uint32_t s, uint32_t n_resp, const Meta& m) {
+    const uint32_t r = lane + u * kBrickThreads;
+    // the run of a response: the run of its group's first response + the runs that END before it inside the group
+    const unsigned long long ends = __ballot((m.w[u / 2][u % 2] & 0x8000u) != 0);
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends, 0u));
+    const uint32_t run = (uint32_t)lds_grp[(s & 1u) * kBrickGrpSlots + ((wave_base + u * kBrickThreads) >> 6)] + before;
+    const RRun rr = lds_runs[(s & 1u) * kBrickRunSlots + (run < (uint32_t)M3_STAGE_MAX_RUNS ? run : (uint32_t)M3_STAGE_MAX_RUNS)];
+    dx[u] = rr.dx;
+    // SGPR base + 32-bit byte offset (a brick's store is far below 4 GB); lanes (and whole waves) past the stage's end
+    // read the brick's first quad -- one line -- and never use it
+    const uint32_t off = r < n_resp ? (uint32_t)(rr.base + (int32_t)r) << 4 : 0u;
+    const M3_GLOBAL f32x4_t* g = (const M3_GLOBAL f32x4_t*)(spl_bytes + off);
+    const f32x4_t v = NT ? __builtin_nontemporal_load(g) : *g;
+    c[u] = make_float4(v.x, v.y, v.z, v.w);
+  };
 #pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        m_n[u] = resp[r < n_resp ? r : last];
-      }
-      const M3_GLOBAL uint32_t* __restrict__ runs = words + h[3];  // 4 words per run
-      const uint32_t n_runs = h[2];
+  for (int u = 0; u < kBrickRPL; ++u) issue_quad(u, 0, bd.st0[0] & 0xFFFFu, m_cur);
+
+  // ---- TF1 side (SplineMonolith.cpp:818-825: after the TSpline3s, in the event's parameter order): one batch of rows
+  float2 ab[kBrickTf1Batch];
+  uint32_t code[kBrickTf1Batch / 4];
+  const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
+  auto tf1_issue = [&](uint32_t j0) {  // loads of rows j0 .. j0 + kBrickTf1Batch - 1 (nothing here waits)
 #pragma unroll
-      for (int u = 0; u < kBrickRunsPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t v = *(const M3_GLOBAL u32x4_t*)(runs + 4 * (size_t)(r < n_runs ? r : n_runs - 1));
-        rt_n[u] = make_uint4(v.x, v.y, v.z, v.w);
-      }
-    } else {
-      const M3_GLOBAL uint16_t* __restrict__ par = (const M3_GLOBAL uint16_t*)(words + h[4]);
+    for (int q = 0; q < kBrickTf1Batch / 4; ++q) {
+      const bool on = tf1_cnt > j0 + 4 * q;
+      const unsigned long long act = __ballot(on);
+      const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+      code[q] = *(const M3_GLOBAL uint32_t*)((const M3_GLOBAL char*)words + 4u * (on ? pos : tf1_dbase));  // idle lanes: an in-range word
+      tf1_dbase += (uint32_t)__popcll(act);
+    }
 #pragma unroll
-      for (int u = 0; u < kBrickRespPerLane; ++u) {
-        const uint32_t r = lane + u * kBrickThreads;
-        m_n[u] = par[r < n_resp ? r : last];
-      }
+    for (int i = 0; i < kBrickTf1Batch; ++i) {
+      const bool on = tf1_cnt > j0 + i;
+      const unsigned long long act = __ballot(on);
+      const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+      // idle lanes re-read the row's first slot (the stores end in a few spare bytes: m3hip_api.hip)
+      const M3_GLOBAL f32x2_t* g = (const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * (on ? pos : tf1_cbase));
+      const f32x2_t v = NT ? __builtin_nontemporal_load(g) : *g;
+      ab[i] = make_float2(v.x, v.y);
+      tf1_cbase += (uint32_t)__popcll(act);
     }
   };
-  auto prefetch_commit = [&](uint32_t s) {  // resolve the stage's runs for this step into its LDS table
-    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
-    if (h[0] != 0) return;
-    const uint32_t n_runs = h[2];
-    RRun* runs_s = lds_runs[s & 1];
-#pragma unroll
-    for (int u = 0; u < kBrickRunsPerLane; ++u) {
-      const uint32_t r = lane + u * kBrickThreads;
-      if (r < n_runs) {
-        const uint4 rt = rt_n[u];
-        const PTab pt = tab_in_lds ? lds_ptab[rt.w] : a.ptab[rt.w];
-        RRun rr;
-        rr.base = (int32_t)(rt.x + (uint32_t)pt.seg * rt.y) - (int32_t)rt.z;
-        rr.dx = pt.dx;
-        runs_s[r] = rr;
-      }
-    }
-  };
-
-  if (n_stages > 0) {
-    prefetch_issue(0);
-    prefetch_commit(0);
-  }
-  for (uint32_t s = 0; s < n_stages; ++s) {
-    const uint32_t* h = lds_hdr + 1 + M3_STAGE_HDR * s;
-    const uint32_t kind = h[0], n_resp = h[1];
-    uint32_t ec[kBrickEvPerLane];
-    uint32_t m[kBrickRespPerLane];
-#pragma unroll
-    for (int q = 0; q < kBrickEvPerLane; ++q) ec[q] = ec_n[q];
-#pragma unroll
-    for (int u = 0; u < kBrickRespPerLane; ++u) m[u] = m_n[u];
-    // stage s's run table is complete, and phase B of stage s-1 no longer reads stage_w
-    __syncthreads();
-    if (kind == 0) {
-      const RRun* runs_s = lds_runs[s & 1];
-#pragma unroll
-      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += kBrickBatch) {
-        if ((uint32_t)(b0 * kBrickThreads) < n_resp) {  // wave-uniform
-          float4 c[kBrickBatch];
-          float dx[kBrickBatch];
-#pragma unroll
-          for (int u = 0; u < kBrickBatch; ++u) {
-            const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            const RRun rr = runs_s[m[b0 + u] & 0xFFFFu];
-            // lanes past the end read an in-range quad and discard it
-            c[u] = stream_load<NT>(&bd.spl[(size_t)(uint32_t)(r < n_resp ? rr.base + (int32_t)r : rr.base)]);
-            dx[u] = rr.dx;
-          }
-#pragma unroll
-          for (int u = 0; u < kBrickBatch; ++u) {
-            const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            if (r < n_resp) stage_w[m[b0 + u] >> 16] = spline_poly(dx[u], c[u]);
-          }
-        }
-      }
-    } else {
-      const float2* __restrict__ tp = bd.tf1 + h[6];
-      const uint32_t last = n_resp - 1;
-#pragma unroll
-      for (int b0 = 0; b0 < kBrickRespPerLane; b0 += kBrickBatch) {
-        if ((uint32_t)(b0 * kBrickThreads) < n_resp) {
-          float2 c[kBrickBatch];
-          float x[kBrickBatch];
-#pragma unroll
-          for (int u = 0; u < kBrickBatch; ++u) {
-            const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            c[u] = stream_load<NT>(&tp[r < n_resp ? r : last]);
-            x[u] = tab_in_lds ? lds_pval[m[b0 + u]] : a.pval[m[b0 + u]];
-          }
-#pragma unroll
-          for (int u = 0; u < kBrickBatch; ++u) {
-            const uint32_t r = lane + (b0 + u) * kBrickThreads;
-            if (r < n_resp) stage_w[r] = fmaf(c[u].x, x[u], c[u].y);  // SplineMonolith.cpp:779
-          }
-        }
-      }
-    }
-    if (s + 1 < n_stages) prefetch_issue(s + 1);  // in flight during the barrier and phase B
-    __syncthreads();
-    // phase B: the event's slice of the staging array, ascending parameter = reference order
-#pragma unroll
-    for (int q = 0; q < kBrickEvPerLane; ++q) {
-      const uint32_t start = ec[q] & 0xFFFFu, cnt = (ec[q] >> 16) - start;
-      uint32_t i = 0;
-      for (; i + 4 <= cnt; i += 4) {  // four LDS reads in flight; the product itself stays sequential
-        const float v0 = stage_w[start + i], v1 = stage_w[start + i + 1], v2 = stage_w[start + i + 2], v3 = stage_w[start + i + 3];
-        w[q] *= v0;
-        w[q] *= v1;
-        w[q] *= v2;
-        w[q] *= v3;
-      }
-      for (; i < cnt; ++i) w[q] *= stage_w[start + i];
-    }
-    if (s + 1 < n_stages) prefetch_commit(s + 1);
-  }
-  __syncthreads();  // last phase B / lds_hist zeroing complete
-
-#pragma unroll
-  for (int q = 0; q < kBrickEvPerLane; ++q) {
-    const uint32_t e = lane * kBrickEvPerLane + q;
-    // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
-    // belong to somebody else's events and must touch nothing
-    if (e >= bd.n_events) continue;
-    const uint64_t pos = (uint64_t)bd.first_event + e;
-    const uint64_t ev = a.perm ? (uint64_t)a.perm[pos] : pos;  // processing order -> event
-    if (MODE & kModeEval) a.spline_w[ev] = w[q];
+  // ---- sample side of the event (CalcWeightTotal's inputs), requested while the TF1 rows stream: first the event's
+  // indices (with the first TF1 rows), then what they point at (small tables that live in L2); the tail finds both there
+  constexpr int kTailNorm = 4;  // norm slots fetched ahead; further ones are read in the tail itself
+  uint32_t ev_own = 0;  // this lane's event (an engine holds fewer than 2^32)
+  int32_t t_bin = -1, t_osc = -1, t_ni[kTailNorm];
+  float t_oscw = 1.f;
+  double t_nv[kTailNorm];
+  auto tail_issue_idx = [&]() {
+    ev_own = bd.first_event + (lane < bd.n_events ? lane : 0u);  // idle lanes shadow the brick's first event
+    if (a.perm) ev_own = a.perm[ev_own];  // processing order -> event; kernel-uniform branch: only grouped uploads pay this dependent load
     if (MODE & (kModeFill | kModeEventW)) {
-      float tw = mul_norm_weights(1.0f, a, ev);  // CalcWeightTotal, as in k_reweight_uniform
-      const int oi = a.osc[ev];
-      if (oi >= 0) tw *= a.osc_table[oi];
+      t_osc = a.osc[ev_own];
+#pragma unroll
+      for (int m = 0; m < kTailNorm; ++m) {  // no branch around the load (wait counts, see above): absent slots re-read a valid word
+        const bool has = (uint32_t)m < a.n_norm_slots;
+        const int16_t* src = has ? a.nidx + (uint64_t)m * a.e_pad + ev_own : (const int16_t*)a.bricks;
+        const int16_t v = *src;
+        t_ni[m] = has ? (int32_t)v : -1;
+      }
+    }
+    if ((MODE & kModeFill) && !DYN) t_bin = a.bin[ev_own];
+  };
+  auto tail_issue_val = [&]() {
+    if (MODE & (kModeFill | kModeEventW)) {
+      // a sample without oscillated events has no table, one without norm parameters no index array: absent entries
+      // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
+      const float* ot = a.osc_table ? a.osc_table : (const float*)a.bricks;
+      const double* pp = a.params ? a.params : (const double*)a.bricks;
+      t_oscw = ot[t_osc >= 0 ? t_osc : 0];
+#pragma unroll
+      for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
+    }
+  };
+  const bool any_tf1 = bd.n_dict > 0;  // kernel-uniform
+
+  float w = 1.0f;  // SplineMonolith.cpp:798
+  // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
+  // scattered to ell[rank][event], and its register reused at once for the next stage's load (LAST: for the first TF1
+  // rows instead); barrier; the event's column of the scatter array, ascending parameter = reference order.
+  auto stage = [&](uint32_t s, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const uint32_t n_resp = hdr(s)[0] & 0xFFFFu;
+    uint32_t n_resp_nxt = 0;
+    Meta m_nn;
+    u32x2_t re_nn;
+    if (!LAST) {
+      const uint32_t* h1 = hdr(s + 1);
+      n_resp_nxt = h1[0] & 0xFFFFu;
+      publish(s + 1, h1[0], m_nxt.grp, re_nxt);  // waits for stage s+1's metadata only: it is older than the quads in flight
+      const uint32_t* h2 = hdr(s + 2);
+      fetch_meta(h2[0], h2[2], h2[3], m_nn);
+      re_nn = fetch_run(h2[0], h2[1]);
+    }
+    __syncthreads();  // stage s+1's tables visible; every wave is through phase B of stage s-1: the scatter array is free
+#pragma unroll
+    for (int u = 0; u < kBrickRPL; ++u) {
+      const uint32_t r = lane + u * kBrickThreads;
+      if (r < n_resp) {
+        const uint32_t wd = m_cur.w[u / 2][u % 2], ev = wd & 0x3FFu, rk = (wd >> 10) & 0xFu;
+        ell[rk * M3_GROUP + ev] = spline_poly(dx[u], c[u]);
+        if (wd & 0x4000u) lds_cnt[ev] = (uint8_t)(rk + 1);  // the event's last response of the stage: its count
+      }
+      if (!LAST) issue_quad(u, s + 1, n_resp_nxt, m_nxt);
+    }
+    if (LAST) {
+      if (any_tf1) tf1_issue(0);
+      tail_issue_idx();
+    }
+    __syncthreads();  // the stage's scatter is complete
+    {
+      const uint32_t n = lds_cnt[lane];
+      lds_cnt[lane] = 0;
+      for (uint32_t j0 = 0; j0 < (uint32_t)M3_ELL_ROWS; j0 += 4) {
+        if (!__any(n > j0)) break;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ell[(j0 + i) * M3_GROUP + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w *= (j0 + i < n) ? v[i] : 1.0f;  // rows past the count hold stale values
+      }
+    }
+    if (!LAST) {
+      m_cur = m_nxt;
+      m_nxt = m_nn;
+      re_nxt = re_nn;
+    }
+  };
+  if (n_stages > 0) {
+    for (uint32_t s = 0; s + 1 < n_stages; ++s) {
+      stage(s, std::false_type{});
+      if (s < 4) M3_STAMP(3 + s);
+    }
+    stage(n_stages - 1, std::true_type{});
+    M3_STAMP(8);
+  } else {
+    if (any_tf1) tf1_issue(0);
+    tail_issue_idx();
+  }
+  tail_issue_val();  // waits for the indices (and with them the first TF1 rows, consumed next anyway)
+
+  if (any_tf1) {
+    int32_t kd = -1;  // position in the dictionary
+    for (uint32_t j0 = 0; __any(tf1_cnt > j0); j0 += kBrickTf1Batch) {
+      if (j0) tf1_issue(j0);
+#pragma unroll
+      for (int i = 0; i < kBrickTf1Batch; ++i) {
+        if (j0 + i < tf1_cnt) {
+          const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
+          const bool skip = cd == (uint32_t)M3_TF1_SKIP;
+          kd += skip ? 254 : (int32_t)cd;
+          const float x = x_in_lds ? lds_tf1x[kd] : tf1x[kd].f;
+          w *= skip ? 1.0f : fmaf(ab[i].x, x, ab[i].y);  // SplineMonolith.cpp:779
+        }
+      }
+    }
+  }
+
+  M3_STAMP(9);
+  // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
+  // belong to somebody else's events and must touch nothing
+  if (lane < bd.n_events) {
+    const uint64_t ev = ev_own;
+    if (MODE & kModeEval) a.spline_w[ev] = w;
+    if (MODE & (kModeFill | kModeEventW)) {
+      // CalcWeightTotal (SampleHandlerFD.cpp:568-594), as in k_reweight_uniform: norm pointers first (double -> float
+      // cast each), then total_weight_pointers = {osc, bin-spline weights, spline total weight}
+      float tw = 1.0f;
+#pragma unroll
+      for (int m = 0; m < kTailNorm; ++m)
+        if (t_ni[m] >= 0) tw *= static_cast<float>(t_nv[m]);
+      if (a.n_norm_slots > (uint32_t)kTailNorm) tw = mul_norm_weights(tw, a, ev, (uint32_t)kTailNorm);
+      if (t_osc >= 0) tw *= t_oscw;
       tw = mul_binned_weights(tw, a, ev);
-      tw *= w[q];
+      tw *= w;
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
         int b;
         if (DYN) {
-          b = e < bd.n_events ? d_event_bin(a.dyn, ev) : -1;
+          b = d_event_bin(a.dyn, ev);
           a.dyn.bin[ev] = b;
         } else {
-          b = a.bin[ev];
+          b = t_bin;
         }
-        if (e < bd.n_events && !(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
+        if (!(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
           if (a.hist_lds) {
             atomicAdd(&lds_hist[b], (double)tw);
             if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
@@ -730,6 +862,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   }
   if ((MODE & kModeFill) && a.hist_lds) {
     __syncthreads();
+    M3_STAMP(10);
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
     for (int i = lane; i < nb; i += kBrickThreads) {
@@ -738,12 +871,15 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       if (v != 0.0) atomicAdd(&a.hist[slot], v);
     }
   }
+  M3_STAMP(11);
 }
 
-template <int MODE>
+template <int MODE, bool DYN>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  if (k.nt) M3_LAUNCH((k_reweight_brick<MODE, true, kBrickBatchDefault>), g, dim3(kBrickThreads), lds, s, k, a);
-  else M3_LAUNCH((k_reweight_brick<MODE, false, kBrickBatchDefault>), g, dim3(kBrickThreads), lds, s, k, a);
+  const dim3 b(kBrickThreads);
+  if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true>), g, b, lds, s, k, a);
+  else if (k.nt || DYN) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false>), g, b, lds, s, k, a);
+  else M3_LAUNCH((k_reweight_brick<MODE, false, false, false>), g, b, lds, s, k, a);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
@@ -752,13 +888,13 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
   if (dyn_bins && (mode & kModeFill)) {
-    if (mode == kModeFill) M3_LAUNCH((k_reweight_brick<kModeFill, true, kBrickBatchDefault, true>), g, dim3(kBrickThreads), lds, s, k, a);
-    else M3_LAUNCH((k_reweight_brick<kModeFill | kModeEval | kModeEventW, true, kBrickBatchDefault, true>), g, dim3(kBrickThreads), lds, s, k, a);
+    if (mode == kModeFill) launch_brick_mode<kModeFill, true>(a, g, lds, k, s);
+    else launch_brick_mode<kModeFill | kModeEval | kModeEventW, true>(a, g, lds, k, s);
     return;
   }
-  if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
-  else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
-  else launch_brick_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
+  if (mode == kModeEval) launch_brick_mode<kModeEval, false>(a, g, lds, k, s);
+  else if (mode == kModeFill) launch_brick_mode<kModeFill, false>(a, g, lds, k, s);
+  else launch_brick_mode<kModeFill | kModeEval | kModeEventW, false>(a, g, lds, k, s);
 }
 
 // ------------------------------------------------------------------------------------

@@ -85,20 +85,24 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 
 // ------------------------------------------------------------------------------------
 // Brick metadata stream (uint32 words, offsets relative to the brick's first word):
-//   [0]                      n_stages
-//   [1 + 8*s .. 8 + 8*s]     stage header: kind (0 TSpline3, 1 TF1), n_resp, n_runs, off_runs,
-//                            off_resp, off_evt, coef_off, 0
-//   off_runs  (TSpline3)     n_runs x {coef_off (float4 from the brick's spline store), plane stride (n_run rounded up to 8 float4 = 128 B),
-//                            start_r (first response of the run in the stage), param}
-//   off_resp  TSpline3: n_resp words {run : 16 | dst << 16}; TF1: n_resp parameters packed two
-//             per word (low half first)
-//   off_evt   M3_EVT_WORDS words = M3_GROUP + 2 uint16, two per word (low half first): start[e] of the
-//             event's slice of the staging array; its length is start[e + 1] - start[e]; entries past
-//             the brick's last event repeat the total, so those events have empty slices
-//   coef_off  TF1 only: float2 index of the stage's first {a,b} in the brick's TF1 store
+//   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3..7] 0
+//   [8 + 4 s ..]  stage header: n_resp | n_runs << 16, off_runs, off_grp, off_resp
+//   off_runs  n_runs x {int32 coef_off - start_r, stride | param << 16}.  coef_off: float4 index of the run's first plane
+//             in the brick's spline store; start_r: first response of the run in the stage; so the quad of segment k of
+//             response r sits at entry[0] + k * stride + r.  stride = n_run rounded up to M3_PLANE_ALIGN.
+//   off_grp   per 64 responses one uint16, two per word: the run of the group's first response
+//   off_resp  n_resp uint16, two per word: event | rank << 10 | last response of the event in the stage << 14 |
+//             last response of its run << 15
+//   off_tf1   [0..15]   float2 index (from the brick's TF1 store) of the first slot of wave w (events 64 w .. 64 w + 63)
+//             [16..31]  word offset (from the brick's first word) of wave w's first code dword
+//             [32..32 + M3_GROUP / 4)  codes per event, uint8, four per word
+//             then the code dwords: per wave, per four rows 4 q .. 4 q + 3, one dword for every lane with more than 4 q
+//             codes (lanes packed, ascending), byte i = code of row 4 q + i.  A code is the step from the event's previous
+//             TF1 parameter to this one in the chunk's TF1 dictionary (first: from -1); M3_TF1_SKIP steps 254 without a response.
+//   TF1 store: per wave, per row j, one float2 {a,b} for every lane with more than j codes (lanes packed, ascending)
 // ------------------------------------------------------------------------------------
-bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_t e0, uint64_t e1, BrickHost* bh,
-                std::vector<uint32_t>* words_all, std::string* err) {
+bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const std::vector<int32_t>& dict_index, uint64_t e0,
+                uint64_t e1, BrickHost* bh, std::vector<uint32_t>* words_all, std::string* err) {
   const uint32_t ne = uint32_t(e1 - e0);
   bh->n_events = ne;
   bh->first_event = e0;
@@ -122,16 +126,14 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
       }
   }
 
-  // ---- inverted index: responses per parameter (counting sort keeps events ascending)
-  std::vector<uint32_t> cnt_s(n_params + 1, 0), cnt_t(n_params + 1, 0);
+  // ---- TSpline3: inverted index, responses per parameter (counting sort keeps events ascending)
+  std::vector<uint32_t> cnt_s(n_params + 1, 0);
   for (uint64_t e = e0; e < e1; ++e) {
     const unsigned int c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
     for (unsigned int i = 0; i < c; ++i) cnt_s[in.param_no[s0 + i] + 1]++;
-    const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
-    for (unsigned int i = 0; i < ct; ++i) cnt_t[in.param_no_tf1[t0 + i] + 1]++;
   }
-  for (int p = 0; p < n_params; ++p) { cnt_s[p + 1] += cnt_s[p]; cnt_t[p + 1] += cnt_t[p]; }
-  const uint32_t S = cnt_s[n_params], T = cnt_t[n_params];
+  for (int p = 0; p < n_params; ++p) cnt_s[p + 1] += cnt_s[p];
+  const uint32_t S = cnt_s[n_params];
   std::vector<uint32_t> inv_s(S), inv_ev(S);  // spline index / local event, parameter-major
   {
     std::vector<uint32_t> cur(cnt_s.begin(), cnt_s.end() - 1);
@@ -145,152 +147,194 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, uint64_
     }
   }
 
-  // ---- stage boundaries: ascending parameter ranges holding <= M3_BRICK_CAP responses
+  // ---- stages: ascending parameter ranges; <= M3_STAGE_CAP responses, <= M3_STAGE_MAX_RUNS runs, no event more than
+  // M3_ELL_ROWS times.  Stages of about equal size (a brick whose responses just exceed a multiple of the cap would
+  // otherwise end in a stage of a few responses that costs the same barriers as a full one).
   struct Range { int p0, p1; };
-  auto split = [&](const std::vector<uint32_t>& cnt) {
-    std::vector<Range> st;
+  std::vector<Range> st_s;
+  {
+    const uint32_t n_want = std::max<uint32_t>(1u, (S + uint32_t(M3_STAGE_CAP) - 1) / uint32_t(M3_STAGE_CAP));
+    const uint32_t soft = (S + n_want - 1) / n_want;
+    std::vector<uint8_t> mult(ne, 0);
     int p0 = 0;
     while (p0 < n_params) {
-      int p1 = p0;
+      std::fill(mult.begin(), mult.end(), uint8_t(0));
       uint32_t tot = 0, runs = 0;
-      while (p1 < n_params && tot + (cnt[p1 + 1] - cnt[p1]) <= uint32_t(M3_BRICK_CAP) && runs < uint32_t(M3_BRICK_MAX_RUNS)) {
-        tot += cnt[p1 + 1] - cnt[p1];
-        runs += (cnt[p1 + 1] != cnt[p1]);
+      int p1 = p0;
+      while (p1 < n_params) {
+        const uint32_t a = cnt_s[p1], b = cnt_s[p1 + 1], n_run = b - a;
+        if (n_run == 0) { ++p1; continue; }
+        if (tot > 0) {
+          bool fits = tot + n_run <= uint32_t(M3_STAGE_CAP) && runs < uint32_t(M3_STAGE_MAX_RUNS);
+          for (uint32_t r = a; fits && r < b; ++r) fits = mult[inv_ev[r]] < uint8_t(M3_ELL_ROWS);
+          if (!fits) break;
+        }
+        for (uint32_t r = a; r < b; ++r) mult[inv_ev[r]]++;
+        tot += n_run;
+        ++runs;
         ++p1;
+        if (tot >= soft) break;
       }
-      if (p1 == p0) ++p1;  // cannot happen: a run holds at most M3_GROUP <= M3_BRICK_CAP responses
-      if (tot > 0) st.push_back({p0, p1});
+      if (tot > 0) st_s.push_back({p0, p1});
       p0 = p1;
     }
-    return st;
-  };
-  const std::vector<Range> st_s = split(cnt_s), st_t = split(cnt_t);
-  const uint32_t n_stages = uint32_t(st_s.size() + st_t.size());
+  }
+  const uint32_t n_stages = uint32_t(st_s.size());
   if (n_stages > uint32_t(M3_BRICK_MAX_STAGES)) {
     *err = "brick: " + std::to_string(n_stages) + " stages exceed the supported " + std::to_string(M3_BRICK_MAX_STAGES) +
-           " (more than ~245k responses in 1024 events)";
+           " (more than ~250k TSpline3 responses in 1024 events)";
     return false;
   }
-  w.assign(1 + size_t(M3_STAGE_HDR) * n_stages, 0u);
+  bh->n_stages = n_stages;
+  w.assign(size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * n_stages, 0u);
   w[0] = n_stages;
 
+  auto push_u16 = [&](const std::vector<uint16_t>& v) {  // two per word, low half first
+    for (size_t i = 0; i < v.size(); i += 2) w.push_back(uint32_t(v[i]) | (uint32_t(i + 1 < v.size() ? v[i + 1] : 0) << 16));
+  };
   uint64_t spl_f4 = 0;
   bh->spl_src.clear();
   bh->spl_src.reserve(S);
-  uint32_t stage = 0;
-  std::vector<uint32_t> ev_cnt(ne), ev_start(ne), ev_cur(ne);
-  // the stage's slice starts as uint16 (a stage holds <= 8192 responses), padded with the total
-  auto push_evt = [&](std::vector<uint32_t>& out, const std::vector<uint32_t>& start, uint32_t total) {
-    for (uint32_t i = 0; i < uint32_t(M3_EVT_WORDS); ++i) {
-      const uint32_t e_lo = 2 * i, e_hi = 2 * i + 1;
-      const uint32_t lo = e_lo < ne ? start[e_lo] : total, hi = e_hi < ne ? start[e_hi] : total;
-      out.push_back((lo & 0xFFFFu) | (hi << 16));
-    }
-  };
-  for (const Range& rg : st_s) {
+  std::vector<uint8_t> rank_of(ne);
+  std::vector<int32_t> last_of(ne);
+  for (uint32_t stage = 0; stage < n_stages; ++stage) {
+    const Range& rg = st_s[stage];
     const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
-    // event-major staging slots
-    std::fill(ev_cnt.begin(), ev_cnt.end(), 0u);
-    for (uint32_t r = r0; r < r1; ++r) ev_cnt[inv_ev[r]]++;
-    uint32_t acc = 0;
-    for (uint32_t e = 0; e < ne; ++e) { ev_start[e] = acc; acc += ev_cnt[e]; ev_cur[e] = ev_start[e]; }
-    // runs
-    std::vector<uint32_t> runs, resp(n_resp);
+    std::fill(rank_of.begin(), rank_of.end(), uint8_t(0));
+    std::fill(last_of.begin(), last_of.end(), -1);
+    std::vector<uint32_t> runs;
+    std::vector<uint16_t> resp(n_resp), grp((n_resp + 63) / 64);
     uint32_t n_runs = 0;
     for (int p = rg.p0; p < rg.p1; ++p) {
       const uint32_t a = cnt_s[p], b = cnt_s[p + 1];
       if (a == b) continue;
       const uint32_t n_run = b - a, nseg = uint32_t(npts[p] - 1);
-      if (n_runs >= 65536u) { *err = "brick: more than 65536 runs in a stage"; return false; }
-      // every segment plane of a run starts on a 128-byte line: a step reads ONE plane per run, so an
-      // unaligned plane would drag in the neighbouring planes' lines at both ends
-      const uint32_t stride = (n_run + 7u) & ~7u;
-      runs.push_back(uint32_t(spl_f4));
-      runs.push_back(stride);
-      runs.push_back(a - r0);
-      runs.push_back(uint32_t(p));
+      // every segment plane of a run starts on a 128-byte line: a step reads ONE plane per run, and the memory side
+      // fetches whole lines, so an unaligned plane would drag in the neighbouring planes' lines at both ends
+      const uint32_t stride = (n_run + uint32_t(M3_PLANE_ALIGN) - 1) & ~uint32_t(M3_PLANE_ALIGN - 1);
+      if (spl_f4 + uint64_t(stride) * nseg > 0x7FFFFFFFull) { *err = "brick: spline store exceeds 2^31 quads"; return false; }
+      runs.push_back(uint32_t(int32_t(spl_f4) - int32_t(a - r0)));
+      runs.push_back(stride | (uint32_t(p) << 16));
       for (uint32_t r = a; r < b; ++r) {
-        const uint32_t dst = ev_cur[inv_ev[r]]++;  // parameters ascend, so slots fill in product order
-        resp[r - r0] = (n_runs & 0xFFFFu) | (dst << 16);
+        const uint32_t ev = inv_ev[r], i = r - r0;
+        if (i % 64 == 0) grp[i / 64] = uint16_t(n_runs);
+        resp[i] = uint16_t(ev | (uint32_t(rank_of[ev]++) << 10));
+        last_of[ev] = int32_t(i);
         bh->spl_src.push_back(inv_s[r]);
       }
+      resp[b - 1 - r0] |= uint16_t(0x8000u);  // last response of its run
       spl_f4 += uint64_t(stride) * nseg;
       ++n_runs;
     }
-    uint32_t* h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[0] = 0; h[1] = n_resp; h[2] = n_runs;
-    h[3] = uint32_t(w.size());
+    for (uint32_t ev = 0; ev < ne; ++ev)
+      if (last_of[ev] >= 0) resp[size_t(last_of[ev])] |= uint16_t(0x4000u);  // last response of its event in the stage
+    if (w.size() & 1) w.push_back(0u);  // run entries are read as 8-byte pairs
+    const uint32_t off_runs = uint32_t(w.size());
     w.insert(w.end(), runs.begin(), runs.end());
-    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[4] = uint32_t(w.size());
-    w.insert(w.end(), resp.begin(), resp.end());
-    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[5] = uint32_t(w.size());
-    push_evt(w, ev_start, n_resp);
-    ++stage;
+    const uint32_t off_grp = uint32_t(w.size());
+    push_u16(grp);
+    const uint32_t off_resp = uint32_t(w.size());
+    push_u16(resp);
+    uint32_t* h = &w[size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * stage];
+    h[0] = n_resp | (n_runs << 16);
+    h[1] = off_runs;
+    h[2] = off_grp;
+    h[3] = off_resp;
   }
   bh->n_spl_f4 = spl_f4;
 
-  // TF1 stages: responses event-major inside the stage, so the staging slot is the response index
-  uint64_t tf1_f2 = 0;
+  // ---- TF1: jagged rows per wave of 64 events, one code byte per response
   bh->tf1_src.clear();
-  bh->tf1_src.reserve(T);
-  for (const Range& rg : st_t) {
-    std::vector<uint32_t> params;
-    std::fill(ev_cnt.begin(), ev_cnt.end(), 0u);
-    for (uint64_t e = e0; e < e1; ++e) {
-      const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
-      for (unsigned int i = 0; i < ct; ++i) {
-        const int p = in.param_no_tf1[t0 + i];
-        if (p >= rg.p0 && p < rg.p1) {
-          params.push_back(uint32_t(p));
-          bh->tf1_src.push_back(t0 + i);
-          ev_cnt[e - e0]++;
-        }
+  std::vector<std::vector<uint8_t>> codes(ne);
+  std::vector<std::vector<uint32_t>> srcs(ne);
+  for (uint32_t le = 0; le < ne; ++le) {
+    const uint64_t e = e0 + le;
+    const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+    int32_t prev = -1;
+    for (unsigned int i = 0; i < ct; ++i) {
+      const int32_t k = dict_index[size_t(in.param_no_tf1[t0 + i])];
+      int32_t gap = k - prev;  // >= 1: parameters ascend and the dictionary is ascending
+      while (gap > 254) {
+        codes[le].push_back(uint8_t(M3_TF1_SKIP));
+        srcs[le].push_back(0xFFFFFFFFu);
+        gap -= 254;
       }
+      codes[le].push_back(uint8_t(gap));
+      srcs[le].push_back(t0 + i);
+      prev = k;
     }
-    const uint32_t n_resp = uint32_t(params.size());
-    uint32_t acc = 0;
-    for (uint32_t e = 0; e < ne; ++e) { ev_start[e] = acc; acc += ev_cnt[e]; }
-    uint32_t* h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[0] = 1; h[1] = n_resp; h[2] = 0; h[3] = 0;
-    h[4] = uint32_t(w.size());
-    for (uint32_t i = 0; i < n_resp; i += 2) w.push_back(params[i] | ((i + 1 < n_resp ? params[i + 1] : 0u) << 16));
-    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[5] = uint32_t(w.size());
-    push_evt(w, ev_start, n_resp);
-    h = &w[1 + size_t(M3_STAGE_HDR) * stage];
-    h[6] = uint32_t(tf1_f2);
-    tf1_f2 += n_resp;
-    ++stage;
+    if (codes[le].size() > size_t(M3_TF1_MAX_CODES)) {
+      *err = "event " + std::to_string(e) + ": more than " + std::to_string(M3_TF1_MAX_CODES) + " TF1 responses in a ragged event";
+      return false;
+    }
   }
+  const uint32_t off_tf1 = uint32_t(w.size());
+  w[1] = off_tf1;
+  const uint32_t n_waves = uint32_t(M3_GROUP / M3_WAVE);
+  w.resize(w.size() + 2 * n_waves + size_t(M3_GROUP) / 4, 0u);
+  for (uint32_t le = 0; le < ne; ++le) w[off_tf1 + 2 * n_waves + le / 4] |= uint32_t(codes[le].size()) << (8 * (le % 4));
+  uint64_t tf1_f2 = 0;
+  for (uint32_t wv = 0; wv < n_waves; ++wv) {
+    w[off_tf1 + wv] = uint32_t(tf1_f2);
+    w[off_tf1 + n_waves + wv] = uint32_t(w.size());
+    const uint32_t l0 = wv * uint32_t(M3_WAVE), l1 = std::min(ne, l0 + uint32_t(M3_WAVE));
+    size_t rows = 0;
+    for (uint32_t le = l0; le < l1; ++le) rows = std::max(rows, codes[le].size());
+    for (size_t j = 0; j < rows; ++j)
+      for (uint32_t le = l0; le < l1; ++le)
+        if (codes[le].size() > j) { bh->tf1_src.push_back(srcs[le][j]); ++tf1_f2; }
+    for (size_t q = 0; 4 * q < rows; ++q)
+      for (uint32_t le = l0; le < l1; ++le)
+        if (codes[le].size() > 4 * q) {
+          uint32_t d = 0;
+          for (size_t i = 0; i < 4 && 4 * q + i < codes[le].size(); ++i) d |= uint32_t(codes[le][4 * q + i]) << (8 * i);
+          w.push_back(d);
+        }
+  }
+  w[2] = uint32_t(tf1_f2);
   bh->n_tf1_f2 = tf1_f2;
+  while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);  // the next brick's stream starts on a line
   bh->n_words = w.size();
   words_all->insert(words_all->end(), w.begin(), w.end());
   return true;
 }
 
-// copies a brick's coefficients: TSpline3 runs become [segment][event-in-run] planes
+// copies a brick's coefficients: TSpline3 runs become [segment][event-in-run] planes, TF1 responses jagged rows
 void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, const uint32_t* words, float* spl, float* tf1) {
   float* bs = spl + 4 * bh.spl_off;
   float* bt = tf1 + 2 * bh.tf1_off;
   const uint32_t n_stages = words[0];
   size_t src_i = 0;
   for (uint32_t s = 0; s < n_stages; ++s) {
-    const uint32_t* h = words + 1 + size_t(M3_STAGE_HDR) * s;
-    if (h[0] != 0) continue;
-    const uint32_t* runs = words + h[3];
-    for (uint32_t r = 0; r < h[2]; ++r) {
-      const uint32_t coef_off = runs[4 * r], stride = runs[4 * r + 1], p = runs[4 * r + 3];
-      const uint32_t n_run = (r + 1 < h[2] ? runs[4 * (r + 1) + 2] : h[1]) - runs[4 * r + 2];  // responses of the run
+    const uint32_t* h = words + size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * s;
+    const uint32_t n_resp = h[0] & 0xFFFFu, n_runs = h[0] >> 16;
+    const uint32_t* runs = words + h[1];
+    uint32_t start_r = 0;
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      const uint32_t stride = runs[2 * r + 1] & 0xFFFFu, p = runs[2 * r + 1] >> 16;
+      const uint64_t coef_off = uint64_t(int64_t(int32_t(runs[2 * r])) + int64_t(start_r));
+      // responses of the run: up to the next run's start (recovered from the entries: coef_off is cumulative)
       const uint32_t nseg = uint32_t(npts[p] - 1);
+      uint32_t n_run;
+      if (r + 1 < n_runs) {
+        // next.coef_off = coef_off + stride * nseg, next.entry = next.coef_off - next.start_r
+        const int64_t next_start = int64_t(coef_off) + int64_t(stride) * nseg - int64_t(int32_t(runs[2 * (r + 1)]));
+        n_run = uint32_t(next_start) - start_r;
+      } else {
+        n_run = n_resp - start_r;
+      }
+      for (uint32_t k = 0; k < nseg; ++k)  // the padding of every plane is defined (never used in a product)
+        std::memset(bs + (coef_off + uint64_t(k) * stride + n_run) * 4, 0, size_t(stride - n_run) * 16);
       for (uint32_t q = 0; q < n_run; ++q) {
         const float* src = in.coeff_many + 4ull * in.nknots_arr[bh.spl_src[src_i++]];
-        for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (uint64_t(coef_off) + uint64_t(k) * stride + q) * 4, src + 4 * k, 16);
+        for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (coef_off + uint64_t(k) * stride + q) * 4, src + 4 * k, 16);
       }
+      start_r += n_run;
     }
   }
-  for (size_t i = 0; i < bh.tf1_src.size(); ++i) std::memcpy(bt + 2 * i, in.coeff_tf1 + 2ull * bh.tf1_src[i], 8);
+  static const float kIdentityTf1[2] = {0.f, 1.f};
+  for (size_t i = 0; i < bh.tf1_src.size(); ++i)
+    std::memcpy(bt + 2 * i, bh.tf1_src[i] == 0xFFFFFFFFu ? kIdentityTf1 : in.coeff_tf1 + 2ull * bh.tf1_src[i], 8);
 }
 
 }  // namespace
@@ -374,10 +418,29 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
     }
     t0 = t1;
   }
+  // the dictionary the bricks' TF1 codes step through: every parameter with a TF1 response in a brick of this chunk
+  plan->tf1_dict.clear();
+  plan->dict_off = 0;
+  std::vector<int32_t> dict_index(size_t(n_params), -1);
+  if (!jobs.empty()) {
+    std::vector<uint8_t> seen(size_t(n_params), 0);
+    for (const BrickJob& job : jobs) {
+      const uint64_t e0 = job.t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, job.t1 * M3_TE);
+      for (uint64_t e = e0; e < e1; ++e) {
+        const unsigned int ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+        for (unsigned int i = 0; i < ct; ++i) seen[size_t(in.param_no_tf1[t0 + i])] = 1;
+      }
+    }
+    for (int p = 0; p < n_params; ++p)
+      if (seen[size_t(p)]) {
+        dict_index[size_t(p)] = int32_t(plan->tf1_dict.size());
+        plan->tf1_dict.push_back(uint16_t(p));
+      }
+  }
   parallel_for(jobs.size(), [&](uint64_t j) {
     BrickJob& job = jobs[j];
     const uint64_t e0 = job.t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, job.t1 * M3_TE);
-    job.ok = plan_brick(n_params, npts, in, e0, e1, &job.bh, &job.words, &job.err);
+    job.ok = plan_brick(n_params, npts, in, dict_index, e0, e1, &job.bh, &job.words, &job.err);
   });
   for (const BrickJob& job : jobs)
     if (!job.ok) { *err = job.err; return false; }  // the first failing brick in event order
@@ -433,6 +496,9 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
     }
     t0 = t1;
   }
+  plan->dict_off = plan->brick_words.size();
+  for (size_t i = 0; i < plan->tf1_dict.size(); i += 2)
+    plan->brick_words.push_back(uint32_t(plan->tf1_dict[i]) | (uint32_t(i + 1 < plan->tf1_dict.size() ? plan->tf1_dict[i + 1] : 0) << 16));
   return true;
 }
 

@@ -15,16 +15,22 @@
 //       wavefront's 64 loads are one 1 KB line-aligned burst.  TF1: tf1[j * M3_TE + lane]
 //       float2 {a,b}.  Lane = event inside the tile; the per-event product runs over j in
 //       the reference's order (splines in event order, then TF1s).
-//   BRICK (ragged parameter lists; one per M3_GROUP = 1024 consecutive events in which the
-//   lists differ): a per-brick CSC.  Responses are regrouped by PARAMETER so that the quads
-//   a step needs for (parameter p, segment seg[p]) are again contiguous:
+//   BRICK (ragged parameter lists; one per M3_GROUP = 1024 consecutive events in which the lists differ).
+//   TSpline3 responses: a per-brick CSC.  They are regrouped by PARAMETER so that the quads a step needs for
+//   (parameter p, segment seg[p]) are again contiguous:
 //       run (p) = the n_run events of the brick that carry p, ascending event order;
-//       spl[coef_off(p) + k * n_run + q]   float4 of segment k for the q-th event of the run
-//   Runs are packed into STAGES of <= M3_BRICK_CAP responses (ascending parameter ranges).  A
-//   stage's weights are evaluated lane-per-response (coalesced), scattered into an LDS staging
-//   array at their EVENT-major position `dst`, and then multiplied per event in ascending
-//   parameter order -- the reference's order, so the float product is bit-identical.  TF1
-//   responses have no segment and are stored event-major per stage (dst = index).
+//       spl[coef_off(p) + k * stride + q]   float4 of segment k for the q-th event of the run
+//       (stride = n_run rounded up to 8 quads: every plane starts on a 128-B line, the unit the memory side fetches --
+//       tools/sector_fetch.hip: a line costs the same whether 16 or 128 of its bytes are used).
+//   Runs are packed into STAGES (ascending parameter ranges) of <= M3_STAGE_CAP responses in which no event holds more
+//   than M3_ELL_ROWS responses.  A stage's weights are evaluated lane-per-response (coalesced) and scattered into an LDS
+//   array ell[rank][event], rank = index of the response among its event's responses of the stage; the event's lane then
+//   multiplies ell[0..n)[event] -- ascending parameter order, the reference's order, so the float product is
+//   bit-identical.  Per response: ONE uint16 {event:10 | rank:4 | last-of-its-event-in-the-stage:1 | last-of-its-run:1}.
+//   TF1 responses have no segment -- every step reads all of them -- so they need no regrouping: they are stored
+//   event-major per WAVE of 64 events as jagged rows (row j = the j-th TF1 of each event that has one, lanes packed),
+//   read lane-per-event straight into the register product.  Per response: ONE byte, the step from the previous
+//   parameter of the event in the chunk's dictionary of TF1 parameters (255: step 254 and no response).
 //   Per-brick metadata is a uint32 word stream (layout in m3hip_layout.cpp).
 #pragma once
 #include <cstddef>
@@ -36,12 +42,18 @@ namespace m3hip {
 
 constexpr int M3_TE = 256;       // events per tile (= workgroup size of the reweight kernels)
 constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
-constexpr int M3_BRICK_CAP = 8192;  // responses per brick stage (= floats of LDS staging)
-constexpr int M3_BRICK_MAX_RUNS = 1024;  // runs per stage (resolved run table lives in LDS)
-constexpr int M3_BRICK_MAX_STAGES = 30;  // stage headers are staged in LDS
-constexpr int M3_STAGE_HDR = 8;     // words per stage header
-constexpr int M3_EVT_WORDS = M3_GROUP / 2 + 1;  // per stage: M3_GROUP + 2 uint16 slice starts, two per word
-constexpr int M3_RUN_WORDS = 4;     // words per run entry
+constexpr int M3_STAGE_CAP = 5120;       // TSpline3 responses per brick stage (5 per lane of the 1024-lane workgroup)
+constexpr int M3_STAGE_MAX_RUNS = 512;   // runs per stage (the resolved run table lives in LDS)
+constexpr int M3_ELL_ROWS = 12;          // responses one event may hold in a stage (rows of the LDS scatter array)
+constexpr int M3_BRICK_MAX_STAGES = 62;  // stage headers are staged in LDS
+constexpr int M3_BRICK_HDR0 = 8;         // words in front of the stage headers
+constexpr int M3_STAGE_HDR = 4;          // words per stage header
+constexpr int M3_RUN_WORDS = 2;          // words per run entry
+constexpr int M3_PLANE_ALIGN = 8;        // quads: segment planes of a run start on 128-B lines
+constexpr int M3_WAVE = 64;              // events per jagged TF1 block
+constexpr int M3_TF1_MAX_CODES = 255;    // TF1 codes (responses + skips) per event
+constexpr int M3_TF1_SKIP = 255;         // code: advance 254 dictionary entries, no response
+constexpr int M3_BRICK_ALIGN_WORDS = 32; // every brick's stream starts on a 128-B line
 
 enum TileKind : uint32_t { kTileUniform = 0, kTileBrick = 1 };
 
@@ -73,7 +85,8 @@ struct BrickHost {
   uint64_t first_event = 0;  // chunk-local
   // fill-time copy lists: source spline / TF1 index of every response, in store order
   std::vector<uint32_t> spl_src;   // per spline response (run-major): index into the chunk's spline arrays
-  std::vector<uint32_t> tf1_src;   // per TF1 response (stage-major, event-major inside)
+  std::vector<uint32_t> tf1_src;   // per TF1 slot (wave-major, jagged rows inside); 0xFFFFFFFF: skip slot -> identity {0,1}
+  uint32_t n_stages = 0;           // TSpline3 stages
 };
 
 struct ChunkInput {
@@ -97,7 +110,11 @@ struct ChunkPlan {
   uint64_t meta_int32 = 0;  // size of the slot-meta store
   uint64_t n_uniform = 0, n_brick = 0;
   std::vector<BrickHost> bricks;
-  std::vector<uint32_t> brick_words;  // metadata streams of all bricks, concatenated
+  std::vector<uint32_t> brick_words;  // metadata streams of all bricks, concatenated; then the TF1 dictionary
+  // ascending list of the parameters that carry a TF1 response somewhere in the chunk's bricks; the bricks' TF1 codes
+  // step through it.  Stored behind the streams in brick_words, two uint16 per word, from word dict_off on.
+  std::vector<uint16_t> tf1_dict;
+  uint64_t dict_off = 0;
   std::vector<int16_t> tile_params;   // slot lists of all uniform tiles, concatenated (TileHost::list_off)
   uint64_t n_padded = 0, pad_spl = 0, pad_tf1 = 0;  // padded tiles and the identity responses they add
 };

@@ -1,0 +1,45 @@
+"""Where a brick's workgroup spends its time: phase stamps of the diagnostic build (`make stamps`,
+build/libm3hip_stamps.so, loaded through M3HIP_LIB).  Prints the mean / median time of every phase over all
+bricks of one launch.  Shares of a diagnostic build, not a timing of the product.
+usage: M3HIP_LIB=build/libm3hip_stamps.so python scripts/brick_stamps.py [events] [config]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from mach3_amd import synth
+from mach3_amd.engine import build_from_synth
+
+ev = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
+spec = synth.CONFIGS[cfg].scaled(ev)
+eng, mono, sh, par = build_from_synth(spec)
+sh.Reweight()
+sh.AddData(sh.GetMCArray())
+for i in range(10):
+    par[:] = synth.params(spec, i + 1)
+    sh.Step()
+eng.sync()
+nb = int(eng.info().n_tiles_brick)
+n = min(nb, 16384)
+buf = np.zeros(n * 16, np.uint64)
+rc = eng.lib.m3hip_debug_read_stamps(C.c_void_p(buf.ctypes.data), C.c_uint64(buf.size))
+assert rc == 0, rc
+t = buf.reshape(n, 16).astype(np.int64)
+names = {1: "prologue: round trip 1 + barrier", 2: "stage 0 tables + barrier", 3: "stage 0", 4: "stage 1", 5: "stage 2", 6: "stage 3",
+         8: "last stage", 9: "TF1 rows", 10: "event tail (norm, osc, bin, LDS fill) + barrier", 11: "flush of the bin vector"}
+prev = 0
+tot = (t[:, 11] - t[:, 0]) / 100.0
+print(f"{cfg} E={ev}: {nb} bricks; brick lifetime mean {tot.mean():.1f} us, median {np.median(tot):.1f} us")
+for k in sorted(names):
+    ok = t[:, k] > 0
+    d = (t[ok, k] - t[ok, prev]) / 100.0
+    if ok.any():
+        print(f"  {names[k]:55s} mean {d.mean():6.2f} us  median {np.median(d):6.2f} us  ({100 * d.mean() / tot.mean():4.1f} %)")
+    prev = k
+first, last = t[:, 0].min(), t[:, 11].max()
+print(f"  launch span {((last - first) / 100.0):.1f} us; bricks in flight on average {tot.sum() / ((last - first) / 100.0):.0f}")
+eng.close()

@@ -76,7 +76,7 @@ def make_monolith(n_params, max_knots, knots_per_param, events):
 def debug_layout(n_params, max_knots, npts, ch):
     """Run the engine's host-side re-layout only.  Returns (rc, err, dict of stores)."""
     lib = capi.load_m3hip()
-    sizes = np.zeros(6, np.uint64)
+    sizes = np.zeros(8, np.uint64)
     args = [n_params, max_knots, capi._ptr(npts, np.int16), ch["n_events"], capi._ptr(ch["coeff_many"], np.float32),
             ch["total_nknots"], capi._ptr(ch["nknots_arr"], np.uint32), capi._ptr(ch["param_no"], np.int16),
             ch["n_splines"], capi._ptr(ch["coeff_tf1"], np.float32), capi._ptr(ch["param_no_tf1"], np.int16),
@@ -84,7 +84,7 @@ def debug_layout(n_params, max_knots, npts, ch):
     rc = lib.m3hip_debug_layout(*args, sizes.ctypes.data, None, None, None, None, None, None)
     if rc != 0:
         return rc, lib.m3hip_last_error(None).decode(), None
-    nt, ns, ntf, nm, nbr, nw = [int(v) for v in sizes]
+    nt, ns, ntf, nm, nbr, nw, dict_off, n_dict = [int(v) for v in sizes]
     spl = np.zeros(max(1, ns) * 4, np.float32)
     tf1 = np.zeros(max(1, ntf) * 2, np.float32)
     meta = np.zeros(max(1, nm), np.int32)
@@ -94,7 +94,8 @@ def debug_layout(n_params, max_knots, npts, ch):
     rc = lib.m3hip_debug_layout(*args, sizes.ctypes.data, spl.ctypes.data, tf1.ctypes.data, meta.ctypes.data,
                                 desc.ctypes.data, bdesc.ctypes.data, words.ctypes.data)
     return rc, "", dict(n_tiles=nt, spl=spl.reshape(-1, 4), tf1=tf1.reshape(-1, 2), meta=meta, desc=desc[:nt],
-                        n_bricks=nbr, bdesc=bdesc[:nbr], words=words[:nw])
+                        n_bricks=nbr, bdesc=bdesc[:nbr], words=words[:nw],
+                        tf1_dict=words[dict_off:nw].view(np.uint16)[:n_dict])
 
 
 def make_binned(n_params, n_cells, rng, max_knots=7, flat_frac=0.2, negative_frac=0.1, float_t=np.float32):

@@ -746,14 +746,14 @@ def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkey
 
 
 def test_brick_stage_limit_is_reported(fresh_engine):
-    """more responses in a sparse 1024-event group than 30 stages hold: the upload is refused with a message,
-    nothing is silently truncated"""
+    """more responses in a sparse 1024-event group than the 62 stage headers hold: the upload is refused with a
+    message, nothing is silently truncated"""
     rng = np.random.default_rng(9)
-    P = 480
+    P = 640
     X3 = np.array([-1.0, 0, 1])
     xs = {p: X3 for p in range(P)}
     events = _ragged_events(rng, 1024, P, 0.6, xs)
-    assert sum(len(e) for e in events) > 260_000
+    assert sum(len(e) for e in events) > 62 * 5120
     cx, npts, ch = make_monolith(P, 3, xs, events)
     with pytest.raises(capi.M3HipError, match="stages"):
         SMonolith(fresh_engine, P, 3, cx, npts, [ch])

@@ -124,41 +124,90 @@ def test_layout_rejects_inconsistent_input():
     assert rc != 0 and "knot count" in err
 
 
+ELL_ROWS, STAGE_CAP, STAGE_MAX_RUNS, HDR0, TF1_SKIP = 12, 5120, 512, 8, 255
+
+
 def brick_event_lists(npts, ch, lay, b):
-    """Replay a brick's metadata stream on the CPU with coefficient quads instead of weights:
-    returns, per event of the brick, the ordered list of (param, kind, coefficients) the kernel
-    would multiply -- phase A scatter to `dst`, phase B read-back per event."""
-    spl, tf1, words = lay["spl"], lay["tf1"], lay["words"]
+    """Replay a brick's metadata stream on the CPU with coefficient quads instead of weights, the way
+    k_reweight_brick walks it: returns, per event of the brick, the ordered list of (param, kind,
+    coefficients) the kernel would multiply.  TSpline3 stages: phase A scatters response r to
+    ell[rank][event], phase B reads the event's column; TF1: the wave's jagged rows, lane per event."""
+    spl, tf1, words, tdict = lay["spl"], lay["tf1"], lay["words"], lay["tf1_dict"]
     spl_off, tf1_off, w_off, n_f4, n_f2, nev, e0, nw = [int(v) for v in lay["bdesc"][b]]
+    assert w_off % 32 == 0 and nw % 32 == 0            # every brick's stream starts on a 128-byte line
     w = words[w_off: w_off + nw]
     out = [[] for _ in range(nev)]
-    for s in range(int(w[0])):
-        h = w[1 + 8 * s: 9 + 8 * s]
-        kind, n_resp, n_runs = int(h[0]), int(h[1]), int(h[2])
-        stage = [None] * n_resp
-        if kind == 0:
-            runs = w[int(h[3]): int(h[3]) + 4 * n_runs].reshape(-1, 4)
-            resp = w[int(h[4]): int(h[4]) + n_resp]
-            for r in range(n_resp):
-                run, dst = int(resp[r]) & 0xFFFF, int(resp[r]) >> 16
-                coef_off, stride, start_r, p = [int(v) for v in runs[run]]
-                n_run = (int(runs[run + 1][2]) if run + 1 < n_runs else n_resp) - start_r
-                assert stride % 8 == 0 and coef_off % 8 == 0 and n_run <= stride < n_run + 8
-                q = r - start_r
-                assert 0 <= q < n_run
-                nseg = int(npts[p]) - 1
-                quads = np.stack([spl[spl_off + coef_off + k * stride + q] for k in range(nseg)])
-                assert stage[dst] is None
-                stage[dst] = (p, "spl", quads)
-        else:
-            par = w[int(h[4]): int(h[4]) + (n_resp + 1) // 2].view(np.uint16)[:n_resp]
-            for r in range(n_resp):
-                stage[r] = (int(par[r]), "tf1", tf1[tf1_off + int(h[6]) + r])
-        starts = w[int(h[5]): int(h[5]) + 1024 // 2 + 1].view(np.uint16)
-        assert len(starts) == 1026 and all(int(v) == n_resp for v in starts[nev:])
+    n_stages, off_tf1 = int(w[0]), int(w[1])
+    used = np.zeros(max(1, n_f4), bool)
+    for s in range(n_stages):
+        h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
+        n_resp, n_runs = h0 & 0xFFFF, h0 >> 16
+        assert 0 < n_resp <= STAGE_CAP and 0 < n_runs <= STAGE_MAX_RUNS and off_runs % 2 == 0
+        runs = w[off_runs: off_runs + 2 * n_runs].reshape(-1, 2)
+        grp = w[off_grp: off_grp + ((n_resp + 63) // 64 + 1) // 2].view(np.uint16)
+        resp = w[off_resp: off_resp + (n_resp + 1) // 2].view(np.uint16)[:n_resp]
+        ell = {}
+        cnt = {}
+        run, prev_param = -1, -1
+        for r in range(n_resp):
+            if r % 64 == 0:
+                run = int(grp[r // 64])                  # the kernel: run of the group's first response ...
+            wd = int(resp[r])
+            ev, rk, last_ev, last_run = wd & 0x3FF, (wd >> 10) & 0xF, (wd >> 14) & 1, wd >> 15
+            assert ev < nev and rk < ELL_ROWS
+            base = int(np.int32(runs[run][0]))
+            stride, p = int(runs[run][1]) & 0xFFFF, int(runs[run][1]) >> 16
+            assert stride % 8 == 0
+            nseg = int(npts[p]) - 1
+            idx = [base + k * stride + r for k in range(nseg)]
+            assert all(0 <= i < n_f4 for i in idx) and not used[idx].any()
+            used[idx] = True
+            assert (rk, ev) not in ell
+            ell[(rk, ev)] = (p, "spl", np.stack([spl[spl_off + i] for i in idx]))
+            if last_ev:
+                assert ev not in cnt
+                cnt[ev] = rk + 1
+            run += last_run                              # ... + the runs that ended before this response
+        assert run == n_runs                             # the last response closes the last run
         for e in range(nev):
-            out[e] += stage[int(starts[e]): int(starts[e + 1])]
-        assert all(x is not None for x in stage)
+            col = [ell.pop((j, e)) for j in range(cnt.get(e, 0))]
+            assert [x[0] for x in col] == sorted(x[0] for x in col)
+            out[e] += col
+        assert not ell                                   # every scattered weight is consumed by its event
+        # planes start on 128-byte lines (start_r of a run = index of its first response, recovered from the words)
+        ends = np.flatnonzero(resp >> 15) + 1
+        first_r = np.concatenate([[0], ends[:-1]])
+        for rn in range(n_runs):
+            assert (int(np.int32(runs[rn][0])) + int(first_r[rn])) % 8 == 0
+    # TF1: jagged rows per wave of 64 events
+    hdr = w[off_tf1: off_tf1 + 32 + 256]
+    cnts = hdr[32:].view(np.uint8)
+    assert all(int(c) == 0 for c in cnts[nev:])
+    slots = 0
+    for wv in range(16):
+        cbase, dbase = int(hdr[wv]), int(hdr[16 + wv])
+        lanes = [le for le in range(64 * wv, min(nev, 64 * wv + 64))]
+        kd = {le: -1 for le in lanes}
+        rows = max([int(cnts[le]) for le in lanes], default=0)
+        for j in range(rows):
+            act = [le for le in lanes if int(cnts[le]) > j]
+            if j % 4 == 0:
+                actq = act
+                codes = {le: int(w[dbase + i]) for i, le in enumerate(actq)}
+                dbase += len(actq)
+            for i, le in enumerate(act):
+                cd = (codes[le] >> (8 * (j % 4))) & 0xFF
+                ab = tf1[tf1_off + cbase + i]
+                if cd == TF1_SKIP:
+                    kd[le] += 254
+                    assert np.array_equal(ab, np.array([0, 1], np.float32))
+                else:
+                    assert cd > 0
+                    kd[le] += cd
+                    out[le].append((int(tdict[kd[le]]), "tf1", ab))
+            cbase += len(act)
+            slots += len(act)
+    assert slots == int(w[2]) == n_f2
     return e0, out
 
 
@@ -200,7 +249,7 @@ def test_ragged_brick_layout(n_events, cfg):
 
 
 def test_more_runs_than_a_stage_holds():
-    """2 600 parameters in 1 400 sparse events: a brick sees more than 1 024 distinct spline parameters, so its
+    """2 600 parameters in 1 400 sparse events: a brick sees more than 512 distinct spline parameters, so its
     TSpline3 stages are cut by run count (the resolved run table of a stage lives in LDS), not by responses."""
     rng = np.random.default_rng(5)
     X3, X5 = np.array([-1.0, 0, 1]), np.array([-2.0, -1, 0, 1, 2])
@@ -210,7 +259,7 @@ def test_more_runs_than_a_stage_holds():
     for _ in range(1400):
         ev = []
         for p in range(P):
-            if rng.random() < 0.012:
+            if rng.random() < 0.006:
                 ev.append((p, "spl", natural_cubic(xs[p], 1 + 0.1 * rng.standard_normal(len(xs[p])))) if p in xs
                           else (p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
         events.append(ev)
@@ -220,17 +269,17 @@ def test_more_runs_than_a_stage_holds():
     assert lay["n_bricks"] == 2 and lay["n_tiles"] == 0
     w = lay["words"]
     w0 = int(lay["bdesc"][0][2])
-    stages = [w[w0 + 1 + 8 * s: w0 + 9 + 8 * s] for s in range(int(w[w0]))]
-    spl_stages = [h for h in stages if int(h[0]) == 0]
-    assert len(spl_stages) >= 2 and all(int(h[2]) <= 1024 for h in spl_stages) and sum(int(h[2]) for h in spl_stages) > 1024
-    assert all(int(h[1]) < 8192 for h in spl_stages)        # none of them is full: the run count made the cut
+    stages = [int(w[w0 + HDR0 + 4 * s]) for s in range(int(w[w0]))]      # n_resp | n_runs << 16
+    assert len(stages) >= 3 and all(h >> 16 <= STAGE_MAX_RUNS for h in stages) and sum(h >> 16 for h in stages) > 1024
+    assert sum(h >> 16 == STAGE_MAX_RUNS for h in stages) >= 2                # the run count made the cut
+    assert all(h & 0xFFFF < STAGE_CAP for h in stages)        # none of them is full
     check_bricks(npts, ch, lay)
 
 
 def test_mixed_uniform_and_ragged_groups():
     """A chunk whose first 1024 events are dense and whose tail is ragged: uniform tiles and a
-    brick side by side, stages split at the 8192-response cap."""
-    P = 12
+    brick side by side, stages split at the response cap."""
+    P = 24
     X7 = np.arange(-3.0, 4.0)
     rng = np.random.default_rng(7)
     quad = lambda: natural_cubic(X7, 1 + 0.1 * rng.standard_normal(7))
@@ -247,7 +296,7 @@ def test_mixed_uniform_and_ragged_groups():
     check_uniform_tiles(P, 7, npts, ch, lay)
     check_bricks(npts, ch, lay)
     w = lay["words"]
-    assert int(w[0]) >= 2  # ~7000 spline responses + TF1s: at least one TSpline3 and one TF1 stage
+    assert int(w[0]) == 2 and int(w[2]) > 3000  # ~7200 TSpline3 responses in two stages (equal halves), ~3600 TF1 slots
 
 
 def test_ragged_requires_ascending_parameters():
@@ -260,13 +309,13 @@ def test_ragged_requires_ascending_parameters():
 
 
 def test_brick_stage_limit_is_reported():
-    """more responses in a sparse 1024-event group than 30 stages of 8192 hold: refused with a message
+    """more responses in a sparse 1024-event group than the 62 stage headers hold: refused with a message
     (a group this full but denser than 70 % would be identity-padded into uniform tiles instead)"""
     rng = np.random.default_rng(9)
-    P, X3 = 480, np.array([-1.0, 0, 1])
+    P, X3 = 640, np.array([-1.0, 0, 1])
     c = natural_cubic(X3, [0.9, 1.0, 1.2])
     events = [[(p, "spl", c) for p in range(P) if rng.random() < 0.6] for _ in range(1024)]
-    assert sum(len(e) for e in events) > 260_000
+    assert sum(len(e) for e in events) > 62 * STAGE_CAP
     cx, npts, ch = make_monolith(P, 3, {p: X3 for p in range(P)}, events)
     rc, err, _ = debug_layout(P, 3, npts, ch)
     assert rc != 0 and "stages" in err
