@@ -660,12 +660,11 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   const std::vector<int32_t> h_meta(s_meta, s_meta + plan.meta_int32);
 
   Chunk c;
-  // + 256 B: idle lanes of the brick kernel read (and drop) one element at a row's first slot, which for the last row
-  // of the last brick may be the slot right behind the store
-  hipError_t e = hipMalloc(&c.d_spl, b_spl + 256);
-  if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 + 256);
+  // + slack: idle lanes of the brick kernel read (and drop) what lies behind the list they index (m3hip_layout.h)
+  hipError_t e = hipMalloc(&c.d_spl, b_spl + M3_STORE_SLACK_BYTES);
+  if (e == hipSuccess) e = hipMalloc(&c.d_tf1, b_tf1 + M3_STORE_SLACK_BYTES);
   const size_t b_words = plan.brick_words.size() * sizeof(uint32_t);
-  if (e == hipSuccess && b_words) e = hipMalloc((void**)&c.d_words, b_words + 256);
+  if (e == hipSuccess && b_words) e = hipMalloc((void**)&c.d_words, b_words + M3_STORE_SLACK_BYTES);
   if (e == hipSuccess && b_words) e = hipMemcpy(c.d_words, plan.brick_words.data(), b_words, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_spl) e = hipMemcpy(c.d_spl, s_spl, b_spl, hipMemcpyHostToDevice);
   if (e == hipSuccess && b_tf1) e = hipMemcpy(c.d_tf1, s_tf1, b_tf1, hipMemcpyHostToDevice);
@@ -743,7 +742,8 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     bd.off_tf1 = bw[1];
     for (int i = 0; i < 4; ++i) bd.st0[i] = bd.n_stages ? bw[M3_BRICK_HDR0 + i] : 0u;
     bd.n_dict = uint32_t(plan.tf1_dict.size());
-    bd.pad_[0] = bd.pad_[1] = bd.pad_[2] = 0;
+    bd.spl_last_off = bh.n_spl_f4 ? uint32_t((bh.n_spl_f4 - 1) * 16) : 0u;
+    bd.pad_[0] = bd.pad_[1] = 0;
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;

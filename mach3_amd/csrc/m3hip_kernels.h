@@ -52,7 +52,8 @@ struct BrickDev {
   uint32_t off_tf1;           // word offset of the TF1 section
   uint32_t st0[4];            // copy of stage 0's header: its metadata is requested without waiting for the header
   uint32_t n_dict;
-  uint32_t pad_[3];
+  uint32_t spl_last_off;      // byte offset of the spline store's last quad (idle lanes' offsets are clamped to it)
+  uint32_t pad_[2];
 };
 
 // ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307

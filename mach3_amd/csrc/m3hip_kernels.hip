@@ -509,12 +509,19 @@ constexpr int kBrickThreads = 1024;                                // one event 
 constexpr int kBrickRPL = M3_STAGE_CAP / kBrickThreads;            // responses per lane and stage = coefficient loads in flight per lane
 constexpr int kBrickHdrWords = M3_BRICK_HDR0 + M3_STAGE_HDR * (M3_BRICK_MAX_STAGES + 2);  // + 2: look-ahead reads past the last stage see zeros
 constexpr int kBrickLdsParams = 1024;                              // per-step parameter table {segment, dx} kept in LDS up to this P
-constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 1, kBrickGrpSlots = M3_STAGE_CAP / 64;
-constexpr int kBrickTf1Batch = 16;                                 // TF1 rows in flight per lane (the registers the quads held)
+// a lane past a stage's end works on whatever word follows the stage's list; its run index can be off by up to 64 runs
+constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 64 + 1;
+constexpr int kBrickGrpPerWave = 8;                                // uint16 per wave and stage: one 16-byte LDS read
+constexpr int kBrickTf1Batch = 16;                                 // TF1 rows of the first batch (the registers the quads held)
+constexpr int kBrickTf1Next = 8;                                   // ... of the following ones
 static_assert(M3_STAGE_CAP % kBrickThreads == 0, "a stage is a whole number of responses per lane");
 static_assert(kBrickHdrWords <= kBrickThreads, "the stage headers are fetched by one load per lane");
 static_assert(M3_STAGE_MAX_RUNS <= kBrickThreads && M3_STAGE_CAP / 64 <= kBrickThreads, "run entries and group entries: one per lane");
 static_assert(M3_GROUP == kBrickThreads, "lane = event");
+static_assert(kBrickRPL <= kBrickGrpPerWave, "group entries of a wave");
+// Idle lanes do not branch around their loads (see the note in the kernel): they read a few KB past the list they index.
+// m3hip_api.hip allocates every chunk's stores with this much room behind them.
+static_assert(M3_STORE_SLACK_BYTES >= 2 * M3_STAGE_CAP + 8 * kBrickThreads, "room behind the stores for idle lanes' reads");
 
 // Diagnostic build only (-DM3_BRICK_STAMPS, `make stamps`): lane 0 of every brick records the 100 MHz wall clock at the
 // kernel's phase boundaries into a device array read back with m3hip_debug_read_stamps.  The production build carries
@@ -533,90 +540,109 @@ extern "C" int m3hip_debug_read_stamps(unsigned long long* out, unsigned long lo
 #define M3_STAMP(k) do {} while (0)
 #endif
 
+// A wave-uniform address, pinned into an SGPR pair: the lane-dependent part of a load's address then stays a 32-bit
+// offset register (`global_load v, v_off, s[base]`).  Without the pin hipcc hoists base + lane offset out of loops
+// as a 64-bit register pair per stream.
+template <class T>
+__device__ __forceinline__ const M3_GLOBAL T* uniform_base(const M3_GLOBAL T* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const M3_GLOBAL T*)(((uint64_t)hi << 32) | lo);
+}
+
 struct RRun {      // per-step resolved run: quad address = base + r, dx of the run's parameter
   int32_t base;    // coef_off - start_r + seg * stride   (float4 units from the brick's store)
   float dx;
 };
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+// The kernel issues about as many instructions as the SIMDs can take (rocprof: the vector pipes are busy > 90 % of the
+// launch), so its inner parts are written for instruction count: a response word is already the byte offset of its
+// slot in the scatter array; unused slots of that array hold 1.0f, so an event's column is multiplied without counts
+// or predicates; idle lanes load from wherever their index points instead of selecting an address.
+//
 // BIGP: more spline parameters than the LDS tables hold (kBrickLdsParams): {segment, dx} and the TF1 parameter values are
 // then read from global memory where they are needed -- a dependent round trip per stage and per TF1 response; a
 // separate instantiation, because a run-time branch around those loads would cost the common case its counted waits
 template <int MODE, bool NT, bool DYN = false, bool BIGP = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
-  __shared__ float ell[M3_ELL_ROWS * M3_GROUP];
-  __shared__ RRun lds_runs[2 * kBrickRunSlots];   // two stages; + 1 slot each: lanes past a stage's last response index one run further
-  __shared__ uint16_t lds_grp[2 * kBrickGrpSlots];
-  __shared__ uint32_t lds_hdr[kBrickHdrWords];
-  __shared__ uint8_t lds_cnt[M3_GROUP];
+  __shared__ float ell[M3_ELL_ROWS * M3_GROUP];   // scatter array [rank][event]; 1.0f wherever no response sits
+  __shared__ RRun lds_runs[2 * kBrickRunSlots];   // resolved run tables of two stages
+  __shared__ __attribute__((aligned(16))) uint16_t lds_grp[2 * 16 * kBrickGrpPerWave];  // [stage & 1][wave][u]: run of the group's first response
+  __shared__ __attribute__((aligned(16))) uint32_t lds_hdr[kBrickHdrWords];
   __shared__ PTab lds_ptab[kBrickLdsParams];
-  __shared__ float lds_tf1x[kBrickLdsParams];  // parameter value per entry of the TF1 dictionary
+  __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
-  const uint32_t wave_base = __builtin_amdgcn_readfirstlane(lane & ~63u);  // first lane of this wave
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(lane >> 6);
   const BrickDev bd = a.bricks[a.tile_base + blockIdx.x];
   const M3_GLOBAL uint32_t* __restrict__ words = as_global(bd.words);
+  const M3_GLOBAL char* __restrict__ wbytes = (const M3_GLOBAL char*)words;
   const M3_GLOBAL PTab* __restrict__ ptab = as_global(a.ptab);
   const uint32_t n_stages = bd.n_stages;
   constexpr bool tab_in_lds = !BIGP;
+  constexpr int kWordRegs = (kBrickRPL + 1) / 2;
 
-  // what one stage's coefficient loads need, requested ahead of time (global loads only, nothing here waits)
-  struct Meta {
-    u16x2_t w[(kBrickRPL + 1) / 2];  // response words (0 past the stage's end), two per register
-    uint32_t grp;                    // lanes < n_groups: run of the group's first response
-  };
+  // What one stage's coefficient loads need, requested ahead of time (global loads only, nothing here waits).
   // NOTE: no branch may enclose a vector-memory instruction between the prologue and the last stage: hipcc's wait-count
   // insertion falls back to vmcnt(0) at control-flow joins with loads pending, which would drain the quads in flight at
-  // every table build.  Hence clamped addresses instead of predicated loads, also for stages that do not exist (their
-  // header reads as zeros and the loads fetch the brick's first words).
-  auto fetch_meta = [&](uint32_t h0, uint32_t off_grp, uint32_t off_resp, Meta& m) {
-    const uint32_t n_resp = h0 & 0xFFFFu;
-    const uint32_t last = n_resp ? n_resp - 1 : 0u;
-    // SGPR base + 32-bit lane offset; lanes past the end re-read the last word (one line) and drop it
-    const M3_GLOBAL char* __restrict__ resp = (const M3_GLOBAL char*)(words + off_resp);
+  // every table build.  Hence no predicated loads: a lane past the end of a list reads what lies behind it (stages that
+  // do not exist have an all-zero header and read the brick's first words), and nothing is ever done with the value.
+  struct Meta {
+    uint32_t w[kWordRegs];  // response words, two per register
+    uint32_t grp;           // lanes < M3_STAGE_CAP / 64: run of the group's first response
+    u32x2_t run;            // lanes < n_runs: the raw entry of run `lane`
+  };
+  struct StageHdr { uint32_t h0, off_runs, off_grp, off_resp; };  // wave-uniform (SGPRs): bases of SGPR + lane-offset loads
+  auto fetch_meta = [&](const StageHdr& hd, Meta& m) {
+    // lanes past the end of a list re-read its last element (one line): an unclamped read would drag 10+ KB of foreign
+    // lines per stage through the memory system
+    const uint32_t n_resp = hd.h0 & 0xFFFFu, n_runs = (hd.h0 >> 16) & 0x3FFu;
+    const M3_GLOBAL char* resp = uniform_base(wbytes + 4u * hd.off_resp);
 #pragma unroll
-    for (int u = 0; u < kBrickRPL; ++u) {
-      const uint32_t r = lane + u * kBrickThreads;
-      const uint16_t v = *(const M3_GLOBAL uint16_t*)(resp + 2u * (r < n_resp ? r : last));
-      m.w[u / 2][u % 2] = r < n_resp ? v : (uint16_t)0;
+    for (int k = 0; k < kWordRegs; ++k) {
+      // block k: one dword per response of batch 2k
+      const uint32_t len = n_resp > 2u * k * kBrickThreads ? n_resp - 2u * k * kBrickThreads : 1u;  // scalar
+      const uint32_t l = lane < len - 1u ? lane : len - 1u;
+      m.w[k] = *(const M3_GLOBAL uint32_t*)(resp + 4u * kBrickThreads * (n_resp > 2u * k * kBrickThreads ? k : 0u) + 4u * l);
     }
-    if (kBrickRPL & 1) m.w[kBrickRPL / 2][1] = 0;
-    const M3_GLOBAL char* __restrict__ grp = (const M3_GLOBAL char*)(words + off_grp);
-    const uint32_t n_grp = (n_resp + 63u) >> 6;
-    m.grp = *(const M3_GLOBAL uint16_t*)(grp + 2u * (lane < n_grp ? lane : 0u));
+    {
+      const uint32_t l = lane < (uint32_t)(M3_STAGE_CAP / 64 - 1) ? lane : (uint32_t)(M3_STAGE_CAP / 64 - 1);
+      m.grp = *(const M3_GLOBAL uint16_t*)(uniform_base(wbytes + 4u * hd.off_grp) + 2u * l);
+    }
+    {
+      const uint32_t last = n_runs ? n_runs - 1u : 0u, l = lane < last ? lane : last;
+      m.run = *(const M3_GLOBAL u32x2_t*)(uniform_base(wbytes + 4u * hd.off_runs) + 8u * l);
+    }
   };
-  auto fetch_run = [&](uint32_t h0, uint32_t off_runs) -> u32x2_t {  // lanes < n_runs: the raw entry of run `lane`
-    const uint32_t n_runs = h0 >> 16;
-    const M3_GLOBAL char* __restrict__ runs = (const M3_GLOBAL char*)(words + off_runs);
-    return *(const M3_GLOBAL u32x2_t*)(runs + 8u * (lane < n_runs ? lane : 0u));
-  };
+  auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
 
   M3_STAMP(0);
   // ---- prologue.  Round trip 1: the stage headers, stage 0's metadata (its header travels in the descriptor), the
-  // parameter table, and everything the TF1 side needs later
+  // parameter table, and the TF1 side's bookkeeping
   uint32_t hdr_w = 0;
   if (lane < kBrickHdrWords) hdr_w = lane < M3_BRICK_HDR0 + M3_STAGE_HDR * n_stages ? words[lane] : 0u;
   Meta m_cur;
-  u32x2_t re_cur;
-  fetch_meta(bd.st0[0], bd.st0[2], bd.st0[3], m_cur);
-  re_cur = fetch_run(bd.st0[0], bd.st0[1]);
+  fetch_meta(StageHdr{bd.st0[0], bd.st0[1], bd.st0[2], bd.st0[3]}, m_cur);
   const M3_GLOBAL uint32_t* __restrict__ tf1h = words + bd.off_tf1;
   const uint32_t tf1_cnt = (tf1h[32 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;  // codes of this lane's event
-  uint32_t tf1_cbase = __builtin_amdgcn_readfirstlane(tf1h[wave_base >> 6]);       // this wave's first slot / code dword
-  uint32_t tf1_dbase = __builtin_amdgcn_readfirstlane(tf1h[16 + (wave_base >> 6)]);
+  uint32_t tf1_cbase = __builtin_amdgcn_readfirstlane(tf1h[wave]);                // this wave's first slot / code dword
+  uint32_t tf1_dbase = __builtin_amdgcn_readfirstlane(tf1h[16 + wave]);
   const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
   if (x_in_lds && lane < bd.n_dict) x_own = tf1x[lane].f;
-  lds_cnt[lane] = 0;
+#pragma unroll
+  for (int j = 0; j < M3_ELL_ROWS; ++j) ell[j * M3_GROUP + lane] = 1.0f;
   if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
   if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
-  if (x_in_lds && lane < bd.n_dict) lds_tf1x[lane] = x_own;
+  if (x_in_lds && lane < bd.n_dict) lds_tf1x[1 + lane] = x_own;
+  if (lane == 0) lds_tf1x[0] = 0.f;
   if (tab_in_lds && lane < (uint32_t)a.n_params) {
     PTab t;
     t.dx = ptab[lane].dx;
@@ -625,11 +651,16 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   }
   __syncthreads();  // headers and the parameter table visible
   M3_STAMP(1);
-  auto hdr = [&](uint32_t s) -> const uint32_t* { return lds_hdr + M3_BRICK_HDR0 + M3_STAGE_HDR * s; };
+  auto hdr = [&](uint32_t s) -> StageHdr {
+    const u32x4_t v = *(const u32x4_t*)(lds_hdr + M3_BRICK_HDR0 + M3_STAGE_HDR * s);
+    return StageHdr{(uint32_t)__builtin_amdgcn_readfirstlane(v.x), (uint32_t)__builtin_amdgcn_readfirstlane(v.y),
+                    (uint32_t)__builtin_amdgcn_readfirstlane(v.z), (uint32_t)__builtin_amdgcn_readfirstlane(v.w)};
+  };
 
-  auto publish = [&](uint32_t s, uint32_t h0, uint32_t grp, u32x2_t e) {  // stage s's run table and group table -> LDS
-    if (lane < (h0 >> 16)) {
-      const uint32_t p = e.y >> 16;
+  auto publish = [&](uint32_t s, uint32_t h0, const Meta& m) {  // stage s's run table and group table -> LDS
+    const uint32_t n_runs = (h0 >> 16) & 0x3FFu;
+    if (lane < n_runs + 65u) {
+      const uint32_t p = m.run.y >> 16;
       PTab t;
       if (tab_in_lds) {
         t = lds_ptab[p];
@@ -638,68 +669,73 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         t.seg = ptab[p].seg;
       }
       RRun rr;
-      rr.base = (int32_t)e.x + t.seg * (int32_t)(e.y & 0xFFFFu);
+      // entries behind the last run: what lanes past the stage's end index (their words are not theirs).  The base
+      // sends their loads far past the store, where the offset clamp turns all of them into one and the same line.
+      rr.base = lane < n_runs ? (int32_t)m.run.x + t.seg * (int32_t)(m.run.y & 0xFFFFu) : 0x07000000;
       rr.dx = t.dx;
       lds_runs[(s & 1u) * kBrickRunSlots + lane] = rr;
     }
-    if (lane < (uint32_t)kBrickGrpSlots) lds_grp[(s & 1u) * kBrickGrpSlots + lane] = (uint16_t)grp;
+    // group g = u * 16 + wave -> [wave][u]: a wave fetches its entries of a stage with one 16-byte read
+    if (lane < (uint32_t)(M3_STAGE_CAP / 64)) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.grp;
   };
   // stage 1's metadata is requested BEFORE stage 0's coefficient loads: vector memory returns in order, so whatever a
   // stage's tables need has to be older than the quads that are in flight while the tables are built
   Meta m_nxt;
-  u32x2_t re_nxt;
-  {
-    const uint32_t* h1 = hdr(1);
-    fetch_meta(h1[0], h1[2], h1[3], m_nxt);
-    re_nxt = fetch_run(h1[0], h1[1]);
-  }
-  publish(0, bd.st0[0], m_cur.grp, re_cur);
+  fetch_meta(hdr(1), m_nxt);
+  publish(0, bd.st0[0], m_cur);
   __syncthreads();  // stage 0's tables visible
   M3_STAMP(2);
 
   float4 c[kBrickRPL];
   float dx[kBrickRPL];
   const M3_GLOBAL char* __restrict__ spl_bytes = (const M3_GLOBAL char*)as_global(bd.spl);
-  // coefficient load of response lane + u * 1024 of stage s (tables of stage s visible)
-  auto issue_quad = [&](int u, uint32_t s, uint32_t n_resp, const Meta& m) {
-    const uint32_t r = lane + u * kBrickThreads;
-    // the run of a response: the run of its group's first response + the runs that END before it inside the group
-    const unsigned long long ends = __ballot((m.w[u / 2][u % 2] & 0x8000u) != 0);
-    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends, 0u));
-    const uint32_t run = (uint32_t)lds_grp[(s & 1u) * kBrickGrpSlots + ((wave_base + u * kBrickThreads) >> 6)] + before;
-    const RRun rr = lds_runs[(s & 1u) * kBrickRunSlots + (run < (uint32_t)M3_STAGE_MAX_RUNS ? run : (uint32_t)M3_STAGE_MAX_RUNS)];
-    dx[u] = rr.dx;
-    // SGPR base + 32-bit byte offset (a brick's store is far below 4 GB); lanes (and whole waves) past the stage's end
-    // read the brick's first quad -- one line -- and never use it
-    const uint32_t off = r < n_resp ? (uint32_t)(rr.base + (int32_t)r) << 4 : 0u;
-    const M3_GLOBAL f32x4_t* g = (const M3_GLOBAL f32x4_t*)(spl_bytes + off);
-    const f32x4_t v = NT ? __builtin_nontemporal_load(g) : *g;
-    c[u] = make_float4(v.x, v.y, v.z, v.w);
-  };
+  const uint32_t spl_last = bd.spl_last_off;  // byte offset of the store's last quad
+  // coefficient loads of stage s (its tables visible): response lane + u * 1024
+  auto issue_quads = [&](uint32_t s, const Meta& m, auto&& between) {
+    const u32x4_t g4 = *(const u32x4_t*)(lds_grp + (s & 1u) * 16 * kBrickGrpPerWave + wave * kBrickGrpPerWave);
+    const uint32_t g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const RRun* runs = lds_runs + (s & 1u) * kBrickRunSlots;
 #pragma unroll
-  for (int u = 0; u < kBrickRPL; ++u) issue_quad(u, 0, bd.st0[0] & 0xFFFFu, m_cur);
+    for (int u = 0; u < kBrickRPL; ++u) {
+      between(u);
+      // the run of a response: the run of its group's first response + the runs that END before it inside the group
+      const unsigned long long ends = __ballot((m.w[u / 2] & (1u << (16 * (u & 1)))) != 0);
+      const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends, 0u));
+      const uint32_t first = __builtin_amdgcn_readfirstlane((g[u / 2] >> (16 * (u & 1))) & 0xFFFFu);
+      const RRun rr = runs[first + before];
+      dx[u] = rr.dx;
+      // SGPR base + 32-bit byte offset (a brick's store is far below 4 GB).  A lane past the stage's end indexes one
+      // of the entries behind the last run: its offset is clamped to the store's last quad, loaded, never used.
+      uint32_t off = ((uint32_t)rr.base + (lane + u * kBrickThreads)) << 4;
+      off = off < spl_last ? off : spl_last;
+      const M3_GLOBAL f32x4_t* gp = (const M3_GLOBAL f32x4_t*)(spl_bytes + off);
+      const f32x4_t v = NT ? __builtin_nontemporal_load(gp) : *gp;
+      c[u] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  issue_quads(0, m_cur, [](int) {});
 
   // ---- TF1 side (SplineMonolith.cpp:818-825: after the TSpline3s, in the event's parameter order): one batch of rows
   float2 ab[kBrickTf1Batch];
   uint32_t code[kBrickTf1Batch / 4];
+  bool tf1_on[kBrickTf1Batch / 4];
   const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
-  auto tf1_issue = [&](uint32_t j0) {  // loads of rows j0 .. j0 + kBrickTf1Batch - 1 (nothing here waits)
+  auto tf1_issue = [&](uint32_t j0, auto nrows_tag) {  // loads of rows j0 .. j0 + N - 1 (nothing here waits)
+    constexpr int N = decltype(nrows_tag)::value;
 #pragma unroll
-    for (int q = 0; q < kBrickTf1Batch / 4; ++q) {
-      const bool on = tf1_cnt > j0 + 4 * q;
-      const unsigned long long act = __ballot(on);
+    for (int q = 0; q < N / 4; ++q) {
+      const unsigned long long act = __ballot(tf1_cnt > j0 + 4 * q);
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      code[q] = *(const M3_GLOBAL uint32_t*)((const M3_GLOBAL char*)words + 4u * (on ? pos : tf1_dbase));  // idle lanes: an in-range word
+      code[q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
+      tf1_on[q] = tf1_cnt > j0 + 4 * q;
     }
 #pragma unroll
-    for (int i = 0; i < kBrickTf1Batch; ++i) {
-      const bool on = tf1_cnt > j0 + i;
-      const unsigned long long act = __ballot(on);
+    for (int i = 0; i < N; ++i) {
+      const unsigned long long act = __ballot(tf1_cnt > j0 + i);
       const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      // idle lanes re-read the row's first slot (the stores end in a few spare bytes: m3hip_api.hip)
-      const M3_GLOBAL f32x2_t* g = (const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * (on ? pos : tf1_cbase));
-      const f32x2_t v = NT ? __builtin_nontemporal_load(g) : *g;
+      const M3_GLOBAL f32x2_t* gp = (const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos);
+      const f32x2_t v = NT ? __builtin_nontemporal_load(gp) : *gp;
       ab[i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
     }
@@ -741,54 +777,46 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 
   float w = 1.0f;  // SplineMonolith.cpp:798
   // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
-  // scattered to ell[rank][event], and its register reused at once for the next stage's load (LAST: for the first TF1
-  // rows instead); barrier; the event's column of the scatter array, ascending parameter = reference order.
+  // scattered to its slot of the scatter array, and its register reused at once for the next stage's load (LAST: for the
+  // first TF1 rows instead); barrier; the event's column of the scatter array, ascending parameter = reference order.
   auto stage = [&](uint32_t s, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    const uint32_t n_resp = hdr(s)[0] & 0xFFFFu;
-    uint32_t n_resp_nxt = 0;
+    const uint32_t h0 = hdr(s).h0;
+    const uint32_t n_resp = h0 & 0xFFFFu, rows = h0 >> 26;
     Meta m_nn;
-    u32x2_t re_nn;
     if (!LAST) {
-      const uint32_t* h1 = hdr(s + 1);
-      n_resp_nxt = h1[0] & 0xFFFFu;
-      publish(s + 1, h1[0], m_nxt.grp, re_nxt);  // waits for stage s+1's metadata only: it is older than the quads in flight
-      const uint32_t* h2 = hdr(s + 2);
-      fetch_meta(h2[0], h2[2], h2[3], m_nn);
-      re_nn = fetch_run(h2[0], h2[1]);
+      publish(s + 1, hdr(s + 1).h0, m_nxt);  // waits for stage s+1's metadata only: it is older than the quads in flight
+      fetch_meta(hdr(s + 2), m_nn);
     }
-    __syncthreads();  // stage s+1's tables visible; every wave is through phase B of stage s-1: the scatter array is free
+    __syncthreads();  // stage s+1's tables visible; every wave is through its column of stage s-1: the scatter array is free
+    auto scatter = [&](int u) {
+      // bits 2..15 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
+      if (lane + u * kBrickThreads < n_resp)
+        *(float*)((char*)ell + (word(m_cur, u) & 0xFFFCu)) = spline_poly(dx[u], c[u]);
+    };
+    if (!LAST) {
+      issue_quads(s + 1, m_nxt, scatter);
+    } else {
 #pragma unroll
-    for (int u = 0; u < kBrickRPL; ++u) {
-      const uint32_t r = lane + u * kBrickThreads;
-      if (r < n_resp) {
-        const uint32_t wd = m_cur.w[u / 2][u % 2], ev = wd & 0x3FFu, rk = (wd >> 10) & 0xFu;
-        ell[rk * M3_GROUP + ev] = spline_poly(dx[u], c[u]);
-        if (wd & 0x4000u) lds_cnt[ev] = (uint8_t)(rk + 1);  // the event's last response of the stage: its count
-      }
-      if (!LAST) issue_quad(u, s + 1, n_resp_nxt, m_nxt);
-    }
-    if (LAST) {
-      if (any_tf1) tf1_issue(0);
+      for (int u = 0; u < kBrickRPL; ++u) scatter(u);
+      if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
       tail_issue_idx();
     }
     __syncthreads();  // the stage's scatter is complete
-    {
-      const uint32_t n = lds_cnt[lane];
-      lds_cnt[lane] = 0;
-      for (uint32_t j0 = 0; j0 < (uint32_t)M3_ELL_ROWS; j0 += 4) {
-        if (!__any(n > j0)) break;
-        float v[4];
+    // the event's column: slots without a response hold 1.0f (exact), and every slot is left at 1.0f for the next stage
+    for (uint32_t j0 = 0; j0 < rows; j0 += 4) {
+      float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = ell[(j0 + i) * M3_GROUP + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w *= (j0 + i < n) ? v[i] : 1.0f;  // rows past the count hold stale values
+      for (int i = 0; i < 4; ++i) {
+        v[i] = ell[(j0 + i) * M3_GROUP + lane];
+        ell[(j0 + i) * M3_GROUP + lane] = 1.0f;
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w *= v[i];
     }
     if (!LAST) {
       m_cur = m_nxt;
       m_nxt = m_nn;
-      re_nxt = re_nn;
     }
   };
   if (n_stages > 0) {
@@ -799,25 +827,32 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     stage(n_stages - 1, std::true_type{});
     M3_STAMP(8);
   } else {
-    if (any_tf1) tf1_issue(0);
+    if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
     tail_issue_idx();
   }
   tail_issue_val();  // waits for the indices (and with them the first TF1 rows, consumed next anyway)
 
   if (any_tf1) {
-    int32_t kd = -1;  // position in the dictionary
-    for (uint32_t j0 = 0; __any(tf1_cnt > j0); j0 += kBrickTf1Batch) {
-      if (j0) tf1_issue(j0);
+    uint32_t kd4 = 0;  // 4 * (1 + position in the dictionary)
+    auto tf1_rows = [&](uint32_t j0, auto nrows_tag) {
+      constexpr int N = decltype(nrows_tag)::value;
 #pragma unroll
-      for (int i = 0; i < kBrickTf1Batch; ++i) {
-        if (j0 + i < tf1_cnt) {
-          const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
-          const bool skip = cd == (uint32_t)M3_TF1_SKIP;
-          kd += skip ? 254 : (int32_t)cd;
-          const float x = x_in_lds ? lds_tf1x[kd] : tf1x[kd].f;
-          w *= skip ? 1.0f : fmaf(ab[i].x, x, ab[i].y);  // SplineMonolith.cpp:779
-        }
+      for (int q = 0; q < N / 4; ++q) code[q] = tf1_on[q] ? code[q] : 0u;  // ... dropped here
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        // code 0: no response in this row (the event's list has ended: the planner zero-fills); M3_TF1_SKIP: a step of 254
+        // without a response
+        const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
+        kd4 += (cd < 254u ? cd : 254u) << 2;
+        const float x = x_in_lds ? *(const float*)((const char*)lds_tf1x + kd4) : tf1x[kd4 ? (kd4 >> 2) - 1u : 0u].f;
+        const float t = fmaf(ab[i].x, x, ab[i].y);  // SplineMonolith.cpp:779
+        w *= (cd - 1u < (uint32_t)(M3_TF1_SKIP - 1)) ? t : 1.0f;
       }
+    };
+    tf1_rows(0, std::integral_constant<int, kBrickTf1Batch>{});
+    for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Next) {
+      tf1_issue(j0, std::integral_constant<int, kBrickTf1Next>{});
+      tf1_rows(j0, std::integral_constant<int, kBrickTf1Next>{});
     }
   }
 

@@ -86,13 +86,16 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 // ------------------------------------------------------------------------------------
 // Brick metadata stream (uint32 words, offsets relative to the brick's first word):
 //   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3..7] 0
-//   [8 + 4 s ..]  stage header: n_resp | n_runs << 16, off_runs, off_grp, off_resp
+//   [8 + 4 s ..]  stage header: n_resp | n_runs << 16 | rows << 26, off_runs, off_grp, off_resp   (rows = the most
+//             responses one event holds in the stage = the rows of the scatter array the stage uses)
 //   off_runs  n_runs x {int32 coef_off - start_r, stride | param << 16}.  coef_off: float4 index of the run's first plane
 //             in the brick's spline store; start_r: first response of the run in the stage; so the quad of segment k of
 //             response r sits at entry[0] + k * stride + r.  stride = n_run rounded up to M3_PLANE_ALIGN.
-//   off_grp   per 64 responses one uint16, two per word: the run of the group's first response
-//   off_resp  n_resp uint16, two per word: event | rank << 10 | last response of the event in the stage << 14 |
-//             last response of its run << 15
+//   off_grp   M3_STAGE_CAP / 64 uint16 (n_runs past the stage's last group), two per word: the run of the group's first response
+//   off_resp  one uint16 per response: (rank << 10 | event) << 2 | last response of its run (bits 2..15 are the byte offset
+//             of the response's slot in the scatter array), stored two per dword the way a lane fetches them:
+//             dword [k][l] = word of response l + 2k * 1024 | word of response l + (2k + 1) * 1024 << 16; block k has
+//             one dword for every response of batch 2k (1024, fewer in the last block)
 //   off_tf1   [0..15]   float2 index (from the brick's TF1 store) of the first slot of wave w (events 64 w .. 64 w + 63)
 //             [16..31]  word offset (from the brick's first word) of wave w's first code dword
 //             [32..32 + M3_GROUP / 4)  codes per event, uint8, four per word
@@ -151,13 +154,20 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   // M3_ELL_ROWS times.  Stages of about equal size (a brick whose responses just exceed a multiple of the cap would
   // otherwise end in a stage of a few responses that costs the same barriers as a full one).
   struct Range { int p0, p1; };
-  std::vector<Range> st_s;
-  {
-    const uint32_t n_want = std::max<uint32_t>(1u, (S + uint32_t(M3_STAGE_CAP) - 1) / uint32_t(M3_STAGE_CAP));
-    const uint32_t soft = (S + n_want - 1) / n_want;
+  // `n_aim` = 0: every stage as long as the limits allow (the fewest stages there can be).  Otherwise: aim at `n_aim` stages
+  // of equal size, re-aimed after every stage (one that the row limit closed early must not leave a stub of a few
+  // responses behind: it would cost the same barriers as a full stage).
+  auto split = [&](uint32_t n_aim) {
+    std::vector<Range> st;
     std::vector<uint8_t> mult(ne, 0);
     int p0 = 0;
+    uint32_t done = 0;  // responses in the stages closed so far
     while (p0 < n_params) {
+      uint32_t soft = uint32_t(M3_STAGE_CAP);
+      if (n_aim) {
+        const uint32_t left = S - done, n_left = n_aim > st.size() ? n_aim - uint32_t(st.size()) : 1u;
+        soft = std::min<uint32_t>(soft, (left + n_left - 1) / n_left);
+      }
       std::fill(mult.begin(), mult.end(), uint8_t(0));
       uint32_t tot = 0, runs = 0;
       int p1 = p0;
@@ -175,9 +185,16 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         ++p1;
         if (tot >= soft) break;
       }
-      if (tot > 0) st_s.push_back({p0, p1});
+      if (tot > 0) st.push_back({p0, p1});
+      done += tot;
       p0 = p1;
     }
+    return st;
+  };
+  std::vector<Range> st_s = split(0);
+  if (st_s.size() > 1) {
+    std::vector<Range> even = split(uint32_t(st_s.size()));
+    if (even.size() <= st_s.size()) st_s.swap(even);
   }
   const uint32_t n_stages = uint32_t(st_s.size());
   if (n_stages > uint32_t(M3_BRICK_MAX_STAGES)) {
@@ -196,15 +213,13 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   bh->spl_src.clear();
   bh->spl_src.reserve(S);
   std::vector<uint8_t> rank_of(ne);
-  std::vector<int32_t> last_of(ne);
   for (uint32_t stage = 0; stage < n_stages; ++stage) {
     const Range& rg = st_s[stage];
     const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
     std::fill(rank_of.begin(), rank_of.end(), uint8_t(0));
-    std::fill(last_of.begin(), last_of.end(), -1);
     std::vector<uint32_t> runs;
-    std::vector<uint16_t> resp(n_resp), grp((n_resp + 63) / 64);
-    uint32_t n_runs = 0;
+    std::vector<uint16_t> resp(n_resp), grp(size_t(M3_STAGE_CAP) / 64, uint16_t(0));  // groups past the end: filled below
+    uint32_t n_runs = 0, rows = 0;
     for (int p = rg.p0; p < rg.p1; ++p) {
       const uint32_t a = cnt_s[p], b = cnt_s[p + 1];
       if (a == b) continue;
@@ -212,31 +227,39 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
       // every segment plane of a run starts on a 128-byte line: a step reads ONE plane per run, and the memory side
       // fetches whole lines, so an unaligned plane would drag in the neighbouring planes' lines at both ends
       const uint32_t stride = (n_run + uint32_t(M3_PLANE_ALIGN) - 1) & ~uint32_t(M3_PLANE_ALIGN - 1);
-      if (spl_f4 + uint64_t(stride) * nseg > 0x7FFFFFFFull) { *err = "brick: spline store exceeds 2^31 quads"; return false; }
+      if (spl_f4 + uint64_t(stride) * nseg > 0x06000000ull) { *err = "brick: spline store exceeds 1.6 GB"; return false; }
       runs.push_back(uint32_t(int32_t(spl_f4) - int32_t(a - r0)));
       runs.push_back(stride | (uint32_t(p) << 16));
       for (uint32_t r = a; r < b; ++r) {
         const uint32_t ev = inv_ev[r], i = r - r0;
         if (i % 64 == 0) grp[i / 64] = uint16_t(n_runs);
-        resp[i] = uint16_t(ev | (uint32_t(rank_of[ev]++) << 10));
-        last_of[ev] = int32_t(i);
+        const uint32_t rk = rank_of[ev]++;
+        rows = std::max(rows, rk + 1);
+        resp[i] = uint16_t((ev | (rk << 10)) << 2);
         bh->spl_src.push_back(inv_s[r]);
       }
-      resp[b - 1 - r0] |= uint16_t(0x8000u);  // last response of its run
+      resp[b - 1 - r0] |= uint16_t(1u);  // last response of its run
       spl_f4 += uint64_t(stride) * nseg;
       ++n_runs;
     }
-    for (uint32_t ev = 0; ev < ne; ++ev)
-      if (last_of[ev] >= 0) resp[size_t(last_of[ev])] |= uint16_t(0x4000u);  // last response of its event in the stage
+    // groups past the stage's end point behind the last run (the kernel keeps harmless entries there for lanes without a response)
+    for (size_t g = (size_t(n_resp) + 63) / 64; g < grp.size(); ++g) grp[g] = uint16_t(n_runs);
     if (w.size() & 1) w.push_back(0u);  // run entries are read as 8-byte pairs
     const uint32_t off_runs = uint32_t(w.size());
     w.insert(w.end(), runs.begin(), runs.end());
     const uint32_t off_grp = uint32_t(w.size());
     push_u16(grp);
+    // response words, two per dword the way a lane fetches them: lane l of the workgroup works on responses
+    // l, l + 1024, l + 2048, ... of the stage; dword [k][l] = word of response l + 2k * 1024 | word of response
+    // l + (2k + 1) * 1024 << 16.  Block k holds one dword for every response of batch 2k (1024 but for the last block).
     const uint32_t off_resp = uint32_t(w.size());
-    push_u16(resp);
+    for (uint32_t k = 0; 2 * k * uint32_t(M3_GROUP) < n_resp; ++k) {
+      const uint32_t lo0 = 2 * k * uint32_t(M3_GROUP), hi0 = lo0 + uint32_t(M3_GROUP);
+      const uint32_t len = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp - lo0);
+      for (uint32_t l = 0; l < len; ++l) w.push_back(uint32_t(resp[lo0 + l]) | (hi0 + l < n_resp ? uint32_t(resp[hi0 + l]) << 16 : 0u));
+    }
     uint32_t* h = &w[size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * stage];
-    h[0] = n_resp | (n_runs << 16);
+    h[0] = n_resp | (n_runs << 16) | (rows << 26);
     h[1] = off_runs;
     h[2] = off_grp;
     h[3] = off_resp;
@@ -254,7 +277,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     for (unsigned int i = 0; i < ct; ++i) {
       const int32_t k = dict_index[size_t(in.param_no_tf1[t0 + i])];
       int32_t gap = k - prev;  // >= 1: parameters ascend and the dictionary is ascending
-      while (gap > 254) {
+      while (gap > 254) {  // real steps are 1 .. 254; a skip advances 254, so that a step of at least 1 remains
         codes[le].push_back(uint8_t(M3_TF1_SKIP));
         srcs[le].push_back(0xFFFFFFFFu);
         gap -= 254;
@@ -307,7 +330,7 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
   size_t src_i = 0;
   for (uint32_t s = 0; s < n_stages; ++s) {
     const uint32_t* h = words + size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * s;
-    const uint32_t n_resp = h[0] & 0xFFFFu, n_runs = h[0] >> 16;
+    const uint32_t n_resp = h[0] & 0xFFFFu, n_runs = (h[0] >> 16) & 0x3FFu;
     const uint32_t* runs = words + h[1];
     uint32_t start_r = 0;
     for (uint32_t r = 0; r < n_runs; ++r) {

@@ -53,6 +53,9 @@ constexpr int M3_PLANE_ALIGN = 8;        // quads: segment planes of a run start
 constexpr int M3_WAVE = 64;              // events per jagged TF1 block
 constexpr int M3_TF1_MAX_CODES = 255;    // TF1 codes (responses + skips) per event
 constexpr int M3_TF1_SKIP = 255;         // code: advance 254 dictionary entries, no response
+// idle lanes of the brick kernel read (and drop) what lies behind the list they index: every chunk's stores are allocated
+// with this much room behind them
+constexpr int M3_STORE_SLACK_BYTES = 32 * 1024;
 constexpr int M3_BRICK_ALIGN_WORDS = 32; // every brick's stream starts on a 128-B line
 
 enum TileKind : uint32_t { kTileUniform = 0, kTileBrick = 1 };

@@ -141,11 +141,19 @@ def brick_event_lists(npts, ch, lay, b):
     used = np.zeros(max(1, n_f4), bool)
     for s in range(n_stages):
         h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
-        n_resp, n_runs = h0 & 0xFFFF, h0 >> 16
+        n_resp, n_runs, rows = h0 & 0xFFFF, (h0 >> 16) & 0x3FF, h0 >> 26
         assert 0 < n_resp <= STAGE_CAP and 0 < n_runs <= STAGE_MAX_RUNS and off_runs % 2 == 0
         runs = w[off_runs: off_runs + 2 * n_runs].reshape(-1, 2)
-        grp = w[off_grp: off_grp + ((n_resp + 63) // 64 + 1) // 2].view(np.uint16)
-        resp = w[off_resp: off_resp + (n_resp + 1) // 2].view(np.uint16)[:n_resp]
+        grp = w[off_grp: off_grp + STAGE_CAP // 128].view(np.uint16)
+        assert (grp[(n_resp + 63) // 64:] == n_runs).all()
+        resp = np.zeros(n_resp, np.uint16)                # two per dword, the way a lane fetches them
+        for k in range((n_resp + 2047) // 2048):
+            ln = min(1024, n_resp - 2048 * k)
+            blk = w[off_resp + 1024 * k: off_resp + 1024 * k + ln]
+            resp[2048 * k: 2048 * k + ln] = blk & 0xFFFF
+            hi = min(ln, max(0, n_resp - 2048 * k - 1024))
+            resp[2048 * k + 1024: 2048 * k + 1024 + hi] = blk[:hi] >> 16
+            assert not (blk[hi:] >> 16).any()
         ell = {}
         cnt = {}
         run, prev_param = -1, -1
@@ -153,7 +161,8 @@ def brick_event_lists(npts, ch, lay, b):
             if r % 64 == 0:
                 run = int(grp[r // 64])                  # the kernel: run of the group's first response ...
             wd = int(resp[r])
-            ev, rk, last_ev, last_run = wd & 0x3FF, (wd >> 10) & 0xF, (wd >> 14) & 1, wd >> 15
+            ev, rk, last_run = (wd >> 2) & 0x3FF, wd >> 12, wd & 1
+            assert not wd & 2
             assert ev < nev and rk < ELL_ROWS
             base = int(np.int32(runs[run][0]))
             stride, p = int(runs[run][1]) & 0xFFFF, int(runs[run][1]) >> 16
@@ -164,9 +173,7 @@ def brick_event_lists(npts, ch, lay, b):
             used[idx] = True
             assert (rk, ev) not in ell
             ell[(rk, ev)] = (p, "spl", np.stack([spl[spl_off + i] for i in idx]))
-            if last_ev:
-                assert ev not in cnt
-                cnt[ev] = rk + 1
+            cnt[ev] = max(cnt.get(ev, 0), rk + 1)
             run += last_run                              # ... + the runs that ended before this response
         assert run == n_runs                             # the last response closes the last run
         for e in range(nev):
@@ -174,8 +181,9 @@ def brick_event_lists(npts, ch, lay, b):
             assert [x[0] for x in col] == sorted(x[0] for x in col)
             out[e] += col
         assert not ell                                   # every scattered weight is consumed by its event
+        assert rows == max(cnt.values()) <= ELL_ROWS      # the rows of the scatter array the stage uses
         # planes start on 128-byte lines (start_r of a run = index of its first response, recovered from the words)
-        ends = np.flatnonzero(resp >> 15) + 1
+        ends = np.flatnonzero(resp & 1) + 1
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
             assert (int(np.int32(runs[rn][0])) + int(first_r[rn])) % 8 == 0
@@ -269,10 +277,11 @@ def test_more_runs_than_a_stage_holds():
     assert lay["n_bricks"] == 2 and lay["n_tiles"] == 0
     w = lay["words"]
     w0 = int(lay["bdesc"][0][2])
-    stages = [int(w[w0 + HDR0 + 4 * s]) for s in range(int(w[w0]))]      # n_resp | n_runs << 16
+    stages = [int(w[w0 + HDR0 + 4 * s]) & 0x3FFFFFF for s in range(int(w[w0]))]      # n_resp | n_runs << 16 (| rows << 26)
     assert len(stages) >= 3 and all(h >> 16 <= STAGE_MAX_RUNS for h in stages) and sum(h >> 16 for h in stages) > 1024
-    assert sum(h >> 16 == STAGE_MAX_RUNS for h in stages) >= 2                # the run count made the cut
-    assert all(h & 0xFFFF < STAGE_CAP for h in stages)        # none of them is full
+    n_runs, n_resp = sum(h >> 16 for h in stages), sum(h & 0xFFFF for h in stages)
+    assert len(stages) == -(-n_runs // STAGE_MAX_RUNS) > -(-n_resp // STAGE_CAP)   # the run count made the cuts, not the responses
+    assert max(h >> 16 for h in stages) - min(h >> 16 for h in stages) < 64        # ... and the stages came out even
     check_bricks(npts, ch, lay)
 
 
