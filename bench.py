@@ -9,15 +9,19 @@ A step = one pass of the hot path over one batch of synthetic MC:
 (the pair MR2T2::ProposeStep runs per proposal, ref: Fitters/MR2T2.cpp:66-76), timed
 DragRace-style (ref: Fitters/FitterBase.cpp:461-489).
 
-Workload: BASELINE.json configs[1] ("c2": 1e6 events, 128 TSpline3 systematics x 7 knots,
-single-sample Poisson LLH) PER GPU; with N > 1 every rank holds its own 1e6-event shard of an
-N x 1e6-event sample and each step ends in ONE RCCL all-reduce of the bin-rate vector (weak
-scaling).  value = N * K / t: LLH evaluations of a 1e6-event shard per second, which at
-N = 1 is exactly MCMC steps/s on configs[1].
+Workload.  N = 1: BASELINE.json configs[2] ("c3": 1e7 events, 512 mixed TSpline3/TF1 systematics at
+occupancy 1/16, 200 bins, Barlow-Beeston) -- the largest configuration BASELINE sizes for one GPU and
+the one north_star's targets are stated on.  N > 1: ONE sample of fixed size sharded over the ranks
+by events (strong scaling): configs[2] for N <= 2, configs[3] ("c4": 4 samples x 1e7 events) for
+N = 4 and 8, as north_star plans them; shard boundaries balance the responses per rank
+(mach3_amd/dist.py).  Every step ends in ONE in-library RCCL all-reduce of the bin vector.
+value = K / t: LLH evaluations (MCMC steps) per second of the whole sample.  `--config` overrides.
 
-Prints ONE JSON line on rank 0 (contract in the task description), carrying `roofline`
-(fused reweight kernel: algorithmic bytes / hipEvent-measured launch time vs 8 TB/s) and,
-at N = 1, `cpu_baseline` (the OpenMP oracle port timed on this host on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task description), carrying `roofline` (fused
+reweight kernel: algorithmic bytes / dispatch-stamped launch time vs 8 TB/s; traffic from the committed
+PMC passes), at N = 1 `cpu_baseline` (the OpenMP oracle port timed on this host on a bounded sample of
+the same configuration, arrays first-touched inside OpenMP loops, best of a thread sweep) and `extra`
+(the configs[1] line of round 1, measured the same way).
 """
 import argparse
 import json
@@ -29,6 +33,7 @@ import time
 # Manager/Monitor.cpp:122-138); must be set before any OpenMP runtime initialises
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
 os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -36,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+CFG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
+STAT_NAME = {0: "Poisson", 1: "Barlow-Beeston", 2: "IceCube", 3: "Pearson", 4: "Dembinski-Abdelmotteleb"}
 
 
 def log(*a):
@@ -45,7 +52,8 @@ def log(*a):
 def pmc_traffic(config_name, per_gpu):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_<config>_pmc_*.json: FETCH_SIZE and WRITE_SIZE collected in separate runs and
-    corrected as MI355X_MICROARCH.md prescribes).  None when no profile matches this workload."""
+    corrected as MI355X_MICROARCH.md prescribes).  The newest profile of this workload wins; None when
+    no profile matches."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config_name}_pmc_*.json"))):
@@ -62,21 +70,24 @@ def pmc_traffic(config_name, per_gpu):
 EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "4"))
 
 
-def cpu_baseline(spec, budget_s=10.0, sample_events=200_000):
-    """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events`
-    events of the same workload; steps/s scaled to the full event count.  Timed DragRace style at
-    min(cores, 16) threads (the reference refuses more unless OMP_NUM_THREADS is exported,
-    Manager/Monitor.cpp:122-138) and, briefly, at 8 threads; phases as SURVEY section 8d asks."""
+def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
+    """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events` events of
+    the same configuration; steps/s scaled to the full event count.  The big arrays are first touched
+    inside OpenMP loops with the compute loops' static schedule (m3o_monolith_localise, HomedArray),
+    threads bound to cores, so a multi-socket host is not handicapped by single-node page placement.
+    Timed DragRace style at 8, 16 (the most the reference uses unless OMP_NUM_THREADS is exported,
+    Manager/Monitor.cpp:122-138) and, on bigger hosts, the physical cores; the best point is `value`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from mach3_amd import synth
 
     n = min(sample_events, spec.n_events)
-    os.environ.setdefault("OMP_PROC_BIND", "close")  # SURVEY section 8d; read by libgomp when the library is loaded
     lib = ob.load("omp")
     cores = os.cpu_count() or 1
-    lib.m3o_set_num_threads(min(cores, 16))
-    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp")
+    physical = max(1, cores // 2) if cores >= 32 else cores  # SMT hosts of the pool: two hardware threads per core
+    sweep_threads = sorted({t for t in (8, 16, min(physical, 128)) if t <= cores} or {cores})
+    lib.m3o_set_num_threads(max(sweep_threads))  # first touch with the widest team: pages spread over all its nodes
+    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp", localise=True)
     samp.reweight()
     samp.add_data(samp.mc)
 
@@ -105,110 +116,92 @@ def cpu_baseline(spec, budget_s=10.0, sample_events=200_000):
                 "ms_per_lap": 1e3 * el / laps, "spline_eval_ms": 1e3 * t_spl / laps, "fill_ms": 1e3 * t_fill / laps,
                 "llh_ms": 1e3 * t_llh / laps}
 
-    main_run = run(min(cores, 16), budget_s, 2000)
-    sweep = {str(main_run["threads"]): main_run["steps_per_s"]}
-    if cores >= 8 and main_run["threads"] != 8:
-        r8 = run(8, 0.35 * budget_s, 1000)
-        sweep["8"] = r8["steps_per_s"]
-    if cores >= 64:  # what exporting OMP_NUM_THREADS buys the reference on this host: half the logical CPUs, at most 128
-        rmany = run(min(cores // 2, 128), 0.35 * budget_s, 1000)
-        sweep[str(rmany["threads"])] = rmany["steps_per_s"]
+    runs = [run(t, budget_s / len(sweep_threads), 4000) for t in sweep_threads]
+    best = max(runs, key=lambda r: r["steps_per_s"])
     samp.close()
     mono.close()
     return {
-        "value": main_run["steps_per_s"],
+        "value": best["steps_per_s"],
         "unit": "steps/s",
-        "cores": main_run["threads"],
+        "cores": best["threads"],
         "kind": "port",
-        "sample": f"first {n} of {spec.n_events} events, {main_run['laps']} laps in {main_run['seconds']:.1f} s "
-                  f"({main_run['ms_per_lap']:.2f} ms/lap: spline eval {main_run['spline_eval_ms']:.2f} ms, fill {main_run['fill_ms']:.2f} ms, "
-                  f"LLH {main_run['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}",
-        "steps_per_s_by_threads": sweep,
+        "sample": f"first {n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
+                  f"{best['threads']} threads ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
+                  f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; arrays first-touched in "
+                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
+        "steps_per_s_by_threads": {str(r["threads"]): r["steps_per_s"] for r in runs},
         "host_cores": cores,
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c2")
-    ap.add_argument("--events", type=int, default=0, help="override events per GPU (debug)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunk", type=int, default=131072)
-    ap.add_argument("--spinup-seconds", type=float, default=2.0,
-                    help="untimed steps before the warm-up: the first ~1 s of GPU work on a fresh process shows one-off "
-                         "50-100 ms stalls (clock / runtime ramp-up) that would otherwise land in a short timed region")
-    args = ap.parse_args()
+def shard_of(spec, rank, n_ranks):
+    """[e0, e1) of this rank: contiguous blocks on 1024-event boundaries, balanced by responses.  The
+    weights come from the generator's own counts in blocks of 65536 events (event data are a pure function of the
+    event number, so every rank computes the same cuts)."""
+    from mach3_amd import dist, synth
+    if n_ranks == 1:
+        return 0, spec.n_events
+    blk = 65536
+    edges = list(range(0, spec.n_events, blk)) + [spec.n_events]
+    w = np.empty(spec.n_events, np.float32)
+    for a, b in zip(edges[:-1], edges[1:]):
+        ns, nt = synth.count(spec, a, b)
+        w[a:b] = (ns + nt) / max(b - a, 1)
+    return dist.shard_ranges(spec.n_events, n_ranks, weights=w)[rank]
 
-    import torch  # device sync + torch.distributed (RCCL) plumbing only
 
+def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
+    """Build this rank's shard, run warm-up + the timed steps, return the numbers of the JSON line."""
     from mach3_amd import synth
     from mach3_amd.engine import build_from_synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    n_gpus = world
-    n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:
-        if os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
-            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
-        local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks share the card
-    torch.cuda.set_device(local_rank)
-    dist = None
-    force_comm = os.environ.get("M3_BENCH_FORCE_COMM") == "1"  # rehearsal: run the N > 1 plumbing with one rank
-    if world > 1 or force_comm:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("M3_BENCH_BACKEND", "nccl")  # "gloo": plumbing rehearsal on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    base = synth.CONFIGS[args.config]
-    per_gpu = args.events or base.n_events
-    spec = base.scaled(per_gpu * n_gpus)
-    e0, e1 = rank * per_gpu, (rank + 1) * per_gpu
-
+    e0, e1 = shard_of(spec, rank, n_ranks)
     t_setup = time.perf_counter()
     eng, mono, sh, par = build_from_synth(spec, device_id=local_rank, chunk_events=args.chunk, event_range=(e0, e1))
     info = eng.info()
-    if rank == 0:
-        log(f"[bench] {spec.name}: {per_gpu} events/GPU x {n_gpus} GPU, P={spec.n_params}, S={info.n_splines}, "
-            f"T={info.n_tf1}, coeff store {info.coeff_bytes / 1e9:.2f} GB, tiles {info.n_tiles_uniform}u/"
-            f"{info.n_tiles_brick}b, setup {time.perf_counter() - t_setup:.1f} s")
+    log(f"[bench] rank {rank}: {spec.name} events [{e0}, {e1}) of {spec.n_events}, P={spec.n_params}, S={info.n_splines}, "
+        f"T={info.n_tf1}, coeff store {info.coeff_bytes / 1e9:.2f} GB, tiles {info.n_tiles_uniform}u/{info.n_tiles_brick}b, "
+        f"setup {time.perf_counter() - t_setup:.1f} s")
 
     comm_mode = "none"
-    if (world > 1 or force_comm) and os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
-        # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id
-        uid = [None]
-        if rank == 0:
-            try:
-                uid = [eng.comm_unique_id()]
-            except Exception as e:
-                log(f"rank 0: ncclGetUniqueId failed ({e})")
-        dist.broadcast_object_list(uid, src=0)  # every rank takes part, whatever rank 0 got
-        ok = torch.zeros(1, device="cuda")
-        if uid[0] is not None:
-            try:
-                eng.comm_init(uid[0], rank, world)
-                ok = torch.ones(1, device="cuda")
-            except Exception as e:  # keep the scaling run alive: exchange the bins through torch.distributed instead
-                log(f"rank {rank}: in-library RCCL init failed ({e}); falling back to torch.distributed all_reduce")
+    force_comm = os.environ.get("M3_BENCH_FORCE_COMM") == "1"  # rehearsal: run the N > 1 plumbing with one rank
+    nccl = os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl"
+    fallback = False
+    if (n_ranks > 1 or force_comm) and nccl:
+        # one in-library RCCL all-reduce per step; torch.distributed only carries the unique id.  ncclCommInitRank is
+        # collective: the ranks first agree that every one of them can load RCCL, or none of them enters it
+        ok = torch.tensor([1.0 if eng.comm_available() else 0.0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) > 0:
-            comm_mode = "rccl-allreduce(f64[n_bins]) in-library, one per step"
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [eng.comm_unique_id()]
+                except Exception as e:
+                    log(f"rank 0: ncclGetUniqueId failed ({e})")
+            dist.broadcast_object_list(uid, src=0)  # every rank takes part, whatever rank 0 got
+            ok = torch.zeros(1, device="cuda")
+            if uid[0] is not None:
+                try:
+                    eng.comm_init(uid[0], rank, n_ranks)
+                    ok = torch.ones(1, device="cuda")
+                except Exception as e:
+                    log(f"rank {rank}: in-library RCCL init failed ({e})")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            comm_mode = "rccl-allreduce(f64 bin vector) in-library, one per step"
         else:
-            comm_mode = "torch.distributed all_reduce of the bin vector (fallback)"
-    elif world > 1:
+            # a communicator that only some ranks joined would dead-lock the first reweight: every rank drops its own
+            eng.comm_destroy()
+            if not allow_fallback:
+                log("in-library RCCL is not available on every rank and --allow-host-fallback was not given: no number is "
+                    "better than the number of a path that round-trips the bins through the host")
+                raise SystemExit(3)
+            fallback = True
+            comm_mode = "torch.distributed all_reduce of the bin vector through the host (FALLBACK, --allow-host-fallback)"
+    elif n_ranks > 1:
         comm_mode = "none (rehearsal backend: ranks do not exchange bins)"
 
-    fallback = comm_mode.startswith("torch.distributed")
     w2_tot = [None]
 
     def reduce_bins():
@@ -266,65 +259,163 @@ def main():
         el = float(t.item())
     k_ms, k_n = eng.timing_read(0)
     eng.timing_enable(False)
+    check = None
+    if args.check:  # LLH of a few laps, for the comparison with a one-rank run of the same sample
+        check = []
+        for i in range(3):
+            check.append(step(1000 + i))
+    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check)
+    eng.close()
+    return out
+
+
+def kernel_name(info):
+    if info.n_tiles_brick and info.n_tiles_uniform:
+        return "k_reweight_uniform<fill> + k_reweight_brick<fill> (spline eval + weight product + bin fill, fused; both launches timed together)"
+    if info.n_tiles_brick:
+        return "k_reweight_brick<fill> (ragged groups: spline eval + weight product + bin fill, fused)"
+    return "k_reweight_uniform<fill> (spline eval + weight product + bin fill, fused)"
+
+
+def workload_text(base, spec, n_ranks):
+    idx = CFG_INDEX.get(base.name, "?")
+    shard = "" if n_ranks == 1 else f", sharded by events over {n_ranks} GPUs (response-balanced contiguous blocks)"
+    return (f"BASELINE configs[{idx}] ({base.name}): {spec.n_events} events{' in ' + str(spec.n_samples) + ' samples' if spec.n_samples > 1 else ''}, "
+            f"{spec.n_params} {'TSpline3/TF1 (alternating)' if spec.mixed else 'TSpline3'} systematics x {spec.n_knots} knots "
+            f"(occupancy {spec.occupancy:g}), {spec.n_norm} norm systematics, pre-staged osc table, {spec.total_bins} bins, "
+            f"{STAT_NAME.get(int(spec.test_statistic), '?')} LLH{shard}")
+
+
+def roofline(base_name, m, per_gpu):
+    info, k_ms = m["info"], m["k_ms"]
+    tr = pmc_traffic(base_name, per_gpu)
+    ach = info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+    return {
+        "bound": "hbm",
+        "kernel": kernel_name(info),
+        "achieved": ach,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS if ach else None,
+        "traffic": tr["bytes"] if tr else None,
+        "traffic_source": tr["source"] if tr else None,
+        "alg_bytes_per_launch": int(info.alg_bytes_fused),
+        "avg_kernel_ms": k_ms,
+        "launches_timed": m["k_n"],
+        "event_sampling": f"every {EVENT_EVERY}th launch of the timed region carries a hipEvent pair stamped with the dispatch's own start/end (hipExtLaunchKernelGGL); rank 0's shard",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="auto", help="c1..c5; auto = c3 for 1-2 GPUs, c4 for 4 and 8 (BASELINE configs[2] / [3])")
+    ap.add_argument("--events", type=int, default=0, help="override the TOTAL number of events (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] line under `extra`")
+    ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--check", action="store_true",
+                    help="N > 1: rank 0 also runs the whole sample on its own GPU and compares the LLH of three laps (<= 1e-9 relative)")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N > 1 without in-library RCCL: time the torch.distributed host round trip instead of failing")
+    ap.add_argument("--spinup-seconds", type=float, default=2.0,
+                    help="untimed steps before the warm-up: the first ~1 s of GPU work on a fresh process shows one-off "
+                         "50-100 ms stalls (clock / runtime ramp-up) that would otherwise land in a short timed region")
+    args = ap.parse_args()
+
+    import torch  # device sync + torch.distributed (RCCL) plumbing only
+
+    from mach3_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if os.environ.get("M3_BENCH_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+        local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks share the card
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1 or os.environ.get("M3_BENCH_FORCE_COMM") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("M3_BENCH_BACKEND", "nccl")  # "gloo": plumbing rehearsal on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    cfg = args.config if args.config != "auto" else ("c3" if n_gpus <= 2 else "c4")
+    base = synth.CONFIGS[cfg]
+    spec = base.scaled(args.events) if args.events else base
+
+    m = measure(spec, rank, n_gpus, local_rank, args, dist, torch, args.allow_host_fallback)
+
+    check = None
+    if args.check and n_gpus > 1:
+        # the same sample, unsharded, on rank 0's GPU alone (the other ranks wait at the barrier below)
+        if rank == 0:
+            a1 = argparse.Namespace(**vars(args))
+            a1.steps, a1.warmup, a1.spinup_seconds = 1, 0, 0.0
+            os.environ["M3_BENCH_FORCE_COMM"] = "0"
+            one = measure(spec, 0, 1, local_rank, a1, None, torch, False)
+            rel = max(abs(x - y) / max(abs(y), 1.0) for x, y in zip(m["check"], one["check"]))
+            check = {"llh_sharded": m["check"], "llh_one_rank": one["check"], "max_rel_diff": rel, "ok": bool(rel <= 1e-9)}
+        dist.barrier()
 
     if rank == 0:
-        tr = pmc_traffic(args.config, per_gpu)
-        cfg_index = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}.get(base.name, "?")
-        stat_name = {0: "Poisson", 1: "Barlow-Beeston", 2: "IceCube", 3: "Pearson", 4: "Dembinski-Abdelmotteleb"}.get(int(spec.test_statistic), "?")
-        if info.n_tiles_brick and info.n_tiles_uniform:
-            kernel_name = "k_reweight_uniform<fill> + k_reweight_brick<fill> (spline eval + weight product + bin fill, fused; both launches timed together)"
-        elif info.n_tiles_brick:
-            kernel_name = "k_reweight_brick<fill> (ragged groups: spline eval + weight product + bin fill, fused)"
-        else:
-            kernel_name = "k_reweight_uniform<fill> (spline eval + weight product + bin fill, fused)"
-
+        per_gpu = m["e1"] - m["e0"]
         out = {
             "metric": "LLH evaluations/sec (MCMC steps/sec)",
-            "value": n_gpus * args.steps / el,
-            "unit": "steps/s" if n_gpus == 1 else f"steps/s x shards (one {per_gpu}-event shard per GPU)",
+            "value": args.steps / m["el"],
+            "unit": "steps/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * el / args.steps,
+            "ms_per_step": 1e3 * m["el"] / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[{cfg_index}] ({base.name}): {per_gpu} events/GPU, {spec.n_params} "
-                            f"{'TSpline3/TF1 (alternating)' if spec.mixed else 'TSpline3'} systematics x {spec.n_knots} knots "
-                            f"(occupancy {spec.occupancy:g}), {spec.n_norm} norm systematics, pre-staged osc table, "
-                            f"{spec.total_bins} bins, {stat_name} LLH",
+                "workload": workload_text(base, spec, n_gpus),
+                "total_events": spec.n_events,
                 "events_per_gpu": per_gpu,
-                "total_events": per_gpu * n_gpus,
-                "spline_responses_per_gpu": int(info.n_splines),
-                "comm": comm_mode,
-                "steps_per_s": args.steps / el,
-                "last_llh": llh,
+                "responses_rank0": int(m["info"].n_splines + m["info"].n_tf1),
+                "comm": m["comm"],
+                "last_llh": m["llh"],
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel_name,
-                "achieved": info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (info.alg_bytes_fused / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else None,
-                "traffic": tr["bytes"] if tr else None,
-                "traffic_source": tr["source"] if tr else None,
-                "alg_bytes_per_launch": int(info.alg_bytes_fused),
-                "avg_kernel_ms": k_ms,
-                "launches_timed": int(k_n),
-                "event_sampling": f"every {EVENT_EVERY}th launch of the timed region carries a hipEvent pair stamped with the dispatch's own start/end (hipExtLaunchKernelGGL)",
-            },
+            "roofline": roofline(base.name, m, per_gpu),
         }
+        if check is not None:
+            out["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(base.scaled(per_gpu))
+                out["cpu_baseline"] = cpu_baseline(spec)
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if n_gpus == 1 and not args.no_extra and cfg != "c2":
+            # round 1's line: BASELINE configs[1] (1e6 events x 128 TSpline3, dense: the uniform-tile kernel), same protocol
+            try:
+                a2 = argparse.Namespace(**vars(args))
+                a2.check = False
+                a2.spinup_seconds = min(args.spinup_seconds, 0.5)
+                c2 = synth.CONFIGS["c2"]
+                m2 = measure(c2, 0, 1, local_rank, a2, None, torch, False)
+                out["extra"] = {"configs[1]": {"workload": workload_text(c2, c2, 1), "value": args.steps / m2["el"], "unit": "steps/s",
+                                               "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}}
+            except Exception as e:
+                out["extra"] = {"configs[1]": {"failed": str(e)}}
         print(json.dumps(out), flush=True)
-    eng.close()
+        if check is not None and not check["ok"]:
+            raise SystemExit(4)
     if dist is not None:
         dist.destroy_process_group()
 

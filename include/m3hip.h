@@ -295,9 +295,19 @@ int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_par
  * per-bin rate vector (and of w2 while it is being updated) before the LLH kernel.
  * ---------------------------------------------------------------------------------- */
 #define M3HIP_UNIQUE_ID_BYTES 128
+/* 1 when librccl can be loaded in this process (no communicator is created): lets every rank agree on
+ * "in-library exchange or not" BEFORE the collective m3hip_comm_init, which would otherwise hang on the
+ * ranks that can while one cannot. */
+int m3hip_comm_available(void);
 int m3hip_comm_get_unique_id(void* out_id /*128 bytes*/);
 int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks);
 int m3hip_comm_destroy(m3hip_handle h);
+/* Validator of the exchange (also M3HIP_COMM_VALIDATE=1 in the environment of m3hip_comm_init):
+ * every m3hip_reweight additionally all-gathers the ranks' partial bin vectors, copies them to the host,
+ * sums them there in rank order and fails with M3HIP_ECOMM if the all-reduced vector differs by more than
+ * a few ulps per bin.  Costs a device synchronisation per step: for tests and first runs on a new node. */
+int m3hip_comm_set_validate(m3hip_handle h, int on);
+int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n_checked);
 
 /* ------------------------------------------------------------------------------------
  * Introspection / measurement

@@ -16,6 +16,8 @@
 
 #include "../../include/m3hip.h"
 #include "m3hip_kernels.h"
+
+#include <rccl/rccl.h>  // types and enum values only: the library itself is loaded with dlopen
 #include "m3hip_layout.h"
 
 using namespace m3hip;
@@ -25,24 +27,22 @@ namespace {
 constexpr int kRing = 4;  // parameter staging slots in flight
 constexpr int kInlineResolveMax = 8192;  // unique slots resolved inside k_prep; beyond that k_resolve runs
 
-struct m3hip_unique_id_t {  // same size/layout as ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
-  char internal[M3HIP_UNIQUE_ID_BYTES];
-};
-
 struct Chunk {
   void* d_spl = nullptr;
   void* d_tf1 = nullptr;
   uint32_t* d_words = nullptr;  // brick metadata streams
 };
 
-// RCCL is loaded on demand so that single-GPU users never touch it.
+// RCCL is loaded on demand so that single-GPU users never touch it (no link-time dependency); the header supplies the
+// types and enum values, so the calls through the dlsym'd pointers have RCCL's own signatures.
 struct Rccl {
   void* lib = nullptr;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, m3hip_unique_id_t, int) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool load(std::string* err) {
     if (lib) return true;
     lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -51,12 +51,20 @@ struct Rccl {
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *err = "librccl lacks nccl* symbols"; return false; }
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !AllGather || !CommDestroy) {
+      *err = "librccl lacks nccl* symbols";
+      dlclose(lib);
+      lib = nullptr;
+      return false;
+    }
     return true;
   }
+  std::string why(ncclResult_t r) const { return GetErrorString ? GetErrorString(r) : "error"; }
 };
+static_assert(sizeof(ncclUniqueId) == M3HIP_UNIQUE_ID_BYTES, "m3hip.h documents the unique id as 128 bytes");
 Rccl g_rccl;
 std::string g_create_err;
 
@@ -204,6 +212,14 @@ struct m3hip_ctx {
 
   // comm
   void* comm = nullptr;
+  // validator of the exchange: every rank's partial vector is gathered, copied to the host and summed there
+  // in rank order; the all-reduced vector must agree to <= 1e-15 relative per bin (M3HIP_COMM_VALIDATE=1)
+  bool comm_validate = false;
+  double* d_gather = nullptr;
+  size_t gather_cap = 0;
+  std::vector<double> h_gather, h_reduced;
+  double validate_max_rel = 0;
+  uint64_t validate_count = 0;
   int rank = 0, n_ranks = 1;
 
   // timing
@@ -437,6 +453,44 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.hist_lds = sizeof(double) * (a.fill_w2 ? 2 : 1) * size_t(h->n_bins) <= size_t(M3_HIST_LDS_MAX_BYTES) ? 1 : 0;
   a.tile_base = 0;
   return a;
+}
+
+// Validator, part 1 (before the all-reduce): all-gather of the ranks' partial vectors, to the host.
+int comm_validate_begin(m3hip_handle h, size_t n_msg) {
+  const size_t need = n_msg * size_t(h->n_ranks);
+  if (h->gather_cap < need) {
+    dev_free(h->d_gather); h->d_gather = nullptr;
+    const int rc = dev_alloc(h, &h->d_gather, need);
+    if (rc) return rc;
+    h->gather_cap = need;
+  }
+  const ncclResult_t r = g_rccl.AllGather(h->d_hist, h->d_gather, n_msg, ncclDouble, (ncclComm_t)h->comm, h->stream);
+  if (r != ncclSuccess) return fail(h, M3HIP_ECOMM, "ncclAllGather (validator): " + g_rccl.why(r));
+  h->h_gather.resize(need);
+  HIPCHK(h, hipMemcpyAsync(h->h_gather.data(), h->d_gather, sizeof(double) * need, hipMemcpyDeviceToHost, h->stream));
+  return M3HIP_OK;
+}
+// Part 2 (after it): the reduced vector to the host, against the host's own sum in rank order.
+int comm_validate_end(m3hip_handle h, size_t n_msg) {
+  h->h_reduced.resize(n_msg);
+  HIPCHK(h, hipMemcpyAsync(h->h_reduced.data(), h->d_hist, sizeof(double) * n_msg, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double worst = 0;
+  for (size_t i = 0; i < n_msg; ++i) {
+    long double sum = 0;
+    for (int r = 0; r < h->n_ranks; ++r) sum += h->h_gather[size_t(r) * n_msg + i];
+    const double ref = double(sum), got = h->h_reduced[i];
+    const double rel = std::fabs(got - ref) / std::max(std::fabs(ref), 1e-300);
+    if (!(got == ref)) worst = std::max(worst, rel);
+  }
+  h->validate_max_rel = std::max(h->validate_max_rel, worst);
+  h->validate_count++;
+  // n - 1 additions, each within half an ulp of its partial sum: the reduced value may differ from the correctly rounded
+  // one by about n ulps whatever order RCCL adds in
+  if (worst > 1.2e-16 * 2 * std::max(2, h->n_ranks))
+    return fail(h, M3HIP_ECOMM, "all-reduce validator: bin vector differs from the host-side sum of the ranks' partial vectors by " +
+                                    std::to_string(worst) + " relative");
+  return M3HIP_OK;
 }
 
 }  // namespace
@@ -1671,16 +1725,25 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (timed && (n_tiles || n_bricks)) h->pending = 0;
   HIPCHK(h, hipGetLastError());
   if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
-    // fold the 32 flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins), and w2
-    // only travels while it is still being accumulated
-    if (h->hist_rep > 1) launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, h->first_w2 ? 1 : 0, h->stream);  // one replica: nothing to fold
-    if (h->first_w2) h->w2_spread = false;
-    int r = g_rccl.AllReduce(h->d_hist, h->d_hist, size_t(h->n_bins), /*ncclDouble*/ 8, /*ncclSum*/ 0, h->comm, h->stream);
-    if (r == 0 && h->first_w2) {
-      double* w2 = h->d_hist + size_t(h->hist_rep) * h->n_bins;
-      r = g_rccl.AllReduce(w2, w2, size_t(h->n_bins), 8, 0, h->comm, h->stream);
+    // Fold the flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins).  While w2 is still being
+    // accumulated it travels in the SAME all-reduce: the fold parks its sum right behind mc's (in mc's second replica,
+    // which the fold has just emptied), one call moves [mc | w2], and k_unpark_w2 puts it back where k_llh looks for it.
+    const bool with_w2 = h->first_w2;
+    const bool parked = with_w2 && h->hist_rep > 1;
+    if (h->hist_rep > 1) launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, with_w2 ? 1 : 0, parked ? 1 : 0, h->stream);  // one replica: nothing to fold
+    if (with_w2) h->w2_spread = false;
+    const size_t n_msg = size_t(h->n_bins) * (with_w2 ? 2 : 1);  // one replica: w2 sits behind mc as it is
+    if (h->comm_validate) {
+      const int rc = comm_validate_begin(h, n_msg);
+      if (rc) return rc;
     }
-    if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+    ncclResult_t r = g_rccl.AllReduce(h->d_hist, h->d_hist, n_msg, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, M3HIP_ECOMM, "ncclAllReduce: " + g_rccl.why(r));
+    if (h->comm_validate) {
+      const int rc = comm_validate_end(h, n_msg);
+      if (rc) return rc;
+    }
+    if (parked) launch_unpark_w2(h->d_hist, h->hist_rep, h->n_bins, h->stream);
   }
   if (!h->update_w2) h->first_w2 = false;  // SampleHandlerFD.cpp:342
   const double t_d = now_s();
@@ -1825,12 +1888,20 @@ int m3hip_get_segments(m3hip_handle h, int16_t* segments, float* vals, int n_par
 
 /* ---------------------------------------------------------------- multi-GPU */
 
+int m3hip_comm_available(void) {
+  std::string err;
+  if (!g_rccl.load(&err)) { g_create_err = err; return 0; }
+  return 1;
+}
+
 int m3hip_comm_get_unique_id(void* out_id) try {
   if (!out_id) return M3HIP_EINVAL;
   std::string err;
   if (!g_rccl.load(&err)) return fail(nullptr, M3HIP_ECOMM, err);
-  int r = g_rccl.GetUniqueId(out_id);
-  if (r != 0) return fail(nullptr, M3HIP_ECOMM, "ncclGetUniqueId failed");
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, M3HIP_ECOMM, "ncclGetUniqueId: " + g_rccl.why(r));
+  memcpy(out_id, &id, sizeof(id));
   return M3HIP_OK;
 } M3_API_CATCH(nullptr)
 
@@ -1841,14 +1912,28 @@ int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks
   if (!g_rccl.load(&err)) return fail(h, M3HIP_ECOMM, err);
   HIPCHK(h, hipSetDevice(h->device));
   m3hip_comm_destroy(h);
-  m3hip_unique_id_t id;
-  memcpy(id.internal, unique_id, M3HIP_UNIQUE_ID_BYTES);
-  void* comm = nullptr;
-  int r = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
-  if (r != 0) return fail(h, M3HIP_ECOMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return fail(h, M3HIP_ECOMM, "ncclCommInitRank: " + g_rccl.why(r));
   h->comm = comm;
   h->rank = rank;
   h->n_ranks = n_ranks;
+  { const char* f = getenv("M3HIP_COMM_VALIDATE"); h->comm_validate = f && f[0] == '1'; }
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_comm_set_validate(m3hip_handle h, int on) try {
+  if (!h) return M3HIP_EINVAL;
+  h->comm_validate = on != 0;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n_checked) try {
+  if (!h) return M3HIP_EINVAL;
+  if (max_rel_diff) *max_rel_diff = h->validate_max_rel;
+  if (n_checked) *n_checked = h->validate_count;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -1856,9 +1941,11 @@ int m3hip_comm_destroy(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (h->comm) {
     (void)hipStreamSynchronize(h->stream);
-    g_rccl.CommDestroy(h->comm);
+    g_rccl.CommDestroy((ncclComm_t)h->comm);
     h->comm = nullptr;
   }
+  dev_free(h->d_gather); h->d_gather = nullptr;
+  h->gather_cap = 0;
   h->rank = 0;
   h->n_ranks = 1;
   return M3HIP_OK;

@@ -248,6 +248,7 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
 constexpr int M3_HIST_LDS_MAX_BYTES = 20 * 1024;
 void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
-void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s);
+void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2, hipStream_t s);
+void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s);
 
 }  // namespace m3hip

@@ -1106,25 +1106,65 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // fold the flush replicas into replica 0 (same fixed order as k_llh), so that the multi-GPU
-// all-reduce moves n_bins doubles instead of hist_rep * n_bins
-__global__ __launch_bounds__(256) void k_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2) {
-  for (int i = threadIdx.x; i < n_bins * (with_w2 ? 2 : 1); i += 256) {
-    double* base = hist + (i < n_bins ? i : (size_t)hist_rep * n_bins + (i - n_bins));
-    double m = 0.0;
-    for (int r0 = 0; r0 < hist_rep; r0 += 8) {
-      double am[8];
+// all-reduce moves n_bins doubles instead of hist_rep * n_bins.  park_w2 (hist_rep > 1): w2's sum goes right behind
+// mc's -- into mc's second replica, which this fold has just emptied -- so that ONE all-reduce moves [mc | w2].
+__global__ __launch_bounds__(256) void k_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2) {
+  double sums[8];  // a slice of 8 x 256 values is folded into registers before any of its replicas is rewritten
+  const int n = n_bins * (with_w2 ? 2 : 1);
+  for (int i0 = 0; i0 < n; i0 += 256 * 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * 256 + (int)threadIdx.x;
+      double m = 0.0;
+      if (i < n) {
+        const double* base = hist + (i < n_bins ? i : (size_t)hist_rep * n_bins + (i - n_bins));
+        for (int r0 = 0; r0 < hist_rep; r0 += 8) {
+          double am[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) m += am[u];
+          for (int u = 0; u < 8; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) m += am[u];
+        }
+      }
+      sums[q] = m;
     }
-    base[0] = m;
-    for (int r = 1; r < hist_rep; ++r) base[(size_t)r * n_bins] = 0.0;
+    __syncthreads();  // every sum of this slice is taken before any replica is rewritten (w2's parking place is an mc replica)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * 256 + (int)threadIdx.x;
+      if (i < n) {
+        double* base = hist + (i < n_bins ? i : (size_t)hist_rep * n_bins + (i - n_bins));
+        for (int r = 0; r < hist_rep; ++r) base[(size_t)r * n_bins] = 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q * 256 + (int)threadIdx.x;
+      if (i < n) {
+        if (i < n_bins) hist[i] = sums[q];
+        else if (park_w2) hist[(size_t)n_bins + (i - n_bins)] = sums[q];
+        else hist[(size_t)hist_rep * n_bins + (i - n_bins)] = sums[q];
+      }
+    }
+    __syncthreads();
   }
 }
 
-void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, hipStream_t s) {
-  hipLaunchKernelGGL(k_fold_hist, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins, with_w2);
+void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2, hipStream_t s) {
+  hipLaunchKernelGGL(k_fold_hist, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins, with_w2, park_w2);
+}
+
+// after the all-reduce of [mc | w2]: w2 back from its parking place (mc's second replica) to its own first replica
+__global__ __launch_bounds__(256) void k_unpark_w2(double* hist, int hist_rep, int n_bins) {
+  for (int i = threadIdx.x; i < n_bins; i += 256) {
+    hist[(size_t)hist_rep * n_bins + i] = hist[(size_t)n_bins + i];
+    hist[(size_t)n_bins + i] = 0.0;
+  }
+}
+
+void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpark_w2, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins);
 }
 
 // sum of one bin over the flush replicas, in replica order (fixed => reproducible), 16 loads in flight

@@ -92,9 +92,23 @@ class Engine:
             raise M3HipError(rc, self.lib.m3hip_last_error(None).decode())
         return buf.raw
 
+    def comm_available(self) -> bool:
+        return bool(self.lib.m3hip_comm_available())
+
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         assert len(unique_id) == capi.UNIQUE_ID_BYTES
         self._chk(self.lib.m3hip_comm_init(self.h, C.c_char_p(unique_id), rank, n_ranks))
+
+    def comm_destroy(self):
+        self._chk(self.lib.m3hip_comm_destroy(self.h))
+
+    def comm_set_validate(self, on=True):
+        self._chk(self.lib.m3hip_comm_set_validate(self.h, int(on)))
+
+    def comm_last_validation(self):
+        rel, n = C.c_double(0), C.c_uint64(0)
+        self._chk(self.lib.m3hip_comm_last_validation(self.h, C.byref(rel), C.byref(n)))
+        return rel.value, n.value
 
 
 class SMonolith:

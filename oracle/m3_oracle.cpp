@@ -22,8 +22,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <limits>
+#include <new>
 #include <vector>
 
 #ifdef MULTITHREAD
@@ -404,6 +406,47 @@ struct FastSplineInfo_o {
   const double* splineParsPointer = nullptr;
 };
 
+// Arrays that are written for the first time inside an OpenMP loop with the static schedule of the loops that later
+// walk them, so that on a multi-socket host every page lands on the memory node of the thread that will use it
+// (first touch).  The reference allocates on one thread; this only matters for the TIMED baseline, which should not be
+// handicapped by a placement the GPU side does not suffer from (bench.py: cpu_baseline).  Serial build: plain arrays.
+template <class T>
+struct HomedArray {
+  T* p = nullptr;
+  uint64_t n = 0;
+  HomedArray() = default;
+  HomedArray(const HomedArray&) = delete;
+  HomedArray& operator=(const HomedArray&) = delete;
+  ~HomedArray() { release(); }
+  void release() {
+    if (!p) return;
+#ifdef MULTITHREAD
+#pragma omp parallel for schedule(static)
+#endif
+    for (uint64_t i = 0; i < n; ++i) p[i].~T();
+    std::free(p);
+    p = nullptr;
+    n = 0;
+  }
+  template <class F>
+  void build(uint64_t count, F&& make) {  // make(i) -> T, called on the thread that owns element i
+    release();
+    n = count;
+    p = static_cast<T*>(std::malloc(sizeof(T) * (count ? count : 1)));
+#ifdef MULTITHREAD
+#pragma omp parallel for schedule(static)
+#endif
+    for (uint64_t i = 0; i < count; ++i) new (&p[i]) T(make(i));
+  }
+  void assign(uint64_t count, const T& v) { build(count, [&](uint64_t) { return v; }); }
+  void copy_from(const T* src, uint64_t count) { build(count, [&](uint64_t i) { return src[i]; }); }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](uint64_t i) { return p[i]; }
+  const T& operator[](uint64_t i) const { return p[i]; }
+  uint64_t size() const { return n; }
+};
+
 struct m3o_monolith {
   uint64_t NEvents = 0;
   short nParams = 0;
@@ -424,9 +467,13 @@ struct m3o_monolith {
   std::vector<short> SplineSegments;
   std::vector<float> ParamValues;
   std::vector<short> CurrSegState;  // mirror of SplineInfoArray[i].CurrSegment for inspection
-  std::vector<float> cpu_weights_spline_var;
-  std::vector<float> cpu_weights_tf1_var;
-  std::vector<float> cpu_total_weights;
+  HomedArray<float> cpu_weights_spline_var;
+  HomedArray<float> cpu_weights_tf1_var;
+  HomedArray<float> cpu_total_weights;
+  // m3o_monolith_localise: owned, first-touched copies of the borrowed arrays
+  HomedArray<float> own_coeff_many, own_coeff_TF1_many;
+  HomedArray<unsigned int> own_nKnots_arr, own_nParamPerEvent, own_nParamPerEvent_tf1;
+  HomedArray<int16_t> own_paramNo_arr, own_paramNo_TF1_arr;
 };
 
 m3o_monolith* m3o_monolith_create(uint64_t n_events, int n_params, int max_knots,
@@ -472,6 +519,25 @@ m3o_monolith* m3o_monolith_create(uint64_t n_events, int n_params, int max_knots
 }
 
 void m3o_monolith_destroy(m3o_monolith* m) { delete m; }
+
+// Re-home the borrowed reference-layout arrays: copies them, inside OpenMP loops, into arrays the oracle owns (see
+// HomedArray).  total_nknots = knots in coeff_many.  The values, the layout and every computation stay the same.
+void m3o_monolith_localise(m3o_monolith* m, uint64_t total_nknots) {
+  m->own_coeff_many.copy_from(m->coeff_many, 4 * total_nknots);
+  m->coeff_many = m->own_coeff_many.data();
+  m->own_nKnots_arr.copy_from(m->nKnots_arr, m->NSplines_valid);
+  m->nKnots_arr = m->own_nKnots_arr.data();
+  m->own_paramNo_arr.copy_from(m->paramNo_arr, m->NSplines_valid);
+  m->paramNo_arr = m->own_paramNo_arr.data();
+  m->own_coeff_TF1_many.copy_from(m->coeff_TF1_many, 2 * m->NTF1_valid);
+  m->coeff_TF1_many = m->own_coeff_TF1_many.data();
+  m->own_paramNo_TF1_arr.copy_from(m->paramNo_TF1_arr, m->NTF1_valid);
+  m->paramNo_TF1_arr = m->own_paramNo_TF1_arr.data();
+  m->own_nParamPerEvent.copy_from(m->nParamPerEvent, 2 * m->NEvents);
+  m->nParamPerEvent = m->own_nParamPerEvent.data();
+  m->own_nParamPerEvent_tf1.copy_from(m->nParamPerEvent_tf1, 2 * m->NEvents);
+  m->nParamPerEvent_tf1 = m->own_nParamPerEvent_tf1.data();
+}
 
 // ref: Splines/SplineMonolith.h:44-46
 void m3o_monolith_set_spline_pointers(m3o_monolith* m, const double* const* ptrs) {
@@ -1010,13 +1076,13 @@ struct KinematicCut_o {
 
 struct m3o_sample {
   std::vector<KinematicCut_o> Selection;
-  std::vector<double> kin_nominal, kin_shifted;  // KinVar pointers alias kin_shifted
+  HomedArray<double> kin_nominal, kin_shifted;  // KinVar pointers alias kin_shifted
   int kin_stride = 1;
   std::vector<FuncShift_o> shifts;
   const m3o_binning* Binning = nullptr;
   m3o_monolith* SplineHandler = nullptr;
   m3o_binned* BinnedHandler = nullptr;
-  std::vector<EventInfo_o> MCSamples;
+  HomedArray<EventInfo_o> MCSamples;
   std::vector<double> SampleHandlerFD_array, SampleHandlerFD_array_w2, SampleHandlerFD_data;
   int fTestStatistic = M3O_kPoisson;
   bool FirstTimeW2 = true;  // ref: SampleHandlerFD.cpp:28-30
@@ -1034,12 +1100,12 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
   m3o_sample* s = new m3o_sample();
   s->Binning = b;
   s->SplineHandler = mono;
-  s->MCSamples.resize(n_events);
   s->kin_stride = kin_stride;
-  s->kin_nominal.assign(kin, kin + n_events * uint64_t(kin_stride));
-  s->kin_shifted = s->kin_nominal;
-  for (uint64_t e = 0; e < n_events; ++e) {
-    EventInfo_o& ev = s->MCSamples[e];
+  s->kin_nominal.copy_from(kin, n_events * uint64_t(kin_stride));
+  s->kin_shifted.copy_from(kin, n_events * uint64_t(kin_stride));
+  // every event is set up by the thread that will fill it (its pointer vectors live on that thread's memory node)
+  s->MCSamples.build(n_events, [&](uint64_t e) {
+    EventInfo_o ev;
     ev.NominalSample = sample_id ? sample_id[e] : 0;
     const int ndim = int(b->SampleBinning[ev.NominalSample].BinEdges.size());
     ev.KinVar.resize(ndim);
@@ -1058,7 +1124,8 @@ m3o_sample* m3o_sample_create(const m3o_binning* b, uint64_t n_events, const int
 #ifndef M3O_FLOAT_T_DOUBLE
     if (mono) ev.total_weight_pointers.push_back(&mono->cpu_total_weights[e]);
 #endif
-  }
+    return ev;
+  });
   const int nb = b->TotalNumberOfBins;
   s->SampleHandlerFD_array.assign(nb, 0.);
   s->SampleHandlerFD_array_w2.assign(nb, 0.);

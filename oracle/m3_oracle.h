@@ -84,6 +84,8 @@ m3o_monolith* m3o_monolith_create(uint64_t n_events, int n_params, int max_knots
                                   const unsigned int* n_param_per_event,
                                   const unsigned int* n_param_per_event_tf1);
 void m3o_monolith_destroy(m3o_monolith* m);
+/* timed baseline only: copy the borrowed arrays into owned ones inside OpenMP loops (first-touch page placement) */
+void m3o_monolith_localise(m3o_monolith* m, uint64_t total_nknots);
 /* SMonolith::setSplinePointers (SplineMonolith.h:44-46) */
 void m3o_monolith_set_spline_pointers(m3o_monolith* m, const double* const* ptrs);
 /* SMonolith::Evaluate CPU branch (SplineMonolith.cpp:712-723) */

@@ -31,6 +31,7 @@ def load(variant="serial"):
     for n in ("m3o_monolith_destroy", "m3o_monolith_evaluate", "m3o_monolith_find_spline_segment",
               "m3o_monolith_calc_spline_weights", "m3o_monolith_calc_total_event_weight"):
         getattr(lib, n).argtypes = [vp]; getattr(lib, n).restype = None
+    lib.m3o_monolith_localise.argtypes = [vp, u64]; lib.m3o_monolith_localise.restype = None
     lib.m3o_monolith_set_spline_pointers.argtypes = [vp, vp]; lib.m3o_monolith_set_spline_pointers.restype = None
     lib.m3o_monolith_set_vals_segments.argtypes = [vp, vp, vp]; lib.m3o_monolith_set_vals_segments.restype = None
     for n in ("m3o_monolith_total_weights", "m3o_monolith_spline_weights", "m3o_monolith_tf1_weights",
@@ -97,6 +98,11 @@ class OracleMonolith:
             ch["coeff_many"].ctypes.data, ch["nknots_arr"].ctypes.data, ch["param_no"].ctypes.data, self.T,
             ch["coeff_tf1"].ctypes.data, ch["param_no_tf1"].ctypes.data, ch["npe"].ctypes.data, ch["npe_tf1"].ctypes.data)
         self._ptrs = None
+        self._nknots = ch["total_nknots"]
+
+    def localise(self):
+        """timed baseline: move the borrowed arrays into oracle-owned ones first touched inside OpenMP loops"""
+        self.lib.m3o_monolith_localise(self.h, self._nknots)
 
     def set_spline_pointers(self, par: np.ndarray, index=None):
         idx = np.arange(self.P) if index is None else np.asarray(index)
@@ -286,9 +292,9 @@ class OracleSample:
             self.h = None
 
 
-def build_oracle_from_synth(spec, e0, e1, variant="serial"):
+def build_oracle_from_synth(spec, e0, e1, variant="serial", localise=False):
     """Oracle objects over events [e0,e1) of a synthetic spec (one chunk).
-    Returns (mono, sample, par_vector, chunk, events)."""
+    Returns (mono, sample, par_vector, chunk, events).  localise: first-touch placement for the timed baseline."""
     from mach3_amd import synth
 
     lib = load(variant)
@@ -297,6 +303,8 @@ def build_oracle_from_synth(spec, e0, e1, variant="serial"):
     ev = synth.events_chunk(spec, e0, e1)
     par = synth.params(spec, 0)
     mono = OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    if localise:
+        mono.localise()
     mono.set_spline_pointers(par)
     b = OracleBinning(lib)
     edges = synth.bin_edges(spec)
