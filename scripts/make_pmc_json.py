@@ -28,7 +28,7 @@ for k, v in K.items():
             v["rocprof_avg_kernel_ns"] = ns
             v["rocprof_calls"] = int(stats[k]["Calls"])
             v["achieved_GBps_from_rocprof"] = ALG / ns
-json.dump({"round": 1, "version": version, "events_per_gpu": bench["config"]["events_per_gpu"] if bench else 1000000,
+json.dump({"round": int(os.environ.get("M3_ROUND", "2")), "version": version, "events_per_gpu": bench["config"]["events_per_gpu"] if bench else 1000000,
            "config": bench["config"]["workload"] if bench else "c2 (1e6 events, 128 TSpline3 x 7 knots, dense), 1x MI355X",
            "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --spinup-seconds 0 "
                       "--no-cpu-baseline (one pass per counter); kernel stats: rocprofv3 --kernel-trace --stats -- python3 bench.py",

@@ -1,5 +1,6 @@
-"""BASELINE configs[1] at FULL size (1e6 events x 128 TSpline3 x 7 knots) through the C ABI, checked by
-size-independent properties plus exact comparison on event windows the oracle can afford:
+"""BASELINE configs at FULL size through the C ABI -- configs[1] and configs[2] whole, configs[3] and configs[4] at the
+shard one of their eight GPUs holds -- checked by size-independent properties plus exact comparison on event windows
+the oracle can afford:
   - event windows [e0, e1) re-generated on the CPU (the generator is chunk-independent): spline weights
     and full event weights bit-exact against the serial oracle,
   - Asimov: LLH == 0 at the data point,
@@ -65,3 +66,85 @@ def test_config2_full_size_properties():
         parts.append(s2.GetMCArray())
         e2.close()
     assert np.allclose(parts[0] + parts[1], mc_whole, rtol=1e-11, atol=0)
+
+
+def _check_full_size(spec, e0, e1, windows, chunk_events=131072, laps=(1, 2), shard_check=True):
+    """properties of events [e0, e1) of `spec` on one GPU (see the module docstring); windows are relative to e0"""
+    E = e1 - e0
+    eng, mono, sh, par = build_from_synth(spec, chunk_events=chunk_events, event_range=(e0, e1))
+    info = eng.info()
+    assert info.n_events == E
+    ns, nt = 0, 0
+    for a in range(e0, e1, 1 << 20):
+        s_, t_ = synth.count(spec, a, min(e1, a + (1 << 20)))
+        ns, nt = ns + s_, nt + t_
+    assert (info.n_splines, info.n_tf1) == (ns, nt)
+    assert info.alg_bytes_fused == 16 * ns + 8 * nt + 8 * E
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    data = sh.GetMCArray()
+    w2_first = sh.GetW2Array()
+    sh.AddData(data)
+    assert sh.GetLikelihood() == 0.0                      # Asimov (every bin: data == mc)
+    oracles = [ob.build_oracle_from_synth(spec, e0 + a, e0 + b) for a, b in windows]
+    bins_all = np.concatenate([synth.events_chunk(spec, a, min(e1, a + 500_000))["bin_idx"] for a in range(e0, e1, 500_000)])
+    assert np.array_equal(sh.GetEventBins(0, 4096) if hasattr(sh, "GetEventBins") else bins_all[:4096], bins_all[:4096])
+    mc = None
+    for lap in laps:
+        par[:] = synth.params(spec, lap)
+        llh = sh.Step()
+        assert llh > 0
+        mc = sh.GetMCArray()
+        ew = sh.GetEventWeights(0, E)
+        sel = (ew > 0) & (bins_all >= 0)                  # conservation, in fp64 (float weights into double bins)
+        ref = np.bincount(bins_all[sel], weights=ew[sel].astype(np.float64), minlength=spec.total_bins)
+        assert np.allclose(mc, ref, rtol=1e-10, atol=0)
+        assert np.array_equal(sh.GetW2Array(), w2_first)  # W2 frozen after the first Reweight
+        for (a, b), (omono, osamp, opar, ch, ev) in zip(windows, oracles):
+            opar[:] = par
+            osamp.reweight()
+            assert np.array_equal(sh.GetSplineWeights(a, b - a).view(np.uint32), omono.total_weights.view(np.uint32))
+            assert np.array_equal(ew[a:b].view(np.uint32), osamp.event_weights().view(np.uint32))
+    for omono, osamp, *_ in oracles:
+        osamp.close()
+        omono.close()
+    eng.close()
+    if shard_check:  # two ranks' worth of events on two handles: what the all-reduce would sum
+        cut = e0 + ((E // 2 + 1023) // 1024) * 1024
+        parts = []
+        for a, b in ((e0, cut), (cut, e1)):
+            e2, m2, s2, p2 = build_from_synth(spec, chunk_events=chunk_events, event_range=(a, b))
+            p2[:] = synth.params(spec, laps[-1])
+            s2.Reweight()
+            parts.append(s2.GetMCArray())
+            e2.close()
+        assert np.allclose(parts[0] + parts[1], mc, rtol=1e-10, atol=0)
+    return info
+
+
+def test_config3_full_size_properties():
+    """configs[2]: 1e7 events, 512 mixed TSpline3 / TF1 parameters at occupancy 1/16, Barlow-Beeston: 9 766 bricks.  In the
+    reference's layout this monolith holds more than 2^32 coefficient floats -- past its `unsigned int` offsets; here it
+    is uploaded in 77 chunks with chunk-local offsets, and the LAST events are checked bit for bit like the first."""
+    spec = synth.CONFIGS["c3"]
+    E = spec.n_events
+    info = _check_full_size(spec, 0, E, [(0, 2500), (5_000_000, 5_002_048), (E - 3000, E)])
+    assert info.n_tiles_brick == (E + 1023) // 1024 and info.n_tiles_uniform == 0
+    assert info.n_splines * spec.n_knots * 4 > 2 ** 32
+
+
+def test_config4_shard_properties():
+    """configs[3]: four samples x 1e7 events (800 bins); the shard one of eight GPUs holds: 5e6 events of all four samples"""
+    spec = synth.CONFIGS["c4"]
+    per = spec.n_events // 8
+    info = _check_full_size(spec, 3 * per, 4 * per, [(0, 2500), (per - 2048, per)], laps=(1,))
+    assert info.n_samples == 4 and info.n_bins == 800
+
+
+def test_config5_shard_properties():
+    """configs[4]: 1e8 events, 1 024 parameters at occupancy 1/64, beam + atmospheric oscillation tables (204 000 pre-staged
+    weights); the shard one of eight GPUs holds: 1.25e7 events"""
+    spec = synth.CONFIGS["c5"]
+    per = spec.n_events // 8
+    info = _check_full_size(spec, 5 * per, 6 * per, [(0, 3000), (per - 2048, per)], laps=(1,), shard_check=False)
+    assert info.n_params == 1024 and info.n_tiles_brick == (per + 1023) // 1024
