@@ -67,8 +67,12 @@ int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes);
 /* Pinned host buffers.  Replaces InitGPU_Segments / InitGPU_Vals and the pinned
  * cpu_total_weights of InitGPU_SplineMonolith (gpuSplineUtils.cu:116-171), and
  * CleanupGPU_Segments / the cudaFreeHost in CleanupGPU_SplineMonolith (:519-570). */
+/* h may be NULL (current device): the reference allocates its pinned segment / value arrays through a still-null
+ * gpu_spline_handler, before the GPU object exists (SplineMonolith.cpp:82-83, 271). */
 int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes);
 int m3hip_free_pinned(m3hip_handle h, void* ptr);
+/* SynchroniseSplines() (gpuSplineUtils.cu:71-73: cudaDeviceSynchronize), a free function in the reference */
+int m3hip_device_synchronize(void);
 
 /*
  * One-time upload of the flattened monolith.  Replaces InitGPU_SplineMonolith +

@@ -31,7 +31,7 @@ class BinnedSplineHandlerT : public SplineBase {
                        const std::vector<short>& npts, const std::vector<int>& coeffindexvec_,
                        const std::vector<int>& uniquesplinevec_Monolith_, const std::vector<int>& uniquecoeffindices_,
                        const std::vector<FloatT>& xcoeff_arr, const std::vector<FloatT>& manycoeff_arr, int device_id = 0)
-      : gpu(new SMonolithGPU(device_id)), MonolithSize(int(coeffindexvec_.size())), nEvents(n_events) {
+      : gpu(SMonolithGPU::make_handler(device_id)), MonolithSize(int(coeffindexvec_.size())), nEvents(n_events) {
     nParams = n_unique_params;
     M3HIP_CALL(gpu->Handle(), Upload(gpu->Handle(), n_events, nParams, max_knots, xpts.data(), npts.data(), MonolithSize, coeffindexvec_.data(),
                                      uniquesplinevec_Monolith_.data(), int(uniquecoeffindices_.size()), uniquecoeffindices_.data(),

@@ -123,7 +123,7 @@ class BinningHandler {
   /// ref: Samples/BinningHandler.cpp:294-307
   int FindNominalBin(int iSample, int iDim, double Var) const {
     const auto& e = Samples[iSample].Edges[iDim];
-    if (Var < e.front() || Var >= e.back()) return M3::UnderOverFlowBin;
+    if (!(Var >= e.front() && Var < e.back())) return M3::UnderOverFlowBin;  // written so that a NaN is out of range (the device does the same)
     return int(std::upper_bound(e.begin(), e.end(), Var) - e.begin()) - 1;
   }
   /// Bins are [lo, hi); a value outside any axis gives UnderOverFlowBin.  NomBin is the cached
@@ -136,7 +136,7 @@ class BinningHandler {
       const auto& e = s.Edges[d];
       const double v = *KinVar[d];
       const int n = int(e.size()) - 1;
-      if (v < e[0] || v >= e[n]) return M3::UnderOverFlowBin;
+      if (!(v >= e[0] && v < e[n])) return M3::UnderOverFlowBin;  // NaN: out of range, not bin n
       int b = NomBin[d];
       if (!(b > M3::UnderOverFlowBin && v >= e[b] && v < e[b + 1])) {
         if (b > 0 && v < e[b] && v >= e[b - 1]) b = b - 1;

@@ -39,34 +39,72 @@ struct SplineMonoStruct {
     if ((expr) != M3HIP_OK) throw MaCh3Exception(__FILE__, __LINE__, m3hip_last_error(handle)); \
   } while (0)
 
-/// The GPU backend, method for method (ref: Splines/gpuSplineUtils.cuh:63-218).
+/// SynchroniseSplines(), a free function in the reference (ref: Splines/gpuSplineUtils.cu:71-73)
+inline void SynchroniseSplines() { M3HIP_CALL(nullptr, m3hip_device_synchronize()); }
+
+/// The GPU backend: same methods, same argument lists as the reference's class (ref: Splines/gpuSplineUtils.cuh:63-218),
+/// so the call sites of Splines/SplineMonolith.cpp:82-83, 271-303, 706 and 619-637 compile against it unchanged
+/// (tests/cpp/seam2_callsites.cpp).  Every method is a thin call into libm3hip.so.
 class SMonolithGPU {
  public:
-  explicit SMonolithGPU(int device_id = 0) {
-    if (m3hip_create(device_id, &h) != M3HIP_OK) throw MaCh3Exception(__FILE__, __LINE__, m3hip_last_error(nullptr));
+  SMonolithGPU() {
+    if (m3hip_create(default_device(), &h) != M3HIP_OK) throw MaCh3Exception(__FILE__, __LINE__, m3hip_last_error(nullptr));
   }
   virtual ~SMonolithGPU() { m3hip_destroy(h); }
   SMonolithGPU(const SMonolithGPU&) = delete;
   SMonolithGPU& operator=(const SMonolithGPU&) = delete;
+  /// device of the SMonolithGPU objects created from now on (the reference has one device, Manager/gpuUtils.cu:71)
+  static int& default_device() {
+    static int device = 0;
+    return device;
+  }
+  static SMonolithGPU* make_handler(int device_id) {
+    default_device() = device_id;
+    return new SMonolithGPU();
+  }
 
-  /// pinned cpu_total_weights (ref: gpuSplineUtils.cu:116-171; device buffers are sized at upload)
+  /// pinned cpu_total_weights (ref: gpuSplineUtils.cu:116-171; the device buffers are sized at upload)
   void InitGPU_SplineMonolith(float** cpu_total_weights, int n_events, unsigned int /*total_nknots*/,
                               unsigned int /*n_splines*/, unsigned int /*n_tf1*/, int /*Eve_size*/) {
     M3HIP_CALL(h, m3hip_alloc_pinned(h, reinterpret_cast<void**>(cpu_total_weights), sizeof(float) * size_t(n_events)));
   }
-  void InitGPU_Segments(short int** segment) { M3HIP_CALL(h, m3hip_alloc_pinned(h, reinterpret_cast<void**>(segment), sizeof(short) * size_t(n_params_hint))); }
-  void InitGPU_Vals(float** vals) { M3HIP_CALL(h, m3hip_alloc_pinned(h, reinterpret_cast<void**>(vals), sizeof(float) * size_t(n_params_hint))); }
-  /// one-time upload (ref: gpuSplineUtils.cu:174-333); npts = FastSplineInfo.nPts per parameter
-  void CopyToGPU_SplineMonolith(SplineMonoStruct* cpu_spline_handler, const std::vector<float>& cpu_many_array_TF1,
-                                const std::vector<short int>& cpu_paramNo_arr_TF1, int n_events,
-                                const std::vector<unsigned int>& cpu_nParamPerEvent,
-                                const std::vector<unsigned int>& cpu_nParamPerEvent_TF1, int n_params,
-                                unsigned int n_splines, short int spline_size, unsigned int total_nknots,
-                                unsigned int n_tf1, const std::vector<short int>& npts) {
-    M3HIP_CALL(h, m3hip_upload_monolith(h, uint64_t(n_events), n_params, spline_size, cpu_spline_handler->coeff_x.data(), npts.data(),
-                                        cpu_spline_handler->coeff_many.data(), total_nknots, cpu_spline_handler->nKnots_arr.data(),
-                                        cpu_spline_handler->paramNo_arr.data(), n_splines, cpu_many_array_TF1.data(),
-                                        cpu_paramNo_arr_TF1.data(), n_tf1, cpu_nParamPerEvent.data(), cpu_nParamPerEvent_TF1.data()));
+  /// Pinned segment / value arrays.  The reference calls these two through a gpu_spline_handler that is still null
+  /// (SplineMonolith.cpp:82-83, before `new SMonolithGPU()` at :271): they must not touch `this`, and they cannot
+  /// know the number of parameters -- so they are sized for the most a `short` parameter index can address.
+  void InitGPU_Segments(short int** segment) {
+    M3HIP_CALL(nullptr, m3hip_alloc_pinned(nullptr, reinterpret_cast<void**>(segment), sizeof(short) * size_t(32767)));
+  }
+  void InitGPU_Vals(float** vals) {
+    M3HIP_CALL(nullptr, m3hip_alloc_pinned(nullptr, reinterpret_cast<void**>(vals), sizeof(float) * size_t(32767)));
+  }
+  /// one-time upload (ref: gpuSplineUtils.cu:174-333), vectors by value as in the reference.  The knot count of a
+  /// parameter (FastSplineInfo.nPts, which the engine's re-layout needs and the reference's argument list lacks) is
+  /// recovered from the arrays themselves: spline s owns knots nKnots_arr[s] .. nKnots_arr[s+1], and all splines of
+  /// a parameter have the same count (ref: SplineMonolith.cpp:162-164).  Events go up in slices (multiples of the
+  /// engine's 1024-event groups), so the pinned staging stays bounded whatever the size of the sample; the
+  /// {count,start} pairs index the shared arrays, so no data moves on the host.
+  void CopyToGPU_SplineMonolith(SplineMonoStruct* cpu_spline_handler, std::vector<float> cpu_many_array_TF1,
+                                std::vector<short int> cpu_paramNo_arr_TF1, int n_events, std::vector<unsigned int> cpu_nParamPerEvent,
+                                std::vector<unsigned int> cpu_nParamPerEvent_TF1, int n_params, unsigned int n_splines,
+                                short int spline_size, unsigned int total_nknots, unsigned int n_tf1) {
+    std::vector<short int> npts(size_t(n_params), 0);
+    for (unsigned int s = 0; s < n_splines; ++s) {
+      const unsigned int next = s + 1 < n_splines ? cpu_spline_handler->nKnots_arr[s + 1] : total_nknots;
+      const short int n = short(next - cpu_spline_handler->nKnots_arr[s]);
+      short int& np = npts[size_t(cpu_spline_handler->paramNo_arr[s])];
+      if (np != 0 && np != n) throw MaCh3Exception(__FILE__, __LINE__, "splines of one parameter differ in their number of knots");
+      np = n;
+    }
+    M3HIP_CALL(h, m3hip_monolith_begin(h, n_params, spline_size, cpu_spline_handler->coeff_x.data(), npts.data()));
+    const uint64_t slice = upload_slice_events();
+    for (uint64_t e0 = 0; e0 < uint64_t(n_events); e0 += slice) {
+      const uint64_t n = std::min<uint64_t>(slice, uint64_t(n_events) - e0);
+      M3HIP_CALL(h, m3hip_monolith_append(h, n, cpu_spline_handler->coeff_many.data(), total_nknots, cpu_spline_handler->nKnots_arr.data(),
+                                          cpu_spline_handler->paramNo_arr.data(), n_splines, cpu_many_array_TF1.data(),
+                                          cpu_paramNo_arr_TF1.data(), n_tf1, cpu_nParamPerEvent.data() + 2 * e0,
+                                          cpu_nParamPerEvent_TF1.data() + 2 * e0));
+    }
+    M3HIP_CALL(h, m3hip_monolith_end(h));
   }
   /// per step, asynchronous (ref: gpuSplineUtils.cu:444-512)
   void RunGPU_SplineMonolith(float* cpu_total_weights, float* vals, short int* segment, const unsigned int /*h_n_splines*/,
@@ -75,13 +113,16 @@ class SMonolithGPU {
   }
   void CleanupGPU_SplineMonolith(float* cpu_total_weights) { m3hip_free_pinned(h, cpu_total_weights); }
   void CleanupGPU_Segments(short int* segment, float* vals) {
-    m3hip_free_pinned(h, segment);
-    m3hip_free_pinned(h, vals);
+    m3hip_free_pinned(nullptr, segment);
+    m3hip_free_pinned(nullptr, vals);
   }
-  void SynchroniseSplines() { M3HIP_CALL(h, m3hip_sync(h)); }  // ref: gpuSplineUtils.cu:71-73
 
   m3hip_handle Handle() const { return h; }
-  int n_params_hint = 0;  ///< set before InitGPU_Segments / InitGPU_Vals (sizes the pinned buffers)
+  /// events per upload slice (a multiple of 1024); settable for tests
+  static uint64_t& upload_slice_events() {
+    static uint64_t n = 131072;
+    return n;
+  }
 
  private:
   m3hip_handle h = nullptr;
@@ -148,13 +189,13 @@ class SMonolith : public SplineBase {
   /// (ref: Splines/SplineMonolith.cpp:204-207).
   SMonolith(std::vector<std::vector<TResponseFunction_red*>>& MasterSpline, const std::vector<RespFuncType>& SplineType,
             const bool SaveFlatTree = false, const std::string& _FastSplineName = "SplineFile.bin", int device_id = 0)
-      : gpu_spline_handler(new SMonolithGPU(device_id)) {
+      : gpu_spline_handler(SMonolithGPU::make_handler(device_id)) {
     PrepareForGPU(MasterSpline, SplineType);
     if (SaveFlatTree) PrepareSplineFile(_FastSplineName);
     MoveToGPU();
   }
   /// from a flat dump written by PrepareSplineFile
-  explicit SMonolith(const std::string& FileName, int device_id = 0) : gpu_spline_handler(new SMonolithGPU(device_id)) {
+  explicit SMonolith(const std::string& FileName, int device_id = 0) : gpu_spline_handler(SMonolithGPU::make_handler(device_id)) {
     LoadSplineFile(FileName);
     MoveToGPU();
   }
@@ -171,7 +212,7 @@ class SMonolith : public SplineBase {
     gpu_spline_handler->RunGPU_SplineMonolith(cpu_total_weights, ParamValues, SplineSegments, NSplines_valid, NTF1_valid);
   }
   std::string GetName() const override { return "SplineMonolith"; }
-  void SynchroniseMemTransfer() const override { gpu_spline_handler->SynchroniseSplines(); }
+  void SynchroniseMemTransfer() const override { M3HIP_CALL(gpu_spline_handler->Handle(), m3hip_sync(gpu_spline_handler->Handle())); }  // ref: :851-856
   const float* retPointer(const int event) const { return &cpu_total_weights[event]; }
   void setSplinePointers(std::vector<const double*> spline_ParsPointers) {
     for (M3::int_t i = 0; i < nParams; ++i) SplineInfoArray[i].splineParsPointer = spline_ParsPointers[i];
@@ -319,7 +360,6 @@ class SMonolith : public SplineBase {
   }
 
   void MoveToGPU() {
-    gpu_spline_handler->n_params_hint = nParams;
     gpu_spline_handler->InitGPU_Segments(&SplineSegments);
     gpu_spline_handler->InitGPU_Vals(&ParamValues);
     for (int j = 0; j < nParams; ++j) {
@@ -328,7 +368,7 @@ class SMonolith : public SplineBase {
     }
     gpu_spline_handler->InitGPU_SplineMonolith(&cpu_total_weights, int(NEvents), nKnots, NSplines_valid, NTF1_valid, _max_knots * nParams);
     gpu_spline_handler->CopyToGPU_SplineMonolith(&flat, cpu_coeff_TF1_many, cpu_paramNo_TF1_arr, int(NEvents), cpu_nParamPerEvent,
-                                                 cpu_nParamPerEvent_tf1, nParams, NSplines_valid, _max_knots, nKnots, NTF1_valid, npts);
+                                                 cpu_nParamPerEvent_tf1, nParams, NSplines_valid, _max_knots, nKnots, NTF1_valid);
     // the host copies are not needed once the device holds the re-laid-out store (ref: SplineMonolith.cpp:305-310)
     if (!keep_host_copy) {
       flat = SplineMonoStruct();

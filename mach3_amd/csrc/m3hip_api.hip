@@ -128,7 +128,7 @@ struct m3hip_ctx {
   uint32_t M = 0;
   // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
   // index with them unguarded)
-  int64_t max_osc_idx = -1, max_norm_idx = -1, max_parmap = -1;
+  int64_t max_osc_idx = -1, max_norm_idx = -1, max_parmap = -1, max_bin_idx = -1;
   float* d_spline_w = nullptr;
   float* d_event_w = nullptr;
   float* d_osc_table = nullptr;
@@ -389,7 +389,7 @@ void free_monolith(m3hip_handle h) {
   if (h->h_vals) { (void)hipHostFree(h->h_vals); h->h_vals = nullptr; }
   if (h->h_segs) { (void)hipHostFree(h->h_segs); h->h_segs = nullptr; }
   h->M = 0;
-  h->max_osc_idx = h->max_norm_idx = h->max_parmap = -1;
+  h->max_osc_idx = h->max_norm_idx = h->max_parmap = h->max_bin_idx = -1;
   h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
   h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
@@ -573,17 +573,28 @@ int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes) try 
 } M3_API_CATCH(h)
 
 int m3hip_alloc_pinned(m3hip_handle h, void** ptr, size_t bytes) try {
-  if (!h || !ptr) return M3HIP_EINVAL;
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  if (!ptr) return M3HIP_EINVAL;
+  // h may be NULL: the reference allocates its pinned segment / value arrays before its GPU object exists
+  // (SplineMonolith.cpp:82-83 calls InitGPU_Segments / InitGPU_Vals through a null gpu_spline_handler)
+  if (h) HIPCHK(h, hipSetDevice(h->device));
+  const hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("alloc_pinned: ") + hipGetErrorString(e));
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
 int m3hip_free_pinned(m3hip_handle h, void* ptr) try {
-  if (!h) return M3HIP_EINVAL;
-  if (ptr) HIPCHK(h, hipHostFree(ptr));
+  if (ptr) {
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(h, M3HIP_EHIP, std::string("free_pinned: ") + hipGetErrorString(e));
+  }
   return M3HIP_OK;
 } M3_API_CATCH(h)
+
+int m3hip_device_synchronize(void) try {  // SynchroniseSplines(): cudaDeviceSynchronize (gpuSplineUtils.cu:71-73)
+  const hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(nullptr, M3HIP_EHIP, std::string("device_synchronize: ") + hipGetErrorString(e));
+  return M3HIP_OK;
+} M3_API_CATCH(nullptr)
 
 /* ---------------------------------------------------------------- monolith upload */
 
@@ -805,8 +816,12 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   h->n_padded += plan.n_padded;
   h->pad_responses += plan.pad_spl + plan.pad_tf1;
   h->E += n_events;
-  h->S += n_splines;
-  h->T += n_tf1;
+  // the responses of THIS chunk's events: the arrays handed over may be those of a larger sample (the {count,start}
+  // pairs index them), as when the C++ facade uploads one sample in slices
+  for (uint64_t e = 0; e < n_events; ++e) {
+    h->S += n_param_per_event[2 * e];
+    h->T += n_param_per_event_tf1[2 * e];
+  }
   h->coeff_bytes += b_spl + b_tf1;
   return M3HIP_OK;
 } M3_API_CATCH(h)
@@ -972,6 +987,7 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
   HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
+  if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
   HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (2 + n_samples), hipHostMallocMapped));
   memset(h->h_out, 0, sizeof(double) * (2 + n_samples));
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_out, h->h_out, 0));
@@ -991,9 +1007,12 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   if (!bin_idx) return fail(h, M3HIP_EINVAL, "upload_events: bin_idx is NULL");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->n_bins > 0)
-    for (uint64_t i = 0; i < n; ++i)
-      if (bin_idx[i] < -1 || bin_idx[i] >= h->n_bins) return fail(h, M3HIP_EINVAL, "upload_events: bin index out of range");
+  int64_t mx = -1;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (bin_idx[i] < -1 || (h->n_bins > 0 && bin_idx[i] >= h->n_bins)) return fail(h, M3HIP_EINVAL, "upload_events: bin index out of range");
+    mx = std::max<int64_t>(mx, bin_idx[i]);
+  }
+  h->max_bin_idx = std::max(h->max_bin_idx, mx);  // re-checked by m3hip_reweight: the bin space may be (re)defined later
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   if (osc_idx) {
     for (uint64_t i = 0; i < n; ++i) h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
@@ -1425,6 +1444,7 @@ int m3hip_compute_bins(m3hip_handle h) try {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, wait_stream(h->stream));
   h->bins_computed = true;
+  h->max_bin_idx = -1;  // every event's bin now comes from the device-side search over the current bin space
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -1588,6 +1608,13 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     if (k.param >= n_par) return fail(h, M3HIP_EINVAL, "reweight: a kinematic shift points past the parameter vector");
     if (k.dim >= h->kin_stride || (k.kind >> 8) >= h->kin_stride) return fail(h, M3HIP_EINVAL, "reweight: a kinematic shift names a column beyond kin_stride");
   }
+  // every precondition is checked BEFORE a ring slot is taken and k_prep empties the bin vectors: an error return must not
+  // leave a reset histogram behind for a later get_likelihood / get_bins to read as the result of a step
+  if (h->max_bin_idx >= int64_t(h->n_bins))
+    return fail(h, M3HIP_EINVAL, "reweight: an event's bin index (" + std::to_string(h->max_bin_idx) + ") lies past the bin space (" +
+                                     std::to_string(h->n_bins) + " bins; the binning was redefined after m3hip_upload_events)");
+  if (!h->h_shifts.empty() && !h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
+  if (h->f64 && !h->h_bricks.empty()) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
   const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_param_capacity(h, n_par);
@@ -1654,7 +1681,6 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   // epilogue (the float_t = double variant keeps the separate k_find_bins pass)
   const bool dyn_bins = !h->h_shifts.empty();
   if (dyn_bins) {
-    if (!h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
     if (h->f64) {
       BinArgs b = make_bin_args(h);
       b.compute_nominal = 0;
@@ -1716,7 +1742,6 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     kb.ev_stop = n_bricks ? h->ev1 : nullptr;
   }
   if (h->f64) {
-    if (n_bricks) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
     launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
     launch_reweight_uniform(a, n_tiles, mode, ku, h->stream, dyn_bins);

@@ -151,8 +151,10 @@ __device__ __forceinline__ int d_upper_bound_bin(const double* e, int n_edges, d
 }
 
 __device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin) {
-  // Samples/SampleStructs.h:577-613
-  if (KinVar < e[0] || KinVar >= e[N_Bins]) return -1;
+  // Samples/SampleStructs.h:577-613.  The range test is written so that a NaN (a non-finite shift parameter, a bad
+  // input) is out of range: in the reference's form `x < lo || x >= hi` a NaN passes, upper_bound then returns the
+  // last edge and the event lands in bin N_Bins -- the next sample's first bin, or past the bin vector.
+  if (!(KinVar >= e[0] && KinVar < e[N_Bins])) return -1;
   if (NomBin > -1) {
     const double lower = e[NomBin], upper = e[NomBin + 1];
     const double lower_lower = NomBin == 0 ? e[0] : e[NomBin - 1];                       // :615-646
@@ -952,7 +954,7 @@ __global__ __launch_bounds__(256) void k_find_bins(BinArgs a) {
     const BinAxis ax = a.axes[sm.axis_off + d];
     const double* e = a.edges + ax.edge_off;
     const double x = a.kin[ev * a.kin_stride + d];
-    a.nom_bin[ev * a.kin_stride + d] = (x < e[0] || x >= e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x);
+    a.nom_bin[ev * a.kin_stride + d] = !(x >= e[0] && x < e[ax.n_bins]) ? -1 : d_upper_bound_bin(e, ax.n_bins + 1, x);  // NaN: out of range
   }
   // the global bin of the nominal event: the per-step cascade with the nominal bins just stored, no shifts
   BinArgs n = a;

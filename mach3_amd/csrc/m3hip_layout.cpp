@@ -384,23 +384,29 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
       return false;
     }
   }
-  for (uint64_t s = 0; s < in.n_splines; ++s) {
-    const int p = in.param_no[s];
-    if (p < 0 || p >= n_params) { *err = "spline " + std::to_string(s) + ": paramNo out of range"; return false; }
-    const int np = npts[p];
-    if (np < 2 || np > max_knots) {
-      *err = "spline " + std::to_string(s) + ": parameter " + std::to_string(p) + " has no valid knot count (nPts=" +
-             std::to_string(np) + ")";
-      return false;
+  // only the responses the chunk's events point at: a caller may hand over the arrays of a whole sample with every
+  // chunk of it (the {count,start} pairs index them), and must not pay for all of them each time
+  for (uint64_t e = 0; e < in.n_events; ++e) {
+    const uint64_t c = in.npe[2 * e], s0 = in.npe[2 * e + 1];
+    for (uint64_t s = s0; s < s0 + c; ++s) {
+      const int p = in.param_no[s];
+      if (p < 0 || p >= n_params) { *err = "spline " + std::to_string(s) + ": paramNo out of range"; return false; }
+      const int np = npts[p];
+      if (np < 2 || np > max_knots) {
+        *err = "spline " + std::to_string(s) + ": parameter " + std::to_string(p) + " has no valid knot count (nPts=" +
+               std::to_string(np) + ")";
+        return false;
+      }
+      if (uint64_t(in.nknots_arr[s]) + uint64_t(np) > in.total_nknots) {
+        *err = "spline " + std::to_string(s) + ": knots exceed total_nknots";
+        return false;
+      }
     }
-    if (uint64_t(in.nknots_arr[s]) + uint64_t(np) > in.total_nknots) {
-      *err = "spline " + std::to_string(s) + ": knots exceed total_nknots";
-      return false;
+    const uint64_t ct = in.npe_tf1[2 * e], t0 = in.npe_tf1[2 * e + 1];
+    for (uint64_t t = t0; t < t0 + ct; ++t) {
+      const int p = in.param_no_tf1[t];
+      if (p < 0 || p >= n_params) { *err = "TF1 " + std::to_string(t) + ": paramNo out of range"; return false; }
     }
-  }
-  for (uint64_t t = 0; t < in.n_tf1; ++t) {
-    const int p = in.param_no_tf1[t];
-    if (p < 0 || p >= n_params) { *err = "TF1 " + std::to_string(t) + ": paramNo out of range"; return false; }
   }
 
   // ---- tiles: classify per group of M3_GROUP events

@@ -1241,3 +1241,59 @@ def test_two_sample_handlers_interleaved():
     finally:
         eng_a.close()
         eng_b.close()
+
+
+def test_nan_kinematics_are_out_of_range(fresh_engine):
+    """A NaN kinematic value (bad input, or a shift by a non-finite parameter) is UNDER/OVERFLOW on the device, not the
+    bin one past the last edge: in the reference's form of the range test a NaN passes, upper_bound returns the last
+    edge, and the event is filled into the NEXT sample's first bin (or past the bin vector).  Its neighbours are untouched."""
+    rng = np.random.default_rng(77)
+    E, P = 2000, 2
+    cx, npts, ch = _dense_monolith(E, P, rng)
+    e1 = np.linspace(0.0, 5.0, 11)
+    sample_id = (np.arange(E) % 2).astype(np.int32)
+    kin = rng.uniform(0.1, 4.9, (E, 1))
+    par = np.zeros(P + 1)
+    mono = SMonolith(fresh_engine, P, 7, cx, npts, [ch])
+    mono.setSplinePointers(par)
+    sh = SampleHandlerFD(fresh_engine, 2, None, par, bin_edges=[[e1], [e1]])
+    sh.SetupKinematics(0, sample_id, kin)
+    sh.ComputeBins()
+    ref_bins = sh.GetEventBins(0, E).copy()
+    sh.Reweight()
+    mc_ref = sh.GetMCArray().copy()
+    bad = np.array([10, 11, 500, 1999])
+    kin2 = kin.copy()
+    kin2[bad, 0] = np.nan
+    sh.SetupKinematics(0, sample_id, kin2)
+    sh.ComputeBins()
+    got = sh.GetEventBins(0, E)
+    assert (got[bad] == -1).all()
+    keep = np.ones(E, bool)
+    keep[bad] = False
+    assert np.array_equal(got[keep], ref_bins[keep])
+    sh.Reweight()
+    mc = sh.GetMCArray()
+    assert np.isfinite(mc).all() and mc.sum() < mc_ref.sum() and (mc <= mc_ref + 1e-9).all()
+
+
+def test_failed_reweight_leaves_the_last_result_in_place(fresh_engine):
+    """Preconditions are checked before the step takes a ring slot and k_prep empties the bin vectors: after an error
+    return the bins and the likelihood are still those of the last good step, not those of an empty MC."""
+    spec = synth.CONFIGS["c2"].scaled(3000, n_params=8)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    sh.Reweight()
+    sh.AddData(sh.GetMCArray())
+    par[:] = synth.params(spec, 1)
+    llh = sh.Step()
+    mc = sh.GetMCArray().copy()
+    assert llh > 0 and mc.sum() > 0
+    short = np.ascontiguousarray(par[: spec.n_params - 1])           # parameter vector shorter than the spline parameters
+    rc = eng.lib.m3hip_reweight(eng.h, short.ctypes.data, len(short))
+    assert rc != 0
+    assert np.array_equal(sh.GetMCArray(), mc) and sh.GetLikelihood() == llh
+    # the bin space redefined with fewer bins than the uploaded indices reach: refused by the next reweight, not read out of bounds
+    off = np.array([0, 50], np.int32)
+    assert eng.lib.m3hip_set_binning(eng.h, 1, off.ctypes.data) == 0
+    rc = eng.lib.m3hip_reweight(eng.h, par.ctypes.data, len(par))
+    assert rc != 0 and "bin index" in eng.lib.m3hip_last_error(eng.h).decode()
