@@ -258,6 +258,25 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n);
 int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n);
 
+/* Experiment weights behind oscillation and splines.  SampleHandlerFD::AddAdditionalWeightPointers
+ * (Samples/SampleHandlerFD.cpp:196) lets an experiment append pointers to an event's total_weight_pointers;
+ * CalcWeightTotal multiplies them in that order after the spline weights (:584-591), and the virtual
+ * CalcWeightFunc(iEvent) (SampleHandlerFD.h:289, called at :428) refreshes what they point at every step.
+ * Here such a pointer is a SLOT (0..7, multiplied in ascending order behind the spline weight):
+ *   m3hip_upload_event_weights  the pointer targets a per-event variable that does not change between steps
+ *                               (flux / POT / detector weights): one float per event;
+ *   m3hip_upload_weight_index + m3hip_set_weight_table
+ *                               the pointer targets a variable shared by a class of events that CalcWeightFunc
+ *                               recomputes: an index per event (-1: the event has no such pointer) into a table the
+ *                               host refreshes whenever it likes, also every step (asynchronous, like the oscillation
+ *                               weights).
+ * A weight that needs per-event arithmetic on the device beyond these two forms is not representable: such a sample
+ * keeps seam 2 (m3hip_eval_splines) and fills its histograms on the host as the reference does. */
+#define M3HIP_MAX_EXTRA_WEIGHTS 8
+int m3hip_upload_event_weights(m3hip_handle h, int slot, uint64_t event_offset, uint64_t n, const float* w);
+int m3hip_upload_weight_index(m3hip_handle h, int slot, uint64_t event_offset, uint64_t n, const int32_t* idx);
+int m3hip_set_weight_table(m3hip_handle h, int slot, const float* table, uint64_t n);
+
 /* SampleHandlerFD::AddData for all global bins (SampleHandlerFD.cpp:1027-1044) */
 int m3hip_set_data(m3hip_handle h, const double* data, int n_bins);
 /* SampleHandlerBase::SetTestStatistic (SampleHandlerBase.h:185) + LikelihoodOptions:UpdateW2

@@ -129,6 +129,20 @@ struct m3hip_ctx {
   // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
   // index with them unguarded)
   int64_t max_osc_idx = -1, max_norm_idx = -1, max_parmap = -1, max_bin_idx = -1;
+  // experiment weights behind the splines (m3hip_upload_event_weights / _weight_index / m3hip_set_weight_table)
+  struct Extra {
+    float* d_col = nullptr;
+    int32_t* d_idx = nullptr;
+    float* d_tab = nullptr;
+    uint64_t n_tab = 0;
+    int64_t max_idx = -1;
+    void* h_stage[2] = {nullptr, nullptr};
+    uint64_t stage_ticket[2] = {0, 0};
+    int stage_pos = 0;
+  } extra[M3_MAX_EXTRA];
+  ExtraSlot* d_extras = nullptr;
+  int n_extra = 0;  // highest slot in use + 1
+  bool extras_dirty = false;
   float* d_spline_w = nullptr;
   float* d_event_w = nullptr;
   float* d_osc_table = nullptr;
@@ -353,6 +367,15 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bin); h->d_bin = nullptr;
   dev_free(h->d_osc); h->d_osc = nullptr;
   dev_free(h->d_nidx); h->d_nidx = nullptr;
+  for (auto& x : h->extra) {
+    dev_free(x.d_col); dev_free(x.d_idx); dev_free(x.d_tab);
+    for (int i = 0; i < 2; ++i)
+      if (x.h_stage[i]) (void)hipHostFree(x.h_stage[i]);
+    x = m3hip_ctx::Extra();
+  }
+  dev_free(h->d_extras); h->d_extras = nullptr;
+  h->n_extra = 0;
+  h->extras_dirty = false;
   dev_free(h->d_spline_w); h->d_spline_w = nullptr;
   dev_free(h->d_b_cidx); h->d_b_cidx = nullptr;
   dev_free(h->d_b_usv); h->d_b_usv = nullptr;
@@ -434,6 +457,8 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.nidx = h->d_nidx;
   a.params = h->d_params;
   a.osc_table = h->d_osc_table;
+  a.extras = h->d_extras;
+  a.n_extra = uint32_t(h->n_extra);
   a.bwidx = h->d_bwidx;
   a.bl_id = h->bl_mode == 1 ? h->d_bl_id : nullptr;
   a.perm = (h->perm_monolith || (h->bl_mode == 1 && h->S + h->T == 0)) ? h->d_perm : nullptr;
@@ -1573,6 +1598,94 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) try
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
+/* ---------------------------------------------------------------- experiment weights behind the splines */
+
+static int extra_slot_check(m3hip_handle h, int slot, uint64_t event_offset, uint64_t n, const char* who) {
+  if (!h->mono_done) return fail(h, M3HIP_ESTATE, std::string(who) + " before monolith_end");
+  if (slot < 0 || slot >= M3_MAX_EXTRA) return fail(h, M3HIP_EINVAL, std::string(who) + ": slot out of range (0.." + std::to_string(M3_MAX_EXTRA - 1) + ")");
+  if (event_offset + n > h->E) return fail(h, M3HIP_EINVAL, std::string(who) + ": range exceeds the monolith's events");
+  return M3HIP_OK;
+}
+
+int m3hip_upload_event_weights(m3hip_handle h, int slot, uint64_t event_offset, uint64_t n, const float* w) try {
+  if (!h) return M3HIP_EINVAL;
+  int rc = extra_slot_check(h, slot, event_offset, n, "upload_event_weights");
+  if (rc) return rc;
+  if (n == 0) return M3HIP_OK;
+  if (!w) return fail(h, M3HIP_EINVAL, "upload_event_weights: w is NULL");
+  auto& x = h->extra[slot];
+  if (x.d_idx) return fail(h, M3HIP_ESTATE, "upload_event_weights: the slot already holds table indices");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!x.d_col) {
+    if ((rc = dev_alloc(h, &x.d_col, size_t(h->E_pad)))) return rc;
+    std::vector<float> ones(size_t(h->E_pad), 1.0f);  // events never uploaded: no such pointer, i.e. a factor of exactly 1
+    HIPCHK(h, hipMemcpy(x.d_col, ones.data(), sizeof(float) * h->E_pad, hipMemcpyHostToDevice));
+  }
+  HIPCHK(h, hipMemcpy(x.d_col + event_offset, w, sizeof(float) * n, hipMemcpyHostToDevice));
+  h->n_extra = std::max(h->n_extra, slot + 1);
+  h->extras_dirty = true;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_upload_weight_index(m3hip_handle h, int slot, uint64_t event_offset, uint64_t n, const int32_t* idx) try {
+  if (!h) return M3HIP_EINVAL;
+  int rc = extra_slot_check(h, slot, event_offset, n, "upload_weight_index");
+  if (rc) return rc;
+  if (n == 0) return M3HIP_OK;
+  if (!idx) return fail(h, M3HIP_EINVAL, "upload_weight_index: idx is NULL");
+  auto& x = h->extra[slot];
+  if (x.d_col) return fail(h, M3HIP_ESTATE, "upload_weight_index: the slot already holds per-event values");
+  for (uint64_t i = 0; i < n; ++i) {
+    if (idx[i] < -1) return fail(h, M3HIP_EINVAL, "upload_weight_index: index below -1");
+    x.max_idx = std::max<int64_t>(x.max_idx, idx[i]);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!x.d_idx) {
+    if ((rc = dev_alloc(h, &x.d_idx, size_t(h->E_pad)))) return rc;
+    HIPCHK(h, hipMemset(x.d_idx, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: no pointer
+  }
+  HIPCHK(h, hipMemcpy(x.d_idx + event_offset, idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  h->n_extra = std::max(h->n_extra, slot + 1);
+  h->extras_dirty = true;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_set_weight_table(m3hip_handle h, int slot, const float* table, uint64_t n) try {
+  if (!h) return M3HIP_EINVAL;
+  if (slot < 0 || slot >= M3_MAX_EXTRA) return fail(h, M3HIP_EINVAL, "set_weight_table: slot out of range");
+  if (!table || n == 0) return fail(h, M3HIP_EINVAL, "set_weight_table: empty table");
+  auto& x = h->extra[slot];
+  if (x.d_col) return fail(h, M3HIP_ESTATE, "set_weight_table: the slot holds per-event values");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if (n != x.n_tab) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    dev_free(x.d_tab); x.d_tab = nullptr;
+    for (int i = 0; i < 2; ++i) {
+      if (x.h_stage[i]) (void)hipHostFree(x.h_stage[i]);
+      x.h_stage[i] = nullptr;
+      x.stage_ticket[i] = 0;
+    }
+    if ((rc = dev_alloc(h, &x.d_tab, size_t(n)))) return rc;
+    for (int i = 0; i < 2; ++i) HIPCHK(h, hipHostMalloc(&x.h_stage[i], sizeof(float) * n, hipHostMallocDefault));
+    x.n_tab = n;
+    h->extras_dirty = true;
+  }
+  // per-step path, as for the oscillation weights: pinned staging slot, asynchronous copy on the engine's stream
+  const int st = x.stage_pos;
+  x.stage_pos ^= 1;
+  if (x.stage_ticket[st] > h->ticket_done) {
+    HIPCHK(h, wait_stream(h->stream));
+    h->ticket_done = h->ticket;
+  }
+  memcpy(x.h_stage[st], table, sizeof(float) * n);
+  HIPCHK(h, hipMemcpyAsync(x.d_tab, x.h_stage[st], sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+  x.stage_ticket[st] = h->ticket + 1;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
 int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) try {
   if (!h) return M3HIP_EINVAL;
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "set_data before set_binning");
@@ -1614,11 +1727,26 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     return fail(h, M3HIP_EINVAL, "reweight: an event's bin index (" + std::to_string(h->max_bin_idx) + ") lies past the bin space (" +
                                      std::to_string(h->n_bins) + " bins; the binning was redefined after m3hip_upload_events)");
   if (!h->h_shifts.empty() && !h->bins_computed) return fail(h, M3HIP_ESTATE, "reweight: kinematic shifts need m3hip_compute_bins first");
+  for (int sl = 0; sl < h->n_extra; ++sl) {
+    const auto& x = h->extra[sl];
+    if (x.d_idx && x.max_idx >= int64_t(x.n_tab))
+      return fail(h, M3HIP_EINVAL, "reweight: weight slot " + std::to_string(sl) + ": an event's index (" + std::to_string(x.max_idx) +
+                                       ") points past its table (" + std::to_string(x.n_tab) + " entries; m3hip_set_weight_table)");
+  }
+  if (h->f64 && h->n_extra) return fail(h, M3HIP_ESTATE, "reweight: experiment weight slots are float (the low-memory build of the sample side)");
   if (h->f64 && !h->h_bricks.empty()) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
   const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_param_capacity(h, n_par);
   if (rc) return rc;
+  if (h->extras_dirty) {  // the device-side slot descriptors follow the uploads (set-up time)
+    ExtraSlot hs[M3_MAX_EXTRA];
+    for (int sl = 0; sl < M3_MAX_EXTRA; ++sl) hs[sl] = ExtraSlot{h->extra[sl].d_col, h->extra[sl].d_idx, h->extra[sl].d_tab, 0};
+    if (!h->d_extras && (rc = dev_alloc(h, &h->d_extras, size_t(M3_MAX_EXTRA)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_extras, hs, sizeof(hs), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `hs` is on this stack frame
+    h->extras_dirty = false;
+  }
   collect_timing(h);
   // stage the proposed values; the slot is free once the k_prep that read it has run
   const int slot = h->ring_pos;

@@ -105,6 +105,17 @@ struct BinArgs {
 };
 void launch_find_bins(const BinArgs& a, hipStream_t s);
 
+// One experiment weight beyond oscillation and splines (SampleHandlerFD::AddAdditionalWeightPointers appends such pointers to
+// total_weight_pointers, Samples/SampleHandlerFD.cpp:196; CalcWeightFunc refreshes what they point at, SampleHandlerFD.h:289):
+// either a per-event value (col) or an index per event into a table that may change every step (idx, tab; -1 = no pointer).
+struct ExtraSlot {
+  const float* col;
+  const int32_t* idx;
+  const float* tab;
+  uint64_t pad_;
+};
+constexpr int M3_MAX_EXTRA = 8;
+
 struct ReweightArgs {
   const TileDev* tiles;
   const BrickDev* bricks;
@@ -130,6 +141,8 @@ struct ReweightArgs {
   const float* bw;           // weightvec_Monolith of the binned spline handler
   uint32_t n_bw_slots;
   const float* osc_table;
+  const ExtraSlot* extras;   // [n_extra] device array, multiplied after the spline weight in slot order
+  uint32_t n_extra;
   // M3::float_t = double build of the sample side (Manager/Core.h:27-51: the default, non-low-memory
   // build): bin-spline weights, oscillation weights and the event weight product are double
   const double* bw_d;

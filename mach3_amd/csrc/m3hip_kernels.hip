@@ -309,6 +309,20 @@ __device__ __forceinline__ WT mul_binned_weights(WT tw, const ReweightArgs& a, u
   return tw;
 }
 
+// experiment weights behind the spline weight in total_weight_pointers, in the order they were appended (slot order)
+__device__ __forceinline__ float mul_extra_weights(float tw, const ReweightArgs& a, uint64_t ev) {
+  for (uint32_t s = 0; s < a.n_extra; ++s) {
+    const ExtraSlot x = a.extras[s];
+    if (x.col) {
+      tw *= x.col[ev];
+    } else if (x.idx) {
+      const int i = x.idx[ev];
+      if (i >= 0) tw *= x.tab[i];
+    }
+  }
+  return tw;
+}
+
 template <class WT>
 __device__ __forceinline__ WT mul_norm_weights(WT tw, const ReweightArgs& a, uint64_t ev, uint32_t m = 0) {
   for (; m + 4 <= a.n_norm_slots; m += 4) {
@@ -408,6 +422,7 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     if (oi >= 0) tw *= F64 ? (WT)a.osc_table_d[oi] : (WT)a.osc_table[oi];
     tw = mul_binned_weights<WT>(tw, a, ev);  // bin-spline weights, in SetSplinePointers order
     tw *= (WT)w;                              // F64: no event-by-event splines in that build, w == 1
+    if (!F64 && a.n_extra) tw = (WT)mul_extra_weights((float)tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
     if (MODE & kModeEventW) {
       if (F64) a.event_w_d[ev] = (double)tw;
       else a.event_w[ev] = (float)tw;
@@ -875,6 +890,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       if (t_osc >= 0) tw *= t_oscw;
       tw = mul_binned_weights(tw, a, ev);
       tw *= w;
+      if (a.n_extra) tw = mul_extra_weights(tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
       if (MODE & kModeEventW) a.event_w[ev] = tw;
       if (MODE & kModeFill) {
         int b;

@@ -316,6 +316,19 @@ class SampleHandlerFD:
             _ptr(np.ascontiguousarray(norm_off, np.uint64), np.uint64) if norm_off is not None else None,
             _ptr(np.ascontiguousarray(norm_idx, np.int16), np.int16) if norm_idx is not None else None))
 
+    # ---- experiment weights behind the splines (AddAdditionalWeightPointers / CalcWeightFunc, SampleHandlerFD.cpp:196, :428)
+    def SetEventWeights(self, slot, event_offset, w):
+        w = np.ascontiguousarray(w, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_upload_event_weights(self.eng.h, int(slot), event_offset, len(w), _ptr(w, np.float32)))
+
+    def SetWeightIndex(self, slot, event_offset, idx):
+        idx = np.ascontiguousarray(idx, np.int32)
+        self.eng._chk(self.eng.lib.m3hip_upload_weight_index(self.eng.h, int(slot), event_offset, len(idx), _ptr(idx, np.int32)))
+
+    def SetWeightTable(self, slot, table):
+        table = np.ascontiguousarray(table, np.float32)
+        self.eng._chk(self.eng.lib.m3hip_set_weight_table(self.eng.h, int(slot), _ptr(table, np.float32), len(table)))
+
     # ---- device-side binning (ref: Samples/BinningHandler.cpp:257-307, SampleStructs.h:577-613)
     def SetupKinematics(self, event_offset, sample_id, kin):
         kin = np.ascontiguousarray(kin, np.float64)

@@ -1240,6 +1240,16 @@ void m3o_sample_set_binned(m3o_sample* s, m3o_binned* b, const uint64_t* w_off, 
       s->MCSamples[e].total_weight_pointers.push_back(&b->weightvec_Monolith[w_idx[k]]);
 }
 
+// ref: Samples/SampleHandlerFD.cpp:196 AddAdditionalWeightPointers (experiment hook): further pointers appended to
+// total_weight_pointers, behind oscillation and splines; what they point at may be rewritten between steps (CalcWeightFunc,
+// SampleHandlerFD.h:289).  idx == NULL: event e points at base[e]; else at base[idx[e]], or gets no pointer when idx[e] < 0.
+void m3o_sample_add_weight_pointers(m3o_sample* s, const m3o_float_t* base, const int32_t* idx) {
+  for (size_t e = 0; e < s->MCSamples.size(); ++e) {
+    if (!idx) s->MCSamples[e].total_weight_pointers.push_back(&base[e]);
+    else if (idx[e] >= 0) s->MCSamples[e].total_weight_pointers.push_back(&base[idx[e]]);
+  }
+}
+
 // ref: Samples/SampleHandlerFD.cpp:316-343
 void m3o_sample_reweight(m3o_sample* s) {
   ResetHistograms(s);

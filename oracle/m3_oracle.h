@@ -176,6 +176,8 @@ void m3o_sample_set_binned(m3o_sample* s, m3o_binned* b, const uint64_t* w_off, 
  * m3o_sample_event_bins reports -1 for events that fail the selection */
 void m3o_sample_add_cut(m3o_sample* s, int sample, int column, double lower, double upper);
 void m3o_sample_add_shift(m3o_sample* s, int sample, int dim, int kind, const double* value_ptr);
+/* AddAdditionalWeightPointers (SampleHandlerFD.cpp:196): idx NULL -> &base[e]; else &base[idx[e]] (idx[e] < 0: none) */
+void m3o_sample_add_weight_pointers(m3o_sample* s, const m3o_float_t* base, const int32_t* idx);
 void m3o_sample_set_test_statistic(m3o_sample* s, int kind, int update_w2);
 void m3o_sample_add_data(m3o_sample* s, const double* data); /* AddData for all bins */
 void m3o_sample_reweight(m3o_sample* s);                     /* Reweight() */

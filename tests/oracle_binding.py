@@ -46,6 +46,7 @@ def load(variant="serial"):
     lib.m3o_binned_weights.argtypes = [vp]; lib.m3o_binned_weights.restype = vp
     lib.m3o_binned_segments.argtypes = [vp]; lib.m3o_binned_segments.restype = vp
     lib.m3o_sample_set_binned.argtypes = [vp, vp, vp, vp]; lib.m3o_sample_set_binned.restype = None
+    lib.m3o_sample_add_weight_pointers.argtypes = [vp, vp, vp]; lib.m3o_sample_add_weight_pointers.restype = None
     lib.m3o_binning_create.argtypes = []; lib.m3o_binning_create.restype = vp
     lib.m3o_binning_destroy.argtypes = [vp]; lib.m3o_binning_destroy.restype = None
     lib.m3o_binning_add_uniform.argtypes = [vp, i32, vp, vp]; lib.m3o_binning_add_uniform.restype = i32
@@ -240,6 +241,14 @@ class OracleSample:
     def set_binned(self, binned: OracleBinned, w_off, w_idx):
         self.keep = self.keep + (binned, w_off, w_idx)
         self.lib.m3o_sample_set_binned(self.h, binned.h, w_off.ctypes.data, w_idx.ctypes.data)
+
+    def add_weight_pointers(self, base, idx=None):
+        """AddAdditionalWeightPointers: one more pointer per event, into `base` (kept alive here; the caller may rewrite
+        its values between reweights, as CalcWeightFunc does)"""
+        assert base.dtype == self.lib.float_t and base.flags.c_contiguous
+        idx = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        self.keep = getattr(self, "keep", ()) + (base, idx)
+        self.lib.m3o_sample_add_weight_pointers(self.h, base.ctypes.data, None if idx is None else idx.ctypes.data)
 
     def add_cut(self, sample, column, lower, upper):
         self.lib.m3o_sample_add_cut(self.h, sample, column, float(lower), float(upper))

@@ -1297,3 +1297,55 @@ def test_failed_reweight_leaves_the_last_result_in_place(fresh_engine):
     assert eng.lib.m3hip_set_binning(eng.h, 1, off.ctypes.data) == 0
     rc = eng.lib.m3hip_reweight(eng.h, par.ctypes.data, len(par))
     assert rc != 0 and "bin index" in eng.lib.m3hip_last_error(eng.h).decode()
+
+
+@pytest.mark.parametrize("cfg,n_params", [("c2", 12), ("c3", 64)])
+def test_experiment_weight_slots_match_oracle(fresh_engine, cfg, n_params):
+    """AddAdditionalWeightPointers / CalcWeightFunc (SampleHandlerFD.cpp:196, :428; SampleHandlerFD.h:289) on the fused path:
+    a per-event weight (slot 0; some events at 0 and below: dropped by `w <= 0`), a table of 37 values that the "experiment"
+    recomputes every step with an index per event, -1 for events without the pointer (slot 2; slot 1 stays unused), and a
+    second per-event weight (slot 3).  Multiplied behind the spline weight in slot order, like the reference's pointer
+    vector: event weights bit-exact against the serial oracle, on uniform tiles (c2) and on bricks (c3)."""
+    rng = np.random.default_rng(99)
+    spec = synth.CONFIGS[cfg].scaled(5000, n_params=n_params)
+    E = spec.n_events
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine, chunk_events=2048)
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, E)
+    col0 = rng.uniform(0.5, 1.5, E).astype(np.float32)
+    col0[rng.choice(E, 40, replace=False)] = 0.0
+    col0[rng.choice(E, 10, replace=False)] = -0.3
+    col3 = rng.uniform(0.9, 1.1, E).astype(np.float32)
+    idx = rng.integers(-1, 37, E).astype(np.int32)
+    table = np.ones(37, np.float32)                      # the oracle's pointers alias THIS array: rewritten in place per step
+    osamp.add_weight_pointers(col0)
+    osamp.add_weight_pointers(table, idx)
+    osamp.add_weight_pointers(col3)
+    sh.SetEventWeights(0, 0, col0[:3000])
+    sh.SetEventWeights(0, 3000, col0[3000:])             # in two pieces
+    sh.SetWeightIndex(2, 0, idx)
+    sh.SetEventWeights(3, 0, col3)
+    with pytest.raises(capi.M3HipError, match="past its table"):
+        sh.Reweight()                                    # indices uploaded, table not yet
+    sh.SetWeightTable(2, table)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2, 3):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        table[:] = (1.0 + 0.2 * np.sin(np.arange(37) + lap)).astype(np.float32)   # CalcWeightFunc
+        sh.SetWeightTable(2, table)
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        assert llh == pytest.approx(osamp.get_likelihood(), rel=1e-9)
+    assert (osamp.event_weights() <= 0).sum() >= 50
+    with pytest.raises(capi.M3HipError):
+        sh.SetEventWeights(2, 0, col3)                   # slot 2 holds indices
+    with pytest.raises(capi.M3HipError):
+        sh.SetEventWeights(8, 0, col3)                   # no such slot
+    osamp.close()
+    omono.close()
