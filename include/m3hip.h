@@ -279,6 +279,13 @@ int m3hip_set_weight_table(m3hip_handle h, int slot, const float* table, uint64_
 
 /* SampleHandlerFD::AddData for all global bins (SampleHandlerFD.cpp:1027-1044) */
 int m3hip_set_data(m3hip_handle h, const double* data, int n_bins);
+/* Deterministic bin fill ("histogram determinism"; the reference's OpenMP array reduction has no fixed order
+ * either, SampleHandlerFD.cpp:415).  on = 1: no floating-point atomics between workgroups.  Inside a workgroup the waves add
+ * their events in turn; every workgroup stores its bin vector to a row of its own, and two small kernels sum the rows in
+ * index order.  Bins and likelihood of a parameter vector are then bit-identical from call to call whatever the
+ * hardware's arbitration does.  Needs the workgroup-private bin vector (at most 1280 bins); the float build of the
+ * sample side.  Cost: two extra launches and one row of bins per workgroup written and read (about 2 % on configs[1]). */
+int m3hip_set_deterministic(m3hip_handle h, int on);
 /* SampleHandlerBase::SetTestStatistic (SampleHandlerBase.h:185) + LikelihoodOptions:UpdateW2
  * (SampleHandlerFD.cpp:62-65) */
 int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2);

@@ -140,6 +140,11 @@ struct m3hip_ctx {
     uint64_t stage_ticket[2] = {0, 0};
     int stage_pos = 0;
   } extra[M3_MAX_EXTRA];
+  // deterministic fill (m3hip_set_deterministic): one row of bins per workgroup + the level-1 rows of the ordered fold
+  bool deterministic = false;
+  double* d_partial = nullptr;
+  double* d_partial_l1 = nullptr;
+  size_t partial_rows = 0, partial_bins = 0;
   ExtraSlot* d_extras = nullptr;
   int n_extra = 0;  // highest slot in use + 1
   bool extras_dirty = false;
@@ -374,6 +379,9 @@ void free_monolith(m3hip_handle h) {
     x = m3hip_ctx::Extra();
   }
   dev_free(h->d_extras); h->d_extras = nullptr;
+  dev_free(h->d_partial); dev_free(h->d_partial_l1);
+  h->d_partial = h->d_partial_l1 = nullptr;
+  h->partial_rows = h->partial_bins = 0;
   h->n_extra = 0;
   h->extras_dirty = false;
   dev_free(h->d_spline_w); h->d_spline_w = nullptr;
@@ -1696,6 +1704,12 @@ int m3hip_set_data(m3hip_handle h, const double* data, int n_bins) try {
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
+int m3hip_set_deterministic(m3hip_handle h, int on) try {
+  if (!h) return M3HIP_EINVAL;
+  h->deterministic = on != 0;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
 int m3hip_set_test_statistic(m3hip_handle h, int kind, int update_w2) try {
   if (!h) return M3HIP_EINVAL;
   if (kind < 0 || kind > 4) return fail(h, M3HIP_EINVAL, "set_test_statistic: unknown kind");
@@ -1734,6 +1748,25 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
                                        ") points past its table (" + std::to_string(x.n_tab) + " entries; m3hip_set_weight_table)");
   }
   if (h->f64 && h->n_extra) return fail(h, M3HIP_ESTATE, "reweight: experiment weight slots are float (the low-memory build of the sample side)");
+  if (h->deterministic) {
+    if (sizeof(double) * 2 * size_t(h->n_bins) > size_t(M3_HIST_LDS_MAX_BYTES))
+      return fail(h, M3HIP_ESTATE, "reweight: the deterministic fill needs the workgroup-private bin vector (at most " +
+                                       std::to_string(M3_HIST_LDS_MAX_BYTES / 16) + " bins)");
+    if (h->f64) return fail(h, M3HIP_ESTATE, "reweight: the deterministic fill is implemented for the float build of the sample side");
+    const size_t rows = h->h_tiles.size() + h->h_bricks.size();
+    if (rows != h->partial_rows || size_t(h->n_bins) != h->partial_bins) {
+      HIPCHK(h, hipSetDevice(h->device));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      dev_free(h->d_partial); dev_free(h->d_partial_l1);
+      h->d_partial = h->d_partial_l1 = nullptr;
+      h->partial_rows = h->partial_bins = 0;
+      int rc_;
+      if ((rc_ = dev_alloc(h, &h->d_partial, std::max<size_t>(1, rows) * 2 * size_t(h->n_bins)))) return rc_;
+      if ((rc_ = dev_alloc(h, &h->d_partial_l1, ((rows + 31) / 32 + 1) * 2 * size_t(h->n_bins)))) return rc_;
+      h->partial_rows = rows;
+      h->partial_bins = size_t(h->n_bins);
+    }
+  }
   if (h->f64 && !h->h_bricks.empty()) return fail(h, M3HIP_ESTATE, "reweight: the float_t = double build has no event-by-event splines");
   const double t_a = now_s();
   HIPCHK(h, hipSetDevice(h->device));
@@ -1869,11 +1902,20 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     kb.ev_start = n_tiles ? nullptr : h->ev0;
     kb.ev_stop = n_bricks ? h->ev1 : nullptr;
   }
+  if (h->deterministic) {
+    a.hist_lds = 1;  // sized for fill_w2 in the check above
+    a.partial = h->d_partial;
+    a.partial_row0 = n_tiles;
+  }
   if (h->f64) {
     launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
     launch_reweight_uniform(a, n_tiles, mode, ku, h->stream, dyn_bins);
     launch_reweight_brick(a, n_bricks, mode, kb, h->stream, dyn_bins);
+  }
+  if (h->deterministic && (n_tiles || n_bricks)) {  // ordered sum of the workgroups' rows -> replica 0
+    launch_fold_partials(h->d_partial, int(n_tiles + n_bricks), h->n_bins, a.fill_w2, h->d_partial_l1, h->d_hist, h->hist_rep, h->stream);
+    if (a.fill_w2) h->w2_spread = false;  // w2 sits folded in its replica 0
   }
   if (timed && (n_tiles || n_bricks)) h->pending = 0;
   HIPCHK(h, hipGetLastError());

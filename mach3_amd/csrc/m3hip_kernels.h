@@ -150,6 +150,8 @@ struct ReweightArgs {
   double* event_w_d;         // [E_pad] (may be null)
   double* hist;              // [2][hist_rep][n_bins]: mc replicas, then w2 replicas
   int32_t hist_rep;          // replicas the workgroups spread their flushes over (contention)
+  double* partial;           // deterministic mode: [tiles + bricks][2 * n_bins], one row per workgroup (null: atomics)
+  uint32_t partial_row0;     // brick launches: row of the launch's first brick (the bricks' rows follow the tiles')
   uint64_t e_pad;
   uint32_t n_norm_slots;     // M
   int32_t n_bins;
@@ -263,5 +265,7 @@ void launch_llh(const LlhArgs& a, hipStream_t s);
 void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2, hipStream_t s);
 void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s);
+// deterministic mode: ordered sum of the workgroups' rows into replica 0 (scratch: ceil(n_rows / 64) rows)
+void launch_fold_partials(const double* partial, int n_rows, int n_bins, int with_w2, double* scratch, double* hist, int hist_rep, hipStream_t s);
 
 }  // namespace m3hip

@@ -446,12 +446,27 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
         }
         return;
       }
+      const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+      if (a.partial) {
+        // deterministic mode (m3hip_set_deterministic): the waves add in turn, so the order of the fp64 adds inside the
+        // workgroup is fixed (within one wave the LDS serves the lanes of an instruction in lane order); the workgroup's
+        // bin vector then goes to its own row of `partial` with plain stores, and k_fold_partials sums the rows in order
+        for (uint32_t wv = 0; wv < 256 / 64; ++wv) {
+          if ((lane >> 6) == wv && fills) {
+            atomicAdd(&lds_hist[b], (double)tw);
+            if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
+          }
+          __syncthreads();
+        }
+        double* row = a.partial + (size_t)tile * (size_t)(2 * a.n_bins);
+        for (int i = lane; i < nb; i += 256) row[i] = lds_hist[i];
+        return;
+      }
       if (fills) {
         atomicAdd(&lds_hist[b], (double)tw);
         if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // square in float_t, then widened (:445)
       }
       __syncthreads();
-      const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
       // one flush per workgroup, spread over hist_rep replicas of the bin vector: thousands of
       // workgroups adding into the same few hundred addresses serialise at the memory side
       for (int i = lane; i < nb; i += 256) {
@@ -874,6 +889,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   }
 
   M3_STAMP(9);
+  bool det_fill = false;
+  int det_b = -1;
+  float det_w = 0.f;
   // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
   // belong to somebody else's events and must touch nothing
   if (lane < bd.n_events) {
@@ -900,7 +918,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         } else {
           b = t_bin;
         }
-        if (!(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
+        if (a.partial) {  // deterministic mode: filled below, wave after wave
+          det_fill = !(tw <= 0.f) && b >= 0;
+          det_b = b;
+          det_w = tw;
+        } else if (!(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
           if (a.hist_lds) {
             atomicAdd(&lds_hist[b], (double)tw);
             if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
@@ -912,6 +934,20 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         }
       }
     }
+  }
+  if ((MODE & kModeFill) && a.hist_lds && a.partial) {
+    // deterministic mode, as in k_reweight_uniform: the waves add in turn, the bin vector goes to the brick's row of `partial`
+    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+    for (uint32_t wv = 0; wv < kBrickThreads / 64; ++wv) {
+      if (wave == wv && det_fill) {
+        atomicAdd(&lds_hist[det_b], (double)det_w);
+        if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + det_b], (double)(det_w * det_w));
+      }
+      __syncthreads();
+    }
+    double* row = a.partial + ((size_t)a.partial_row0 + blockIdx.x) * (size_t)(2 * a.n_bins);
+    for (int i = lane; i < nb; i += kBrickThreads) row[i] = lds_hist[i];
+    return;
   }
   if ((MODE & kModeFill) && a.hist_lds) {
     __syncthreads();
@@ -1183,6 +1219,39 @@ __global__ __launch_bounds__(256) void k_unpark_w2(double* hist, int hist_rep, i
 
 void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s) {
   hipLaunchKernelGGL(k_unpark_w2, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins);
+}
+
+// Deterministic mode: the bin vector as an ordered sum of the workgroups' rows.  Level 1: every 64 consecutive rows into one
+// (thread = bin, rows added in index order); level 2: one workgroup adds the level-1 rows in order into replica 0.  No
+// atomics anywhere: the result depends on nothing but the rows.
+constexpr int kFoldGroup = 32;
+// m += rows[r][i] for r in [r0, r1), in index order; the loads of a batch are in flight together, the adds stay sequential
+__device__ __forceinline__ double fold_rows(const double* rows, int r0, int r1, int row_len, int i) {
+  double m = 0.0;
+  for (int r = r0; r < r1; r += kFoldGroup) {
+    double v[kFoldGroup];
+#pragma unroll
+    for (int u = 0; u < kFoldGroup; ++u) v[u] = r + u < r1 ? rows[(size_t)(r + u) * row_len + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < kFoldGroup; ++u) m += v[u];  // + 0.0 past the end changes nothing (m is never -0.0 here: it starts at +0.0)
+  }
+  return m;
+}
+__global__ __launch_bounds__(256) void k_fold_partials(const double* rows, int n_rows, int row_len, int n_used, double* out, int out_len) {
+  const int g = blockIdx.y, r0 = g * kFoldGroup, r1 = min(n_rows, r0 + kFoldGroup);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_used) out[(size_t)g * out_len + i] = fold_rows(rows, r0, r1, row_len, i);
+}
+__global__ __launch_bounds__(256) void k_fold_final(const double* rows, int n_rows, int row_len, double* hist, int hist_rep, int n_bins, int with_w2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_bins * (with_w2 ? 2 : 1))
+    hist[i < n_bins ? i : (size_t)hist_rep * n_bins + (i - n_bins)] = fold_rows(rows, 0, n_rows, row_len, i);  // replica 0 (k_prep has emptied the others)
+}
+void launch_fold_partials(const double* partial, int n_rows, int n_bins, int with_w2, double* scratch, double* hist, int hist_rep, hipStream_t s) {
+  const int row_len = 2 * n_bins, n_used = n_bins * (with_w2 ? 2 : 1), n_groups = (n_rows + kFoldGroup - 1) / kFoldGroup;
+  const int bx = (n_used + 255) / 256;
+  hipLaunchKernelGGL(k_fold_partials, dim3(bx, n_groups), dim3(256), 0, s, partial, n_rows, row_len, n_used, scratch, row_len);
+  hipLaunchKernelGGL(k_fold_final, dim3(bx), dim3(256), 0, s, scratch, n_groups, row_len, hist, hist_rep, n_bins, with_w2);
 }
 
 // sum of one bin over the flush replicas, in replica order (fixed => reproducible), 16 loads in flight

@@ -92,6 +92,9 @@ class Engine:
             raise M3HipError(rc, self.lib.m3hip_last_error(None).decode())
         return buf.raw
 
+    def set_deterministic(self, on=True):
+        self._chk(self.lib.m3hip_set_deterministic(self.h, int(on)))
+
     def comm_available(self) -> bool:
         return bool(self.lib.m3hip_comm_available())
 

@@ -1349,3 +1349,58 @@ def test_experiment_weight_slots_match_oracle(fresh_engine, cfg, n_params):
         sh.SetEventWeights(8, 0, col3)                   # no such slot
     osamp.close()
     omono.close()
+
+
+@pytest.mark.parametrize("cfg,n_params,n_events", [("c2", 16, 40_000), ("c3", 64, 60_000)])
+def test_deterministic_fill_is_bit_reproducible(cfg, n_params, n_events):
+    """m3hip_set_deterministic: no floating-point atomics between workgroups, waves add in turn inside one.  Event weights are
+    spread over twelve decades (an experiment weight slot), so that the fp64 bin sums really do round and the order of the
+    adds shows: ten evaluations of the same parameter vector, interleaved with others, give bit-identical bins and
+    likelihood; the values agree with the default (atomic) fill to rounding; and on the plain configuration (adds exact at
+    these magnitudes) the bins of two half-sample engines add up to the whole sample's bit for bit."""
+    rng = np.random.default_rng(5)
+    spec = synth.CONFIGS[cfg].scaled(n_events, n_params=n_params)
+    wide = (10.0 ** rng.uniform(-6, 6, n_events)).astype(np.float32)
+    eng, mono, sh, par = build_from_synth(spec, chunk_events=16384)
+    sh.SetEventWeights(0, 0, wide)
+    sh.Reweight()
+    sh.AddData(sh.GetMCArray())
+    par[:] = synth.params(spec, 4)
+    llh_atomic = sh.Step()
+    mc_atomic = sh.GetMCArray().copy()
+    eng.set_deterministic(True)
+    seen = set()
+    for rep in range(10):
+        par[:] = synth.params(spec, 4)
+        llh = sh.Step()
+        seen.add((llh, sh.GetMCArray().tobytes(), sh.GetW2Array().tobytes()))
+        par[:] = synth.params(spec, 5 + rep)   # something else in between
+        sh.Step()
+    assert len(seen) == 1
+    llh_det, mc_det = next(iter(seen))[0], np.frombuffer(next(iter(seen))[1])
+    # (the likelihood of such a sample cancels eight digits between its terms: 1e-6, the north-star bar, not 1e-9)
+    assert np.allclose(mc_det, mc_atomic, rtol=1e-12, atol=0) and llh_det == pytest.approx(llh_atomic, rel=1e-6)
+    eng.close()
+
+    # shard additivity, bit for bit, on the configuration as it is (no twelve-decade weights)
+    def bins(e0, e1):
+        e, m, s, p = build_from_synth(spec, chunk_events=16384, event_range=(e0, e1))
+        e.set_deterministic(True)
+        p[:] = synth.params(spec, 4)
+        s.Reweight()
+        out = s.GetMCArray().copy(), s.GetW2Array().copy()
+        e.close()
+        return out
+    cut = (n_events // 2 // 1024) * 1024
+    (mc_a, w2_a), (mc_b, w2_b), (mc_w, w2_w) = bins(0, cut), bins(cut, n_events), bins(0, n_events)
+    assert np.array_equal(mc_a + mc_b, mc_w) and np.array_equal(w2_a + w2_b, w2_w)
+
+
+def test_deterministic_fill_needs_the_private_bin_vector(fresh_engine):
+    spec = synth.CONFIGS["c2"].scaled(3000, n_params=4, n_samples=1, n_bins=3000)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    eng.set_deterministic(True)
+    with pytest.raises(capi.M3HipError, match="deterministic"):
+        sh.Reweight()
+    eng.set_deterministic(False)
+    sh.Reweight()
