@@ -43,7 +43,7 @@ clean:
 .PHONY: all oracle clean isa stamps
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
-examples: build/mr2t2_dragrace build/facade_check build/libm3facade_test.so build/libm3seam2_test.so
+examples: build/mr2t2_dragrace build/facade_check build/c5_step_loop build/libm3facade_test.so build/libm3seam2_test.so
 
 # C shim over the header-only facade for the CPU tests (links libm3hip.so only for the symbols the headers reference)
 build/libm3facade_test.so: tests/cpp/facade_shim.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so
@@ -61,6 +61,12 @@ build/facade_check: examples/facade_check.cpp include/mach3_amd/*.h include/m3hi
 	@mkdir -p build
 	g++ -std=c++17 -O2 -Wall -Wextra -ffp-contract=off -Iinclude -o $@ examples/facade_check.cpp -L$(LIBDIR) -lm3hip \
 	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../mach3_amd/lib' -Wl,-rpath,/opt/rocm/lib
+
+# BASELINE configs[4]: the adaptive-MCMC step loop at 1 040 parameters, host phases timed beside the GPU step
+build/c5_step_loop: examples/c5_step_loop.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
+	@mkdir -p build
+	g++ -std=c++17 -O3 -march=x86-64-v3 -fopenmp -Wall -Wextra -Iinclude -o $@ examples/c5_step_loop.cpp -L$(LIBDIR) -lm3hip -lm3synth \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
 	@mkdir -p build

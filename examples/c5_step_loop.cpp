@@ -1,0 +1,167 @@
+// c5_step_loop.cpp -- BASELINE configs[4] ("adaptive-MCMC step loop"): the Metropolis step of Fitters/MR2T2.cpp:25-115 with the
+// adaptive proposal (Parameters/AdaptiveMCMCHandler.cpp:332-397) over a shard of the 1e8-event, 1 024-systematic sample on ONE GPU,
+// with every host phase of the step timed beside the GPU's: how much of a step is the O(nPar^2) host side?
+//   propose   ParameterHandlerBase::ProposeStep   (Cholesky-correlated throw, ParameterHandlerBase.cpp:652-745)
+//   launch    bounds (:844-856) + m3hip_reweight: the sample's step is only launched
+//   under     prior 0.5 d^T V^-1 d (:816-841), the Haario update left from the previous step (AdaptiveMCMCHandler.cpp:332-397) and the
+//             correlated throw of the NEXT proposal (:690-745; it does not depend on where the chain stands), while the device works
+//   wait      m3hip_get_likelihood: the rest of the GPU step
+//   accept    acceptance test, AcceptStep; every `update_step` steps the Haario update runs here, with a new Cholesky factor
+// The sample goes up through the C ABI in generator-sized chunks (the MasterSpline object form of such a sample would
+// need 100 GB of pointers).  usage: c5_step_loop [events=12500000] [steps=300] [update_step=100]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../include/m3hip.h"
+#include "../include/mach3_amd/Fitters.h"
+#include "../mach3_amd/synth/m3synth.h"
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CK(expr)                                                                    \
+  do {                                                                              \
+    if ((expr) != M3HIP_OK) { std::fprintf(stderr, "%s: %s\n", #expr, m3hip_last_error(h)); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const uint64_t E = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 12500000ull;
+  const int NSteps = argc > 2 ? std::atoi(argv[2]) : 300;
+  const int UpdateStep = argc > 3 ? std::atoi(argv[3]) : 100;
+  m3synth_config cfg{};  // mach3_amd/synth.py: CONFIGS["c5"]
+  cfg.seed = 20260318; cfg.n_params = 1024; cfg.n_knots = 7; cfg.mixed = 1; cfg.n_norm = 16; cfg.max_norm_per_event = 3;
+  cfg.n_samples = 1; cfg.n_bins = 200; cfg.osc_n = 4000 + 200000; cfg.occupancy = 1.0 / 64; cfg.bin_lo = 0.0; cfg.bin_hi = 5.0;
+  cfg.nc_fraction = 0.1;
+  const int P = cfg.n_params, nPar = P + cfg.n_norm;
+
+  m3hip_handle h = nullptr;
+  if (m3hip_create(0, &h) != M3HIP_OK) { std::fprintf(stderr, "m3hip_create: %s\n", m3hip_last_error(nullptr)); return 1; }
+  const double t_setup = now_s();
+  {
+    std::vector<float> cx(size_t(P) * 7);
+    std::vector<int16_t> npts(P);
+    m3synth_knots(&cfg, cx.data(), npts.data());
+    CK(m3hip_monolith_begin(h, P, 7, cx.data(), npts.data()));
+    const uint64_t chunk = 131072;
+    for (uint64_t e0 = 0; e0 < E; e0 += chunk) {
+      const uint64_t e1 = std::min(E, e0 + chunk);
+      uint64_t S = 0, T = 0;
+      m3synth_count(&cfg, e0, e1, &S, &T);
+      std::vector<float> cm(S * 28), ct(T * 2);
+      std::vector<unsigned> nk(S), npe(2 * (e1 - e0)), npt(2 * (e1 - e0));
+      std::vector<int16_t> pn(S), pt(T);
+      m3synth_monolith(&cfg, e0, e1, cm.data(), nk.data(), pn.data(), ct.data(), pt.data(), npe.data(), npt.data());
+      CK(m3hip_monolith_append(h, e1 - e0, cm.data(), S * 7, nk.data(), pn.data(), S, ct.data(), pt.data(), T, npe.data(), npt.data()));
+    }
+    CK(m3hip_monolith_end(h));
+    const int32_t off[2] = {0, cfg.n_bins};
+    CK(m3hip_set_binning(h, 1, off));
+    std::vector<double> edges(cfg.n_bins + 1);
+    m3synth_bin_edges(&cfg, edges.data());
+    for (uint64_t e0 = 0; e0 < E; e0 += chunk) {
+      const uint64_t n = std::min(E, e0 + chunk) - e0;
+      std::vector<int32_t> sid(n), osc(n), bin(n);
+      std::vector<double> erec(n);
+      std::vector<uint64_t> noff(n + 1);
+      std::vector<int16_t> nidx(n * 3 + 1);
+      m3synth_events(&cfg, e0, e0 + n, sid.data(), erec.data(), osc.data(), noff.data(), nidx.data());
+      for (uint64_t i = 0; i < n; ++i) {  // static 1-D binning, [lo, hi) (BinningHandler.cpp:294-307)
+        const double x = erec[i];
+        bin[i] = (x < edges.front() || x >= edges.back()) ? -1 : int(std::upper_bound(edges.begin(), edges.end(), x) - edges.begin()) - 1;
+      }
+      for (auto& v : nidx) v = int16_t(v + 0);  // indices are already global (P + k)
+      CK(m3hip_upload_events(h, e0, n, bin.data(), osc.data(), noff.data(), nidx.data()));
+    }
+    std::vector<float> tbl(size_t(cfg.osc_n));
+    m3synth_osc_table(&cfg, tbl.data());
+    CK(m3hip_set_osc_table(h, tbl.data(), tbl.size()));
+    CK(m3hip_set_test_statistic(h, 1 /*Barlow-Beeston*/, 0));
+  }
+  m3hip_info info;
+  CK(m3hip_get_info(h, &info));
+  std::printf("configs[4] shard: %llu events, %d spline parameters + %d norm, %llu TSpline3 + %llu TF1 responses, store %.1f GB, set-up %.1f s\n",
+              (unsigned long long)E, P, cfg.n_norm, (unsigned long long)info.n_splines, (unsigned long long)info.n_tf1, info.coeff_bytes / 1e9, now_s() - t_setup);
+
+  // ---- the parameter handler: unit Gaussian priors on the spline parameters (sigma units), 5 % on the norms
+  std::vector<double> prefit(nPar, 0.0), cov(size_t(nPar) * nPar, 0.0), lo(nPar, -5.0), up(nPar, 5.0);
+  for (int i = 0; i < nPar; ++i) {
+    const bool norm = i >= P;
+    prefit[i] = norm ? 1.0 : 0.0;
+    cov[size_t(i) * nPar + i] = norm ? 0.05 * 0.05 : 1.0;
+    lo[i] = norm ? 0.0 : -3.0;   // inside the splines' knot range
+    up[i] = norm ? 2.0 : 3.0;
+  }
+  for (int i = 0; i + 1 < nPar; ++i) {  // some correlation, so that the Cholesky factor is not diagonal
+    const double c = 0.3 * std::sqrt(cov[size_t(i) * nPar + i] * cov[size_t(i + 1) * nPar + i + 1]);
+    cov[size_t(i) * nPar + i + 1] = cov[size_t(i + 1) * nPar + i] = c;
+  }
+  const double t_ph = now_s();
+  ParameterHandlerBase par("c5_pars", prefit, cov, lo, up, {}, 12345);
+  par.SetStepScale(0.3 * par.GetGlobalStepScale());
+  par.InitialiseAdaption(0, 1 << 30, 50, UpdateStep);
+  std::printf("parameter handler for %d parameters (inverse + Cholesky of the prior covariance): %.2f s\n", nPar, now_s() - t_ph);
+
+  // Asimov data at the prior centre (Fitters/MaCh3Factory.h:142-153)
+  double llh = 0;
+  CK(m3hip_reweight(h, prefit.data(), nPar));
+  {
+    std::vector<double> mc(cfg.n_bins), w2(cfg.n_bins);
+    CK(m3hip_get_bins(h, mc.data(), w2.data(), cfg.n_bins));
+    CK(m3hip_set_data(h, mc.data(), cfg.n_bins));
+  }
+  // ---- MR2T2::ProposeStep / CheckStep / AcceptStep, phase by phase (Fitters/MR2T2.cpp:25-115)
+  std::mt19937_64 rng(777);
+  std::uniform_real_distribution<double> unif(0.0, 1.0);
+  double logLCurr = 0.0;
+  CK(m3hip_step(h, par.GetParPropVec().data(), nPar, &logLCurr, nullptr));
+  logLCurr += par.GetLikelihood();
+  double t_prop = 0, t_launch = 0, t_under = 0, t_wait = 0, t_acc = 0, t_acc_max = 0;
+  int accepted = 0, oob = 0;
+  for (int warm = 0; warm < 20; ++warm) CK(m3hip_step(h, par.GetParPropVec().data(), nPar, &llh, nullptr));
+  const double t0 = now_s();
+  for (int s = 0; s < NSteps; ++s) {
+    // the order of MCMCBase::EvaluateProposal (include/mach3_amd/Fitters.h): bounds, LAUNCH of the sample's step, then the
+    // prior and the pending Haario update on the host while the device works, then the wait for the likelihood
+    const double a = now_s();
+    par.ProposeStep();
+    const double b = now_s();
+    const bool out_of_bounds = par.CheckBounds() > 0;  // MR2T2.cpp:62: a proposal outside the bounds never reaches the samples
+    if (!out_of_bounds) CK(m3hip_reweight(h, par.GetParPropVec().data(), nPar));
+    const double c = now_s();
+    double logLProp = par.GetLikelihood();
+    par.FinishPendingAdaption();
+    par.PrepareNextThrow();
+    const double d = now_s();
+    if (!out_of_bounds) {
+      CK(m3hip_get_likelihood(h, &llh, nullptr));
+      logLProp += llh;
+    } else {
+      ++oob;
+    }
+    const double e = now_s();
+    const double accProb = out_of_bounds ? 0.0 : std::min(1.0, std::exp(logLCurr - logLProp));
+    if (!(unif(rng) > accProb)) {
+      par.AcceptStep();
+      logLCurr = logLProp;
+      ++accepted;
+    }
+    par.UpdateAdaptiveCovariance();
+    const double f = now_s();
+    t_prop += b - a; t_launch += c - b; t_under += d - c; t_wait += e - d; t_acc += f - e;
+    t_acc_max = std::max(t_acc_max, f - e);
+  }
+  const double el = now_s() - t0;
+  const double us = 1e6 / NSteps;
+  std::printf("%d steps in %.3f s = %.0f steps/s (%.1f us/step); acceptance %.2f, out of bounds %d\n", NSteps, el, NSteps / el, el * us, double(accepted) / NSteps, oob);
+  std::printf("per step: propose %.1f us | bounds + launch %.1f us | prior + Haario update + next step's correlated throw UNDER the GPU step %.1f us | rest of the wait for the "
+              "likelihood %.1f us | accept (+ a new Cholesky factor every %d steps) %.1f us, worst %.1f us\n",
+              t_prop * us, t_launch * us, t_under * us, t_wait * us, UpdateStep, t_acc * us, t_acc_max * 1e6);
+  const double exposed = t_prop + t_acc, gpu = t_launch + t_under + t_wait;
+  std::printf("host work on the step's critical path %.1f us = %.1f %% of the step; the GPU step spans %.1f us, of which the host computed during %.1f us\n",
+              exposed * us, 100.0 * exposed / (exposed + gpu), gpu * us, t_under * us);
+  m3hip_destroy(h);
+  std::printf("OK\n");
+  return 0;
+}

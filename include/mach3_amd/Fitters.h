@@ -23,6 +23,14 @@
 #include "Core.h"
 #include "SampleHandlerFD.h"
 
+// OpenMP is optional for the host driver: with -fopenmp the quadratic loops are vectorised and the Haario update threaded
+#if defined(_OPENMP)
+#define M3_OMP_STR(x) #x
+#define M3_OMP(x) _Pragma(M3_OMP_STR(x))
+#else
+#define M3_OMP(x)
+#endif
+
 class ParameterHandlerBase {
  public:
   /// prior central values, prior covariance (row-major nPar x nPar), bounds; flat_prior[i] drops
@@ -64,6 +72,7 @@ class ParameterHandlerBase {
   /// flags them through the sign of _fError)
   bool IsParameterFixed(const int i) const { return fixed[size_t(i)]; }
   void ToggleFixParameter(const int i) {
+    throw_ready = throw_drawn = false;
     if (i < 0 || i >= _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "ToggleFixParameter: parameter index out of range");
     fixed[size_t(i)] = !fixed[size_t(i)];
   }
@@ -122,29 +131,56 @@ class ParameterHandlerBase {
 
   /// ref: ParameterHandlerBase.cpp:652-664 (ProposeStep), 690-707 (Randomize), 726-745 (CorrelateSteps)
   void ProposeStep() {
-    for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
-    for (int i = 0; i < _fNumPar; ++i) {  // corr_throw = L z, L lower triangular
-      double s = 0.0;
-      for (int j = 0; j <= i; ++j) s += throwMatrixCholDecomp[size_t(i) * _fNumPar + j] * randParams[size_t(j)];
-      corr_throw[size_t(i)] = s;
-    }
+    if (!throw_ready) PrepareNextThrow();
+    throw_ready = throw_drawn = false;
     for (int i = 0; i < _fNumPar; ++i)
       if (!IsParameterFixed(i)) _fPropVal[size_t(i)] = _fCurrVal[size_t(i)] + corr_throw[size_t(i)] * _fGlobalStepScale * _fIndivStepScale[size_t(i)];
     if (doSpecialStepProposal) SpecialStepProposal();
   }
-  void AcceptStep() { _fCurrVal = _fPropVal; }  // ref: :748-761
+  /// The correlated throw of the NEXT proposal: Randomize (:690-707) + CorrelateSteps (:726-745).  It depends on the throw
+  /// matrix only, not on where the chain stands, so a fitter may compute it ahead of time under the GPU's work on the
+  /// current step (MCMCBase::EvaluateProposal); ProposeStep computes it itself when nobody did, and again (same random
+  /// vector) when the throw matrix or the set of fixed parameters changed in between.
+  void PrepareNextThrow() {
+    if (!throw_drawn) {
+      for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
+      throw_drawn = true;
+    }
+    // corr_throw = L z, L lower triangular.  O(nPar^2) per step: at the 1 040 parameters of BASELINE configs[4] the three
+    // quadratic loops of this class (this one, the prior, the Haario update) would cost more than the GPU step if left
+    // scalar and serial to it, so their inner loops are contiguous row sweeps the compiler vectorises (`omp simd` with
+    // -fopenmp, plain loops without), and the fitter runs all three while the device works.
+    const double* L = throwMatrixCholDecomp.data();
+    const double* z = randParams.data();
+    for (int i = 0; i < _fNumPar; ++i) {
+      const double* row = L + size_t(i) * _fNumPar;
+      double s = 0.0;
+M3_OMP(omp simd reduction(+ : s))
+      for (int j = 0; j <= i; ++j) s += row[j] * z[j];
+      corr_throw[size_t(i)] = s;
+    }
+    throw_ready = true;
+  }
+  void AcceptStep() {  // ref: :748-761
+    FinishPendingAdaption();  // the pending Haario update belongs to the point the chain is about to leave
+    _fCurrVal = _fPropVal;
+  }
 
   /// ref: :816-841 -- 0.5 * d^T V^-1 d over the parameters with a Gaussian prior
   double CalcLikelihood() const {
+    // sum over i, j <= i of (i == j ? 0.5 : 1) d_i d_j V^-1_ij with d = 0 for flat priors, one row sweep per parameter
+    std::vector<double>& d = diff_scratch;
+    d.resize(size_t(_fNumPar));
+    for (int i = 0; i < _fNumPar; ++i) d[size_t(i)] = _fFlatPrior[size_t(i)] ? 0.0 : _fPropVal[size_t(i)] - _fPreFitValue[size_t(i)];
+    const double* dv = d.data();
     double logL = 0.0;
     for (int i = 0; i < _fNumPar; ++i) {
       if (_fFlatPrior[size_t(i)]) continue;
-      const double Diff = _fPropVal[size_t(i)] - _fPreFitValue[size_t(i)];
-      for (int j = 0; j <= i; ++j) {
-        if (_fFlatPrior[size_t(j)]) continue;
-        const double scale = (i != j) ? 1. : 0.5;
-        logL += scale * Diff * (_fPropVal[size_t(j)] - _fPreFitValue[size_t(j)]) * InvertCovMatrix[size_t(i) * _fNumPar + j];
-      }
+      const double* row = InvertCovMatrix.data() + size_t(i) * _fNumPar;
+      double s = 0.0;
+M3_OMP(omp simd reduction(+ : s))
+      for (int j = 0; j < i; ++j) s += dv[j] * row[j];
+      logL += dv[i] * (s + 0.5 * dv[i] * row[i]);
     }
     return logL;
   }
@@ -174,27 +210,44 @@ class ParameterHandlerBase {
     adaptive_covariance.assign(size_t(_fNumPar) * _fNumPar, 0.0);
   }
   void UpdateAdaptiveCovariance() {
+    FinishPendingAdaption();  // (a driver that did not finish the previous step's update under its GPU work)
     if (total_steps > end_adaptive_update || total_steps < start_adaptive_update) {  // SkipAdaption
       ++total_steps;
       return;
     }
-    // Haario update (ref: AdaptiveMCMCHandler.cpp:332-397), no blocks / skipped parameters
-    const std::vector<double> par_means_prev = par_means;
+    // The running mean / covariance only matter to the chain when they are turned into a new throw matrix.  On the steps
+    // in between, the O(nPar^2) update is left pending: the fitter finishes it under the next step's GPU work
+    // (FinishPendingAdaption); AcceptStep -- the next thing that would change the current values -- finishes it itself if
+    // nobody did.  Same sequence of updates, same numbers.
+    const bool refresh = total_steps >= start_adaptive_throw && (total_steps - start_adaptive_throw) % adaptive_update_step == 0;
+    adaption_pending = true;
+    if (refresh || total_steps == start_adaptive_throw) FinishPendingAdaption();
+  }
+  void FinishPendingAdaption() {
+    if (!adaption_pending) return;
+    adaption_pending = false;
+    // Haario update (ref: AdaptiveMCMCHandler.cpp:332-397), no blocks / skipped parameters.  Only the lower triangle is kept
+    // (SetThrowMatrix reads nothing else; GetAdaptiveCovariance mirrors it): the matrix is 8.7 MB at 1 040 parameters, and a
+    // mirrored write per element would stride through all of it.
+    par_means_prev = par_means;
     const int steps_post_burn = total_steps - start_adaptive_update;
     for (int i = 0; i < _fNumPar; ++i) par_means[size_t(i)] = (_fCurrVal[size_t(i)] + par_means_prev[size_t(i)] * steps_post_burn) / (steps_post_burn + 1);
-    for (int i = 0; i < _fNumPar; ++i)
-      for (int j = 0; j <= i; ++j) {
-        const double cov_prev = adaptive_covariance[size_t(i) * _fNumPar + j];
-        double cov_updated = 0.0;
-        if (steps_post_burn > 0) {
-          const double cov_t = cov_prev * (steps_post_burn - 1) / steps_post_burn;
-          const double prev_means_t = steps_post_burn * par_means_prev[size_t(i)] * par_means_prev[size_t(j)];
-          const double curr_means_t = (steps_post_burn + 1) * par_means[size_t(i)] * par_means[size_t(j)];
-          const double curr_step_t = _fCurrVal[size_t(i)] * _fCurrVal[size_t(j)];
-          cov_updated = cov_t + (prev_means_t - curr_means_t + curr_step_t) / steps_post_burn;
-        }
-        adaptive_covariance[size_t(i) * _fNumPar + j] = adaptive_covariance[size_t(j) * _fNumPar + i] = cov_updated;
+    const int n = _fNumPar;
+    double* cov = adaptive_covariance.data();
+    const double* mp = par_means_prev.data();
+    const double* mc = par_means.data();
+    const double* x = _fCurrVal.data();
+    if (steps_post_burn > 0) {
+      const double keep = double(steps_post_burn - 1) / steps_post_burn, nb = double(steps_post_burn), nb1 = double(steps_post_burn + 1);
+      for (int i = 0; i < n; ++i) {
+        double* row = cov + size_t(i) * n;
+        const double pi = nb * mp[i], ci = nb1 * mc[i], xi = x[i];
+M3_OMP(omp simd)
+        for (int j = 0; j <= i; ++j) row[j] = row[j] * keep + (pi * mp[j] - ci * mc[j] + xi * x[j]) / nb;
       }
+    } else {
+      for (int i = 0; i < n; ++i) std::fill(cov + size_t(i) * n, cov + size_t(i) * n + i + 1, 0.0);
+    }
     if (total_steps == start_adaptive_throw) std::fill(_fIndivStepScale.begin(), _fIndivStepScale.end(), 1.0);  // IndivStepScaleAdapt
     if (total_steps >= start_adaptive_throw && (total_steps - start_adaptive_throw) % adaptive_update_step == 0) {  // UpdateMatrixAdapt
       try {
@@ -205,15 +258,25 @@ class ParameterHandlerBase {
     }
     ++total_steps;
   }
-  const std::vector<double>& GetAdaptiveCovariance() const { return adaptive_covariance; }
+  /// the running covariance as a full symmetric matrix (only its lower triangle is maintained)
+  std::vector<double> GetAdaptiveCovariance() {
+    FinishPendingAdaption();
+    std::vector<double> full(adaptive_covariance);
+    for (int i = 0; i < _fNumPar; ++i)
+      for (int j = 0; j < i; ++j) full[size_t(j) * _fNumPar + i] = full[size_t(i) * _fNumPar + j];
+    return full;
+  }
 
   /// throw matrix -> its lower Cholesky factor (ref: SetThrowMatrix / MakePosDef, ParameterHandlerBase.cpp:1140-1200)
   void SetThrowMatrix(const std::vector<double>& cov) {
     std::vector<double> L(size_t(_fNumPar) * _fNumPar, 0.0);
     for (int i = 0; i < _fNumPar; ++i)
       for (int j = 0; j <= i; ++j) {
-        double s = cov[size_t(i) * _fNumPar + j];
-        for (int k = 0; k < j; ++k) s -= L[size_t(i) * _fNumPar + k] * L[size_t(j) * _fNumPar + k];
+        const double *li = L.data() + size_t(i) * _fNumPar, *lj = L.data() + size_t(j) * _fNumPar;
+        double dot = 0.0;
+M3_OMP(omp simd reduction(+ : dot))
+        for (int k = 0; k < j; ++k) dot += li[k] * lj[k];
+        const double s = cov[size_t(i) * _fNumPar + j] - dot;
         if (i == j) {
           if (s <= 0.0) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
           L[size_t(i) * _fNumPar + i] = std::sqrt(s);
@@ -222,6 +285,7 @@ class ParameterHandlerBase {
         }
       }
     throwMatrixCholDecomp = L;
+    throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)
   }
 
  private:
@@ -246,6 +310,10 @@ class ParameterHandlerBase {
         for (int k = 0; k < n; ++k) { m[size_t(r) * n + k] -= f * m[size_t(c) * n + k]; inv[size_t(r) * n + k] -= f * inv[size_t(c) * n + k]; }
       }
     }
+    // entries of an inverse that decay geometrically away from the diagonal end up denormal, and every multiplication with a
+    // denormal costs ~100 cycles: the prior's row sweeps then take ten times longer for nothing
+    for (double& v : inv)
+      if (std::fabs(v) < 1e-290) v = 0.0;
     return inv;
   }
 
@@ -267,7 +335,9 @@ class ParameterHandlerBase {
   // adaption
   bool use_adaptive = false;
   int start_adaptive_update = 0, end_adaptive_update = 0, start_adaptive_throw = 0, adaptive_update_step = 1, total_steps = 0;
-  std::vector<double> par_means, adaptive_covariance;
+  std::vector<double> par_means, par_means_prev, adaptive_covariance;
+  mutable std::vector<double> diff_scratch;
+  bool adaption_pending = false, throw_ready = false, throw_drawn = false;
 };
 
 /// ref: Fitters/FitterBase.h:36-61 + Fitters/MCMCBase.cpp:32-216 (chain bookkeeping kept in memory)
@@ -348,15 +418,24 @@ class MCMCBase {
   }
   /// everything MR2T2::ProposeStep does after the proposal itself (ref: MR2T2.cpp:33-98)
   void EvaluateProposal() {
+    // Same decisions as the reference (bounds first: a proposal outside them never reaches the samples, MR2T2.cpp:62),
+    // but the O(nPar^2) host work rides under the GPU: Reweight() only LAUNCHES the step; the prior term and the Haario
+    // update left over from the previous step are computed while the device works, and GetLikelihood() then waits.
     out_of_bounds = false;
+    for (auto* s : systematics)
+      if (s->CheckBounds() > 0) out_of_bounds = true;
+    if (!out_of_bounds)
+      for (auto* s : samples) s->Reweight();
     double llh = 0.0;
     for (size_t s = 0; s < systematics.size(); ++s) {
       syst_llh[s] = systematics[s]->GetLikelihood();
       llh += syst_llh[s];
     }
-    if (llh >= M3::_LARGE_LOGL_) out_of_bounds = true;
+    for (auto* s : systematics) {
+      s->FinishPendingAdaption();
+      s->PrepareNextThrow();
+    }
     if (!out_of_bounds) {
-      for (auto* s : samples) s->Reweight();
       for (size_t i = 0; i < samples.size(); ++i) {
         sample_llh[i] = samples[i]->GetLikelihood();
         llh += sample_llh[i];
