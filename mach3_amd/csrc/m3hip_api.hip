@@ -838,7 +838,8 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     const uint32_t* bw = plan.brick_words.data() + bh.words_off;
     bd.n_stages = bw[0];
     bd.off_tf1 = bw[1];
-    for (int i = 0; i < 4; ++i) bd.st0[i] = bd.n_stages ? bw[M3_BRICK_HDR0 + i] : 0u;
+    for (int i = 0; i < 4; ++i) bd.st0[i] = bd.n_stages > 0 ? bw[M3_BRICK_HDR0 + i] : 0u;
+    for (int i = 0; i < 4; ++i) bd.st1[i] = bd.n_stages > 1 ? bw[M3_BRICK_HDR0 + M3_STAGE_HDR + i] : 0u;
     bd.n_dict = uint32_t(plan.tf1_dict.size());
     bd.spl_last_off = bh.n_spl_f4 ? uint32_t((bh.n_spl_f4 - 1) * 16) : 0u;
     bd.pad_[0] = bd.pad_[1] = 0;

@@ -50,7 +50,8 @@ struct BrickDev {
   uint32_t first_event;
   uint32_t n_stages;          // TSpline3 stages
   uint32_t off_tf1;           // word offset of the TF1 section
-  uint32_t st0[4];            // copy of stage 0's header: its metadata is requested without waiting for the header
+  uint32_t st0[4];            // copies of the headers of stages 0 and 1: their metadata is requested without waiting for
+  uint32_t st1[4];            // the header block
   uint32_t n_dict;
   uint32_t spl_last_off;      // byte offset of the spline store's last quad (idle lanes' offsets are clamped to it)
   uint32_t pad_[2];

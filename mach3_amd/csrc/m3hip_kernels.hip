@@ -652,12 +652,17 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
 
   M3_STAMP(0);
-  // ---- prologue.  Round trip 1: the stage headers, stage 0's metadata (its header travels in the descriptor), the
-  // parameter table, and the TF1 side's bookkeeping
+  // ---- prologue: ONE round trip and ONE barrier before the first coefficient loads.  The descriptor carries the headers of
+  // stages 0 and 1, so their metadata is requested together with the header block, the parameter table and the TF1 side's
+  // bookkeeping; stage 0's runs take their {segment, dx} straight from global memory (a second, L2-served round trip for
+  // the few lanes that hold a run) instead of waiting for the table to be visible in LDS behind a barrier of its own.
   uint32_t hdr_w = 0;
   if (lane < kBrickHdrWords) hdr_w = lane < M3_BRICK_HDR0 + M3_STAGE_HDR * n_stages ? words[lane] : 0u;
-  Meta m_cur;
+  Meta m_cur, m_nxt;
   fetch_meta(StageHdr{bd.st0[0], bd.st0[1], bd.st0[2], bd.st0[3]}, m_cur);
+  // stage 1's metadata is requested BEFORE stage 0's coefficient loads: vector memory returns in order, so whatever a
+  // stage's tables need has to be older than the quads that are in flight while the tables are built
+  fetch_meta(StageHdr{bd.st1[0], bd.st1[1], bd.st1[2], bd.st1[3]}, m_nxt);
   const M3_GLOBAL uint32_t* __restrict__ tf1h = words + bd.off_tf1;
   const uint32_t tf1_cnt = (tf1h[32 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;  // codes of this lane's event
   uint32_t tf1_cbase = __builtin_amdgcn_readfirstlane(tf1h[wave]);                // this wave's first slot / code dword
@@ -666,37 +671,29 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
   if (x_in_lds && lane < bd.n_dict) x_own = tf1x[lane].f;
+  PTab t_own;
+  t_own.dx = 0.f;
+  t_own.seg = 0;
+  if (tab_in_lds && lane < (uint32_t)a.n_params) {
+    t_own.dx = ptab[lane].dx;
+    t_own.seg = ptab[lane].seg;
+  }
 #pragma unroll
   for (int j = 0; j < M3_ELL_ROWS; ++j) ell[j * M3_GROUP + lane] = 1.0f;
   if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
-  if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
-  if (x_in_lds && lane < bd.n_dict) lds_tf1x[1 + lane] = x_own;
-  if (lane == 0) lds_tf1x[0] = 0.f;
-  if (tab_in_lds && lane < (uint32_t)a.n_params) {
-    PTab t;
-    t.dx = ptab[lane].dx;
-    t.seg = ptab[lane].seg;
-    lds_ptab[lane] = t;
-  }
-  __syncthreads();  // headers and the parameter table visible
-  M3_STAMP(1);
-  auto hdr = [&](uint32_t s) -> StageHdr {
-    const u32x4_t v = *(const u32x4_t*)(lds_hdr + M3_BRICK_HDR0 + M3_STAGE_HDR * s);
-    return StageHdr{(uint32_t)__builtin_amdgcn_readfirstlane(v.x), (uint32_t)__builtin_amdgcn_readfirstlane(v.y),
-                    (uint32_t)__builtin_amdgcn_readfirstlane(v.z), (uint32_t)__builtin_amdgcn_readfirstlane(v.w)};
-  };
-
-  auto publish = [&](uint32_t s, uint32_t h0, const Meta& m) {  // stage s's run table and group table -> LDS
+  // stage s's run table and group table -> LDS; the parameters' {segment, dx} from LDS (FROM_LDS) or from global memory
+  auto publish = [&](uint32_t s, uint32_t h0, const Meta& m, auto from_lds_tag) {
+    constexpr bool FROM_LDS = decltype(from_lds_tag)::value;
     const uint32_t n_runs = (h0 >> 16) & 0x3FFu;
     if (lane < n_runs + 65u) {
       const uint32_t p = m.run.y >> 16;
       PTab t;
-      if (tab_in_lds) {
+      if (FROM_LDS) {
         t = lds_ptab[p];
-      } else {  // more parameters than the table holds: a dependent global round trip per stage
+      } else {  // stage 0, or more parameters than the LDS table holds: a dependent (L2) round trip
         t.dx = ptab[p].dx;
         t.seg = ptab[p].seg;
       }
@@ -710,13 +707,19 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     // group g = u * 16 + wave -> [wave][u]: a wave fetches its entries of a stage with one 16-byte read
     if (lane < (uint32_t)(M3_STAGE_CAP / 64)) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.grp;
   };
-  // stage 1's metadata is requested BEFORE stage 0's coefficient loads: vector memory returns in order, so whatever a
-  // stage's tables need has to be older than the quads that are in flight while the tables are built
-  Meta m_nxt;
-  fetch_meta(hdr(1), m_nxt);
-  publish(0, bd.st0[0], m_cur);
-  __syncthreads();  // stage 0's tables visible
+  publish(0, bd.st0[0], m_cur, std::false_type{});
+  if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
+  if (x_in_lds && lane < bd.n_dict) lds_tf1x[1 + lane] = x_own;
+  if (lane == 0) lds_tf1x[0] = 0.f;
+  if (tab_in_lds && lane < (uint32_t)a.n_params) lds_ptab[lane] = t_own;
+  __syncthreads();  // stage 0's tables, the headers and the parameter table visible
+  M3_STAMP(1);
   M3_STAMP(2);
+  auto hdr = [&](uint32_t s) -> StageHdr {
+    const u32x4_t v = *(const u32x4_t*)(lds_hdr + M3_BRICK_HDR0 + M3_STAGE_HDR * s);
+    return StageHdr{(uint32_t)__builtin_amdgcn_readfirstlane(v.x), (uint32_t)__builtin_amdgcn_readfirstlane(v.y),
+                    (uint32_t)__builtin_amdgcn_readfirstlane(v.z), (uint32_t)__builtin_amdgcn_readfirstlane(v.w)};
+  };
 
   float4 c[kBrickRPL];
   float dx[kBrickRPL];
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     const uint32_t n_resp = h0 & 0xFFFFu, rows = h0 >> 26;
     Meta m_nn;
     if (!LAST) {
-      publish(s + 1, hdr(s + 1).h0, m_nxt);  // waits for stage s+1's metadata only: it is older than the quads in flight
+      publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight
       fetch_meta(hdr(s + 2), m_nn);
     }
     __syncthreads();  // stage s+1's tables visible; every wave is through its column of stage s-1: the scatter array is free
