@@ -124,7 +124,7 @@ struct ChunkPlan {
 
 // A ragged group is laid out as identity-padded uniform tiles instead of a brick when the responses its events
 // really have fill at least this fraction of the padded slots.  Measured break-even on a 1e6-event, 128-parameter
-// sample (scripts/kbench5.py): at 90 % fill the padded tiles take 314 us against 371 us for bricks, at 75 % both
+// sample (scripts/kbench.py pad): at 90 % fill the padded tiles take 314 us against 371 us for bricks, at 75 % both
 // take ~313 us.  Settable for experiments (M3HIP_PAD_MIN_FILL; > 1 switches the padding off).
 constexpr double kPadMinFillDefault = 0.78;
 extern double g_pad_min_fill;

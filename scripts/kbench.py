@@ -100,8 +100,8 @@ elif args.what == "step":
           f"{np.median(dv[:, 1] + off - dv[:, 3]):.1f} us; k_llh end -> result seen median {np.median(dv[:, 4] - (dv[:, 2] + off)):.1f} us")
     eng.close()
 elif args.what == "pad":  # the reference drops an event's flat splines: nearly uniform lists
-    for occ in (0.9, 0.75):
-        for pad in ("0.78", "2"):
+    for occ in (0.9, 0.8, 0.7):
+        for pad in ("0.01", "2"):  # always padded / never
             os.environ["M3HIP_PAD_MIN_FILL"] = pad
             spec = synth.CONFIGS["c2"].scaled(args.events or 1_000_000, occupancy=occ)
             eng, sh, par, laps = ready(spec)
