@@ -287,6 +287,24 @@ class SampleHandlerFD : public SampleHandlerBase {
   /// M3::float_t = double build (with a BinnedSplineHandlerT<double> behind the handle)
   void SetOscillationWeights(const std::vector<double>& w) { M3HIP_CALL(h, m3hip_set_osc_table_f64(h, w.data(), w.size())); }
 
+  /// Experiment weights behind the spline weight.  The reference lets an experiment append pointers to an event's
+  /// total_weight_pointers (AddAdditionalWeightPointers, SampleHandlerFD.cpp:196; multiplied in that order at :584-591)
+  /// and refresh what they point at in the virtual CalcWeightFunc (SampleHandlerFD.h:289, called at :428).  Here a
+  /// pointer is a slot 0..7, multiplied in ascending order behind the spline weight.  Form 1: the target is a
+  /// per-event variable (flux, POT, detector weights; or whatever CalcWeightFunc computed, uploaded again when it
+  /// changes) ...
+  void AddAdditionalWeightPointers(int Slot, const std::vector<float>& PerEventWeight, unsigned int FirstEvent = 0) {
+    M3HIP_CALL(h, m3hip_upload_event_weights(h, Slot, FirstEvent, PerEventWeight.size(), PerEventWeight.data()));
+  }
+  /// ... form 2: the target is a variable shared by a class of events: an index per event (-1: the event has no such
+  /// pointer) into a table set with SetAdditionalWeights, also every step.
+  void AddAdditionalWeightPointers(int Slot, const std::vector<int32_t>& IndexPerEvent, unsigned int FirstEvent = 0) {
+    M3HIP_CALL(h, m3hip_upload_weight_index(h, Slot, FirstEvent, IndexPerEvent.size(), IndexPerEvent.data()));
+  }
+  void SetAdditionalWeights(int Slot, const std::vector<float>& Table) { M3HIP_CALL(h, m3hip_set_weight_table(h, Slot, Table.data(), Table.size())); }
+  /// bins, W2 and likelihood bit-reproducible from call to call (fixed-order fill instead of fp64 atomics)
+  void SetDeterministicFill(bool On) { M3HIP_CALL(h, m3hip_set_deterministic(h, On ? 1 : 0)); }
+
   // ---- per step (ref: Samples/SampleHandlerFD.cpp:316-343, 1262-1300)
   void Reweight() override { M3HIP_CALL(h, m3hip_reweight(h, fPropVal, nPar)); }
   double GetLikelihood() const override {

@@ -30,6 +30,7 @@ def test_cpp_driver_runs_a_chain():
     assert 0.02 < acc < 0.98
     assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out and "functional parameter" in out
     assert "reloaded monolith are bit-identical" in out
+    assert "experiment weight slots" in out
 
 
 @pytest.mark.gpu
