@@ -99,7 +99,7 @@ int m3hip_device_synchronize(void);
  *   - 256 events that carry the same ordered parameter list form a "uniform tile" (the streaming fast path);
  *   - lists that differ only by a few missing entries (the reference drops an event's flat one-knot splines)
  *     are padded to their union with identity responses {1,0,0,0} / {0,1}, which leave the float product
- *     unchanged bit for bit (at least 78 % of the padded slots must be real; M3HIP_PAD_MIN_FILL);
+ *     unchanged bit for bit (at least 88 % of the padded slots must be real; M3HIP_PAD_MIN_FILL);
  *   - a chunk whose events mix several lists (interaction modes in random order) is PROCESSED grouped by
  *     list -- a lane permutation inside the kernels -- when that avoids the slow path (M3HIP_GROUP_EVENTS=0
  *     switches it off);

@@ -124,9 +124,12 @@ struct ChunkPlan {
 
 // A ragged group is laid out as identity-padded uniform tiles instead of a brick when the responses its events
 // really have fill at least this fraction of the padded slots.  Measured break-even on a 1e6-event, 128-parameter
-// sample (scripts/kbench.py pad): at 90 % fill the padded tiles take 314 us against 371 us for bricks, at 75 % both
-// take ~313 us.  Settable for experiments (M3HIP_PAD_MIN_FILL; > 1 switches the padding off).
-constexpr double kPadMinFillDefault = 0.78;
+// sample (scripts/kbench.py pad, round 2's brick kernel): at 90 % fill padded tiles and bricks take the same time
+// (305.5 / 306.1 us), at 80 % the bricks are 12 % faster (269 vs 305 us), at 70 % 22 % (237 vs 306 us) -- long runs make
+// bricks stream at 76 % of the HBM peak, and padded tiles stream their padding.  (Round 1's brick kernel broke even at
+// 75 %.)  The padded form also costs 1/fill of the store.  Settable for experiments (M3HIP_PAD_MIN_FILL; > 1 switches the
+// padding off).
+constexpr double kPadMinFillDefault = 0.88;
 extern double g_pad_min_fill;
 
 // Validates the chunk against (n_params, npts) and sizes the tile store.

@@ -593,7 +593,7 @@ def test_extreme_shapes(fresh_engine, case, monkeypatch):
     """Edges of the layout: a single event; ragged groups in which a third of the events carry no response
     at all (weight stays 1, SplineMonolith.cpp:798) and some carry TF1s only; a brick with ~190k responses
     in its 1024 events (24+ stages, close to the 30-stage limit); the same 80 %-occupied group laid out as
-    identity-padded uniform tiles (the default for groups that are at least 70 % full); 2 600 parameters."""
+    identity-padded uniform tiles (what groups that carry at least 88 % of their union list become by default); 2 600 parameters."""
     rng = np.random.default_rng({"one_event": 1, "holes": 2, "deep_brick": 3, "padded": 3, "mode_blocks": 4, "many_params": 5}[case])
     X7, X5, X3 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2]), np.array([-1.0, 0, 1])
     if case == "one_event":
@@ -636,8 +636,8 @@ def test_extreme_shapes(fresh_engine, case, monkeypatch):
         n_resp = sum(len(e) for e in events)
         assert 180_000 < n_resp < 200_000
         cx, npts, ch = make_monolith(P, 7, xs, events)
-        if case == "deep_brick":
-            monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "2")      # identity padding off: one brick
+        # 80 % full: a brick by default (>= 88 % would be padded)
+        monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "2" if case == "deep_brick" else "0.7")
         info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng, laps=2)
         if case == "deep_brick":
             assert info.n_tiles_brick == 1 and info.n_tiles_padded == 0

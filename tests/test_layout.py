@@ -319,7 +319,7 @@ def test_ragged_requires_ascending_parameters():
 
 def test_brick_stage_limit_is_reported():
     """more responses in a sparse 1024-event group than the 62 stage headers hold: refused with a message
-    (a group this full but denser than 70 % would be identity-padded into uniform tiles instead)"""
+    (a group whose events carry at least 88 % of the union list would be identity-padded into uniform tiles instead)"""
     rng = np.random.default_rng(9)
     P, X3 = 640, np.array([-1.0, 0, 1])
     c = natural_cubic(X3, [0.9, 1.0, 1.2])
@@ -366,6 +366,7 @@ def test_nearly_uniform_groups_become_identity_padded_tiles(monkeypatch):
                 ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
         events.append(ev)
     cx, npts, ch = make_monolith(P, 7, xs, events)
+    monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "0.8")    # the default (0.88) is right at this sample's fill
     rc, err, lay = debug_layout(P, 7, npts, ch)
     assert rc == 0, err
     assert lay["n_bricks"] == 0 and lay["n_tiles"] == 7
@@ -376,7 +377,7 @@ def test_nearly_uniform_groups_become_identity_padded_tiles(monkeypatch):
     monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "2")
     rc, err, lay = debug_layout(P, 7, npts, ch)
     assert rc == 0 and lay["n_bricks"] == 2 and lay["n_tiles"] == 0
-    monkeypatch.delenv("M3HIP_PAD_MIN_FILL")
+    monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "0.8")
     rc, err, lay = debug_layout(P, 7, npts, ch)
     assert rc == 0 and lay["n_bricks"] == 0
 
