@@ -342,6 +342,9 @@ def main():
         local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks share the card
     torch.cuda.set_device(local_rank)
     dist = None
+    if world == 1 and os.environ.get("M3_BENCH_FORCE_COMM") == "1":  # one-rank rehearsal started without a launcher
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29571")):
+            os.environ.setdefault(k, v)
     if world > 1 or os.environ.get("M3_BENCH_FORCE_COMM") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -112,26 +112,30 @@ elif args.what == "modes":  # four interaction modes, 96 of 128 parameters each,
     rng = np.random.default_rng(1)
     modes = [np.sort(rng.choice(P, L, replace=False)).astype(np.int16) for _ in range(4)]
 
-    def chunk(which):
-        pn = np.concatenate([modes[m] for m in which]).astype(np.int16)
+    def chunk(which, drop):  # drop: fraction of an event's splines that are flat and left out (SplineMonolith.cpp:160-207)
+        keep = [np.ones(L, bool) if drop == 0 else rng.random(L) >= drop for _ in which]
+        cnt = np.array([int(k.sum()) for k in keep], np.uint32)
+        pn = np.concatenate([modes[m][k] for m, k in zip(which, keep)]).astype(np.int16)
         S = len(pn)
+        start = np.concatenate([[0], np.cumsum(cnt[:-1], dtype=np.uint64)]).astype(np.uint32)
         return dict(n_events=len(which), n_splines=S, n_tf1=0, total_nknots=S * K, coeff_many=(1 + 0.01 * rng.standard_normal(S * K * 4)).astype(np.float32),
                     nknots_arr=(np.arange(S, dtype=np.uint64) * K).astype(np.uint32), param_no=pn, coeff_tf1=np.zeros(0, np.float32),
                     param_no_tf1=np.zeros(0, np.int16), npe_tf1=np.zeros(2 * len(which), np.uint32),
-                    npe=np.stack([np.full(len(which), L, np.uint32), (np.arange(len(which), dtype=np.uint64) * L).astype(np.uint32)], axis=1).reshape(-1))
+                    npe=np.stack([cnt, start], axis=1).reshape(-1))
     cx, npts, which = np.tile(np.arange(-3.0, 4.0, dtype=np.float32), P), np.full(P, K, np.int16), rng.integers(0, 4, E)
-    for label, w, env in (("random order, engine grouping", which, None), ("random order, no grouping", which, "0"), ("sorted by mode", np.sort(which), None)):
-        os.environ.pop("M3HIP_GROUP_EVENTS", None) if env is None else os.environ.__setitem__("M3HIP_GROUP_EVENTS", env)
-        eng = Engine(0)
-        mono = SMonolith(eng, P, K, cx, npts, [chunk(w[i:i + 131072]) for i in range(0, E, 131072)])
-        par = np.zeros(P)
-        mono.setSplinePointers(par)
-        sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kPoisson)
-        sh.SetupEvents(0, rng.integers(0, 200, E).astype(np.int32), None, None, None)
-        sh.Reweight(); sh.AddData(sh.GetMCArray())
-        laps = [rng.normal(0, 0.3, P) for _ in range(16)]
-        line(label, eng.info(), *kernel_us(eng, sh, par, laps, n=100))
-        eng.close()
+    for drop in (0.0, 0.15):  # 0.15: too ragged for identity padding (fill 0.85 < 0.88): grouped bricks against mixed bricks
+        for label, w, env in (("random order, engine grouping", which, None), ("random order, no grouping", which, "0"), ("sorted by mode", np.sort(which), None)):
+            os.environ.pop("M3HIP_GROUP_EVENTS", None) if env is None else os.environ.__setitem__("M3HIP_GROUP_EVENTS", env)
+            eng = Engine(0)
+            mono = SMonolith(eng, P, K, cx, npts, [chunk(w[i:i + 131072], drop) for i in range(0, E, 131072)])
+            par = np.zeros(P)
+            mono.setSplinePointers(par)
+            sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kPoisson)
+            sh.SetupEvents(0, rng.integers(0, 200, E).astype(np.int32), None, None, None)
+            sh.Reweight(); sh.AddData(sh.GetMCArray())
+            laps = [rng.normal(0, 0.3, P) for _ in range(16)]
+            line(f"{label}, {drop:.0%} of the splines flat", eng.info(), *kernel_us(eng, sh, par, laps, n=100))
+            eng.close()
 elif args.what == "det":
     for cfg in (args.config or "c2,c3").split(","):
         spec = synth.CONFIGS[cfg].scaled(args.events or (1_000_000 if cfg == "c2" else 2_000_000))

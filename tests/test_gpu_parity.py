@@ -689,6 +689,7 @@ def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkey
                 ev.append((p, "tf1", (0.05 * rng.standard_normal(), 1.0)))
         events.append(ev)
     cx, npts, ch = make_monolith(P, 7, xs, events)
+    monkeypatch.setenv("M3HIP_PAD_MIN_FILL", "0.8")   # this sample's tiles sit around the default (0.88): the test is about grouping
     if grouping == "off":
         monkeypatch.setenv("M3HIP_GROUP_EVENTS", "0")
     n_norm = 3
