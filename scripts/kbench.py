@@ -24,7 +24,7 @@ from mach3_amd import capi, synth
 from mach3_amd.engine import Engine, SMonolith, SampleHandlerFD, build_from_synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("what", choices=["shard", "occ", "step", "pad", "modes", "det"])
+ap.add_argument("what", choices=["shard", "occ", "step", "pad", "modes", "det", "mix"])
 ap.add_argument("--config", default=None)
 ap.add_argument("--events", type=int, default=None)
 ap.add_argument("--unroll", type=int, default=8)
@@ -135,6 +135,16 @@ elif args.what == "modes":  # four interaction modes, 96 of 128 parameters each,
             sh.Reweight(); sh.AddData(sh.GetMCArray())
             laps = [rng.normal(0, 0.3, P) for _ in range(16)]
             line(f"{label}, {drop:.0%} of the splines flat", eng.info(), *kernel_us(eng, sh, par, laps, n=100))
+            eng.close()
+elif args.what == "mix":  # what limits the brick kernel: run length or the TF1 side?  2 x 2: short / long runs, with / without TF1
+    for P, occ in ((512, 1 / 16), (128, 0.5)):
+        for mixed in (False, True):
+            spec = synth.CONFIGS["c3"].scaled(args.events or 2_000_000, n_params=P, occupancy=occ, mixed=mixed)
+            os.environ["M3HIP_PAD_MIN_FILL"] = "2"
+            eng, sh, par, laps = ready(spec)
+            info = eng.info()
+            nb = max(int(info.n_tiles_brick), 1)
+            line(f"P={P} occupancy {occ:g} {'TSpline3 + TF1' if mixed else 'TSpline3 only'}: {1024 * occ:.0f} responses per run", info, *kernel_us(eng, sh, par, laps))
             eng.close()
 elif args.what == "det":
     for cfg in (args.config or "c2,c3").split(","):
