@@ -307,6 +307,11 @@ def roofline(base_name, m, per_gpu):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: libraries that print banners there (RCCL's version block at communicator
+    # init, for one) are sent to stderr for the whole run, and the line is written to the saved descriptor at the end
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -416,7 +421,7 @@ def main():
                                                "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}}
             except Exception as e:
                 out["extra"] = {"configs[1]": {"failed": str(e)}}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         if check is not None and not check["ok"]:
             raise SystemExit(4)
     if dist is not None:
