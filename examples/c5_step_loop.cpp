@@ -28,8 +28,12 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 int main(int argc, char** argv) {
   const uint64_t E = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 12500000ull;
-  const int NSteps = argc > 2 ? std::atoi(argv[2]) : 300;
-  const int UpdateStep = argc > 3 ? std::atoi(argv[3]) : 100;
+  const int NSteps = argc > 2 ? std::atoi(argv[2]) : 4000;
+  const int UpdateStep = argc > 3 ? std::atoi(argv[3]) : 200;
+  // the running covariance of a 1 040-parameter chain is singular until the chain has visited more points than it has
+  // parameters: the throw matrix follows it from this step on (before, every update would be made decomposable by
+  // diagonal shifts, as the reference does, and propose along the few directions visited so far)
+  const int StartThrow = argc > 4 ? std::atoi(argv[4]) : 3000;
   m3synth_config cfg{};  // mach3_amd/synth.py: CONFIGS["c5"]
   cfg.seed = 20260318; cfg.n_params = 1024; cfg.n_knots = 7; cfg.mixed = 1; cfg.n_norm = 16; cfg.max_norm_per_event = 3;
   cfg.n_samples = 1; cfg.n_bins = 200; cfg.osc_n = 4000 + 200000; cfg.occupancy = 1.0 / 64; cfg.bin_lo = 0.0; cfg.bin_hi = 5.0;
@@ -100,7 +104,7 @@ int main(int argc, char** argv) {
   const double t_ph = now_s();
   ParameterHandlerBase par("c5_pars", prefit, cov, lo, up, {}, 12345);
   par.SetStepScale(0.3 * par.GetGlobalStepScale());
-  par.InitialiseAdaption(0, 1 << 30, 50, UpdateStep);
+  par.InitialiseAdaption(0, 1 << 30, StartThrow, UpdateStep);
   std::printf("parameter handler for %d parameters (inverse + Cholesky of the prior covariance): %.2f s\n", nPar, now_s() - t_ph);
 
   // Asimov data at the prior centre (Fitters/MaCh3Factory.h:142-153)
@@ -156,8 +160,8 @@ int main(int argc, char** argv) {
   const double us = 1e6 / NSteps;
   std::printf("%d steps in %.3f s = %.0f steps/s (%.1f us/step); acceptance %.2f, out of bounds %d\n", NSteps, el, NSteps / el, el * us, double(accepted) / NSteps, oob);
   std::printf("per step: propose %.1f us | bounds + launch %.1f us | prior + Haario update + next step's correlated throw UNDER the GPU step %.1f us | rest of the wait for the "
-              "likelihood %.1f us | accept (+ a new Cholesky factor every %d steps) %.1f us, worst %.1f us\n",
-              t_prop * us, t_launch * us, t_under * us, t_wait * us, UpdateStep, t_acc * us, t_acc_max * 1e6);
+              "likelihood %.1f us | accept (+ a new Cholesky factor every %d steps from step %d on) %.1f us, worst %.1f us\n",
+              t_prop * us, t_launch * us, t_under * us, t_wait * us, UpdateStep, StartThrow, t_acc * us, t_acc_max * 1e6);
   const double exposed = t_prop + t_acc, gpu = t_launch + t_under + t_wait;
   std::printf("host work on the step's critical path %.1f us = %.1f %% of the step; the GPU step spans %.1f us, of which the host computed during %.1f us\n",
               exposed * us, 100.0 * exposed / (exposed + gpu), gpu * us, t_under * us);

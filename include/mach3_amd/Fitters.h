@@ -253,7 +253,7 @@ M3_OMP(omp simd)
       try {
         SetThrowMatrix(adaptive_covariance);
       } catch (const MaCh3Exception&) {
-        // not positive definite yet (too few distinct points): keep the previous throw matrix
+        // could not be made positive definite: keep the previous throw matrix
       }
     }
     ++total_steps;
@@ -267,23 +267,35 @@ M3_OMP(omp simd)
     return full;
   }
 
-  /// throw matrix -> its lower Cholesky factor (ref: SetThrowMatrix / MakePosDef, ParameterHandlerBase.cpp:1140-1200)
+  /// throw matrix -> its lower Cholesky factor (ref: SetThrowMatrix, ParameterHandlerBase.cpp:1140-1200).  A matrix that
+  /// cannot be decomposed gets 1e-9 added to its diagonal until it can, as M3::MakeMatrixPosDef does
+  /// (Parameters/ParameterHandlerUtils.h:512-545; an adaptive covariance from fewer steps than parameters is singular).
   void SetThrowMatrix(const std::vector<double>& cov) {
     std::vector<double> L(size_t(_fNumPar) * _fNumPar, 0.0);
-    for (int i = 0; i < _fNumPar; ++i)
-      for (int j = 0; j <= i; ++j) {
-        const double *li = L.data() + size_t(i) * _fNumPar, *lj = L.data() + size_t(j) * _fNumPar;
-        double dot = 0.0;
+    constexpr int MaxAttempts = 100000;
+    double shift = 0.0;
+    for (int attempt = 0;; ++attempt, shift += 1e-9) {
+      bool ok = true;
+      for (int i = 0; i < _fNumPar && ok; ++i)
+        for (int j = 0; j <= i; ++j) {
+          const double *li = L.data() + size_t(i) * _fNumPar, *lj = L.data() + size_t(j) * _fNumPar;
+          double dot = 0.0;
 M3_OMP(omp simd reduction(+ : dot))
-        for (int k = 0; k < j; ++k) dot += li[k] * lj[k];
-        const double s = cov[size_t(i) * _fNumPar + j] - dot;
-        if (i == j) {
-          if (s <= 0.0) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
-          L[size_t(i) * _fNumPar + i] = std::sqrt(s);
-        } else {
-          L[size_t(i) * _fNumPar + j] = s / L[size_t(j) * _fNumPar + j];
+          for (int k = 0; k < j; ++k) dot += li[k] * lj[k];
+          const double s = cov[size_t(i) * _fNumPar + j] + (i == j ? shift : 0.0) - dot;
+          if (i == j) {
+            if (!(s > 0.0)) {
+              ok = false;
+              break;
+            }
+            L[size_t(i) * _fNumPar + i] = std::sqrt(s);
+          } else {
+            L[size_t(i) * _fNumPar + j] = s / L[size_t(j) * _fNumPar + j];
+          }
         }
-      }
+      if (ok) break;
+      if (attempt + 1 >= MaxAttempts) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
+    }
     throwMatrixCholDecomp = L;
     throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)
   }
