@@ -395,6 +395,9 @@ def main():
             "config": {
                 "workload": workload_text(base, spec, n_gpus),
                 "total_events": spec.n_events,
+                # the job's work rate, comparable across the two workloads the N-series uses (N <= 2: configs[2], 1e7
+                # events; N = 4, 8: configs[3], 4e7 events): scaling efficiency across that switch is the ratio of THESE
+                "event_steps_per_s": spec.n_events * args.steps / m["el"],
                 "events_per_gpu": per_gpu,
                 "responses_rank0": int(m["info"].n_splines + m["info"].n_tf1),
                 "comm": m["comm"],
