@@ -144,9 +144,14 @@ def shard_of(spec, rank, n_ranks):
     blk = 65536
     edges = list(range(0, spec.n_events, blk)) + [spec.n_events]
     w = np.empty(spec.n_events, np.float32)
-    for a, b in zip(edges[:-1], edges[1:]):
-        ns, nt = synth.count(spec, a, b)
+
+    def fill(ab):
+        a, b = ab
+        ns, nt = synth.count(spec, a, b)  # a ctypes call: runs without the interpreter lock
         w[a:b] = (ns + nt) / max(b - a, 1)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 8) // max(n_ranks, 1)))) as pool:
+        list(pool.map(fill, zip(edges[:-1], edges[1:])))
     return dist.shard_ranges(spec.n_events, n_ranks, weights=w)[rank]
 
 
