@@ -29,17 +29,23 @@ buf = np.zeros(n * 16, np.uint64)
 rc = eng.lib.m3hip_debug_read_stamps(C.c_void_p(buf.ctypes.data), C.c_uint64(buf.size))
 assert rc == 0, rc
 t = buf.reshape(n, 16).astype(np.int64)
-names = {1: "prologue: round trip 1 + barrier", 2: "stage 0 tables + barrier", 3: "stage 0", 4: "stage 1", 5: "stage 2", 6: "stage 3",
-         8: "last stage", 9: "TF1 rows", 10: "event tail (norm, osc, bin, LDS fill) + barrier", 11: "flush of the bin vector"}
-prev = 0
+names = {1: "prologue: first round trip, tables of stage 0, barrier", 2: "(stamp 2: unused)", 3: "stage 0 (waits for the first quads)", 4: "stage 1", 5: "stage 2",
+         6: "stage 3", 8: "last stage", 9: "TF1 rows", 10: "event tail (norm, osc, bin, LDS fill) + barrier", 11: "flush of the bin vector"}
 tot = (t[:, 11] - t[:, 0]) / 100.0
 print(f"{cfg} E={ev}: {nb} bricks; brick lifetime mean {tot.mean():.1f} us, median {np.median(tot):.1f} us")
+# a brick writes only the stamps of the stages it has (3 + s for its first four stages except the last one, 8 after the last);
+# slots it did not write hold what an earlier launch left there: a stamp counts when it lies between its predecessor and the end
+acc = {k: [] for k in names}
+for r in t:
+    prev = r[0]
+    for k in sorted(names):
+        if prev <= r[k] <= r[11]:
+            acc[k].append((r[k] - prev) / 100.0)
+            prev = r[k]
 for k in sorted(names):
-    ok = t[:, k] > 0
-    d = (t[ok, k] - t[ok, prev]) / 100.0
-    if ok.any():
-        print(f"  {names[k]:55s} mean {d.mean():6.2f} us  median {np.median(d):6.2f} us  ({100 * d.mean() / tot.mean():4.1f} %)")
-    prev = k
+    d = np.array(acc[k])
+    if d.size and k != 2:
+        print(f"  {names[k]:55s} mean {d.mean():6.2f} us  median {np.median(d):6.2f} us  ({d.size:5d} bricks; {100 * d.sum() / tot.sum():4.1f} % of all brick time)")
 first, last = t[:, 0].min(), t[:, 11].max()
 print(f"  launch span {((last - first) / 100.0):.1f} us; bricks in flight on average {tot.sum() / ((last - first) / 100.0):.0f}")
 eng.close()
