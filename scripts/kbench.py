@@ -6,6 +6,7 @@
     python scripts/kbench.py step   [--config c2] [--events 1000000]      step latency, host phases and device span of ONE library build
     python scripts/kbench.py pad    [--events 1000000]                    identity-padded tiles vs bricks on nearly uniform lists
     python scripts/kbench.py modes  [--events 1000000]                    engine-side grouping of shuffled interaction modes
+    python scripts/kbench.py mix    [--events 2000000]                    brick kernel: short / long runs x with / without TF1 responses
     python scripts/kbench.py det    [--config c2,c3]                      cost of the deterministic fill
 
 Two builds are compared by running the script twice in ONE gpurun call with M3HIP_LIB=<path to the other libm3hip.so>
