@@ -101,3 +101,24 @@ def test_shard_ranges():
     loads = [w[a:b].sum() for a, b in rw]
     assert max(loads) / min(loads) < 1.1 and rw[-1][1] == 81920 and rw[0][1] == 40960
     assert shard_ranges(100, 4)[0] == (0, 100)  # fewer events than one group: rank 0 holds them all
+
+
+def test_bench_shards_cover_the_sample_and_balance_the_responses():
+    """bench.py's split of a configuration over ranks (what every rank computes for itself, from the generator's counts):
+    contiguous, on 1024-event boundaries, the same on every rank, responses balanced to a per cent"""
+    import importlib.util
+
+    spec_ = importlib.util.spec_from_file_location("m3_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    from mach3_amd import synth
+
+    spec = synth.CONFIGS["c3"].scaled(600_000)
+    for n in (2, 4, 8):
+        r = [bench.shard_of(spec, k, n) for k in range(n)]
+        assert r == [bench.shard_of(spec, k, n) for k in range(n)]
+        assert r[0][0] == 0 and r[-1][1] == spec.n_events and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all(a[1] % 1024 == 0 for a in r[:-1])
+        loads = [sum(synth.count(spec, a, b)) for a, b in r]
+        assert max(loads) / min(loads) < 1.02, loads
+    assert bench.shard_of(spec, 0, 1) == (0, spec.n_events)
