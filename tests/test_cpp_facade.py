@@ -120,3 +120,19 @@ def test_reference_call_sites_of_SMonolithGPU_run_unchanged():
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
     osamp.close()
     omono.close()
+
+
+@pytest.mark.gpu
+def test_configs4_step_loop_example_runs():
+    """examples/c5_step_loop.cpp at a small size: 1 040 parameters, adaptive proposal taking over part way, the host's
+    O(P^2) work overlapped with the device step; the run reports its phases and ends with OK"""
+    exe = os.path.join(ROOT, "build", "c5_step_loop")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    r = subprocess.run([exe, "200000", "1500", "100", "1200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert out.strip().endswith("OK") and "1024 spline parameters + 16 norm" in out
+    acc = float(out.split("acceptance ")[1].split(",")[0])
+    assert 0.05 < acc < 0.99
+    assert "out of bounds 0" in out and "host work on the step's critical path" in out
