@@ -568,8 +568,16 @@ __device__ unsigned long long g_brick_stamps[kStampBricks * kStampSlots];
 extern "C" int m3hip_debug_read_stamps(unsigned long long* out, unsigned long long n_words) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_brick_stamps), sizeof(unsigned long long) * n_words, 0, hipMemcpyDeviceToHost);
 }
+// slot 12: where the workgroup ran -- HW_ID (hwreg 4: cu_id bits 8..11, sh_id 12, se_id 13..15) | XCC_ID (hwreg 20) << 32
+#define M3_STAMP_HWID()                                                                                   \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < kStampBricks)                                                    \
+      g_brick_stamps[blockIdx.x * kStampSlots + 12] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | \
+                                                      ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+  } while (0)
 #else
 #define M3_STAMP(k) do {} while (0)
+#define M3_STAMP_HWID() do {} while (0)
 #endif
 
 // A wave-uniform address, pinned into an SGPR pair: the lane-dependent part of a load's address then stays a 32-bit
@@ -654,6 +662,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
 
   M3_STAMP(0);
+  M3_STAMP_HWID();
   // ---- prologue: ONE round trip and ONE barrier before the first coefficient loads.  The descriptor carries the headers of
   // stages 0 and 1, so their metadata is requested together with the header block, the parameter table and the TF1 side's
   // bookkeeping; stage 0's runs take their {segment, dx} straight from global memory (a second, L2-served round trip for

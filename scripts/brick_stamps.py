@@ -48,4 +48,33 @@ for k in sorted(names):
         print(f"  {names[k]:55s} mean {d.mean():6.2f} us  median {np.median(d):6.2f} us  ({d.size:5d} bricks; {100 * d.sum() / tot.sum():4.1f} % of all brick time)")
 first, last = t[:, 0].min(), t[:, 11].max()
 print(f"  launch span {((last - first) / 100.0):.1f} us; bricks in flight on average {tot.sum() / ((last - first) / 100.0):.0f}")
+# occupancy over the launch and the gaps between successive workgroups of one CU (slot 12: HW_ID | XCC_ID << 32)
+hw = buf.reshape(n, 16)[:, 12]
+cu = ((hw >> 32) & 0xF).astype(np.int64) * 4096 + ((hw >> 8) & 0xFF).astype(np.int64)   # xcc, (se, sh, cu)
+t0, t1 = t[:, 0], t[:, 11]
+span = last - first
+edges = np.linspace(first, last, 21)
+occ = [(np.clip(np.minimum(t1, b) - np.maximum(t0, a), 0, None).sum() / (b - a)) for a, b in zip(edges[:-1], edges[1:])]
+print("  bricks in flight per twentieth of the launch: " + " ".join(f"{o:.0f}" for o in occ))
+ncu = len(np.unique(cu))
+idle2, idle1, gaps = 0, 0, []
+for c in np.unique(cu):
+    m = cu == c
+    ev_t = np.concatenate([t0[m], t1[m]])
+    ev_d = np.concatenate([np.ones(m.sum(), np.int64), -np.ones(m.sum(), np.int64)])
+    o = np.lexsort((ev_d, ev_t))
+    ev_t, ev_d = ev_t[o], ev_d[o]
+    lvl = np.cumsum(ev_d)
+    # time at level < 2 between the CU's first start and its last start (the tail after the last start is counted separately)
+    last_start = t0[m].max()
+    for i in range(len(ev_t) - 1):
+        a, b = ev_t[i], min(ev_t[i + 1], last_start)
+        if b > a and lvl[i] < 2:
+            (gaps.append((b - a) / 100.0))
+            idle1 += (b - a) * (2 - lvl[i])
+    idle2 += (2 * (last - last_start) - np.clip(t1[m] - last_start, 0, None).sum())
+print(f"  {ncu} CUs seen; slot-time idle between a CU's workgroups {100 * idle1 / (2 * ncu * span):.1f} % of all slot time "
+      f"(gap mean {np.mean(gaps) if gaps else 0:.2f} us, median {np.median(gaps) if gaps else 0:.2f} us, {len(gaps)} gaps); "
+      f"idle behind a CU's last start (tail) {100 * idle2 / (2 * ncu * span):.1f} %; ramp (first start after launch start) "
+      f"{100 * sum((t0[cu == c].min() - first) * 2 for c in np.unique(cu)) / (2 * ncu * span):.1f} %")
 eng.close()
