@@ -74,6 +74,11 @@ int m3hip_free_pinned(m3hip_handle h, void* ptr);
 /* SynchroniseSplines() (gpuSplineUtils.cu:71-73: cudaDeviceSynchronize), a free function in the reference */
 int m3hip_device_synchronize(void);
 
+/* Optional, before the first m3hip_monolith_append: the number of events this device is going to hold (the reference
+ * knows it when it sizes its buffers: InitGPU_SplineMonolith's n_events, Splines/gpuSplineUtils.cuh:76-82).  Uploads are
+ * streamed, so the engine cannot see the total by itself; with it, samples of many light events are laid out in bricks of
+ * 2048 or 4096 events instead of 1024.  0 = unknown. */
+int m3hip_monolith_expect_events(m3hip_handle h, uint64_t n_events);
 /*
  * One-time upload of the flattened monolith.  Replaces InitGPU_SplineMonolith +
  * CopyToGPU_SplineMonolith (gpuSplineUtils.cu:116-333).  Input is the reference's flat
@@ -354,6 +359,7 @@ typedef struct {
   uint64_t pad_responses;   /* identity responses added by that padding (TSpline3 + TF1); not in n_splines / n_tf1 */
   uint64_t n_grouped_chunks; /* upload chunks whose events the engine grouped by parameter list (processing order only:
                               * every per-event array and result keeps the caller's event order) */
+  uint64_t brick_groups;     /* G: a brick holds up to G x 1024 events (1, 2 or 4; 0 before the first chunk) */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

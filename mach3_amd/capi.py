@@ -27,7 +27,7 @@ M3HIP_SYMBOLS = [
     "m3hip_get_bins", "m3hip_get_spline_weights", "m3hip_record_event_weights", "m3hip_get_event_weights",
     "m3hip_get_segments",
     "m3hip_comm_get_unique_id", "m3hip_comm_init", "m3hip_comm_destroy", "m3hip_comm_available", "m3hip_device_synchronize", "m3hip_upload_event_weights", "m3hip_upload_weight_index",
-    "m3hip_set_weight_table", "m3hip_set_deterministic",
+    "m3hip_set_weight_table", "m3hip_set_deterministic", "m3hip_monolith_expect_events",
     "m3hip_comm_set_validate", "m3hip_comm_last_validation",
     "m3hip_debug_layout", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
     "m3hip_get_info", "m3hip_timing_enable", "m3hip_timing_read", "m3hip_timing_reset", "m3hip_version",
@@ -54,7 +54,7 @@ class Info(C.Structure):
         ("n_tiles_uniform", C.c_uint64), ("n_tiles_brick", C.c_uint64),
         ("coeff_bytes", C.c_uint64), ("alg_bytes_eval", C.c_uint64), ("alg_bytes_fused", C.c_uint64),
         ("n_params", C.c_int), ("max_knots", C.c_int), ("n_bins", C.c_int), ("n_samples", C.c_int),
-        ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64),
+        ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64), ("brick_groups", C.c_uint64),
     ]
 
 
@@ -149,6 +149,7 @@ def load_m3hip():
         "m3hip_upload_weight_index": [vp, i32, u64, u64, vp],
         "m3hip_set_weight_table": [vp, i32, vp, u64],
         "m3hip_set_deterministic": [vp, i32],
+        "m3hip_monolith_expect_events": [vp, u64],
         "m3hip_comm_set_validate": [vp, i32],
         "m3hip_comm_last_validation": [vp, vp, vp],
         "m3hip_get_info": [vp, C.POINTER(Info)],
@@ -163,6 +164,8 @@ def load_m3hip():
         "m3hip_debug_layout": [i32, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
+        if os.environ.get("M3HIP_LIB") and not hasattr(lib, name):
+            continue  # A/B runs against an older build: entry points it lacks stay unbound
         f = getattr(lib, name)
         f.argtypes = args
         f.restype = C.c_int

@@ -125,6 +125,10 @@ struct m3hip_ctx {
   int32_t* d_bin = nullptr;
   int32_t* d_osc = nullptr;
   int16_t* d_nidx = nullptr;
+  uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
+  bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
+  bool evw_ok = false;            // the sample fits the packed word's fields
+  int64_t min_norm_idx = INT64_MAX;
   uint32_t M = 0;
   // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
   // index with them unguarded)
@@ -187,6 +191,8 @@ struct m3hip_ctx {
   bool perm_dirty = false;
   std::vector<std::pair<uint64_t, std::vector<uint32_t>>> grouped;  // (first event, order) of every grouped chunk
   bool perm_monolith = false;     // some chunk was grouped
+  int brick_groups = 0;           // G of this monolith's bricks (m3hip_layout.h); 0 until the first chunk with ragged events fixes it
+  uint64_t expect_events = 0;     // m3hip_monolith_expect_events: the events this device will hold (0: unknown)
   uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
@@ -372,6 +378,10 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bin); h->d_bin = nullptr;
   dev_free(h->d_osc); h->d_osc = nullptr;
   dev_free(h->d_nidx); h->d_nidx = nullptr;
+  dev_free(h->d_evw); h->d_evw = nullptr;
+  h->evw_dirty = true;
+  h->evw_ok = false;
+  h->min_norm_idx = INT64_MAX;
   for (auto& x : h->extra) {
     dev_free(x.d_col); dev_free(x.d_idx); dev_free(x.d_tab);
     for (int i = 0; i < 2; ++i)
@@ -405,6 +415,7 @@ void free_monolith(m3hip_handle h) {
   h->grouped.clear();
   h->perm_monolith = false;
   h->n_grouped_chunks = 0;
+  h->brick_groups = 0;
   h->h_bl_id.clear();
   h->perm_dirty = false;
   h->bl_mode = -1;
@@ -455,6 +466,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   memset(&a, 0, sizeof(a));
   a.tiles = h->d_tiles;
   a.bricks = h->d_bricks;
+  a.brick_groups = uint32_t(h->brick_groups > 0 ? h->brick_groups : 1);
   a.ptab = h->d_ptab;
   a.pval = h->d_pval;
   a.n_params = h->P;
@@ -664,6 +676,32 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
+// G of an engine's bricks (m3hip_layout.h: a brick holds up to G x 1024 events).  Larger bricks spread a workgroup's fixed
+// phases over more events and lengthen the parameter runs, but leave fewer workgroups: the device wants several rounds
+// of its 512 resident ones.  M3HIP_BRICK_GROUPS = 1 | 2 | 4 overrides; without m3hip_monolith_expect_events the total is
+// unknown and G stays 1.
+static int choose_brick_groups(const ChunkInput& in, uint64_t expect_events) {
+  if (const char* f = getenv("M3HIP_BRICK_GROUPS")) {
+    const int g = atoi(f);
+    if (g == 1 || g == 2 || g == 4) return g;
+  }
+  if (expect_events == 0 || in.n_events == 0) return 1;
+  uint64_t resp = 0;
+  for (uint64_t e = 0; e < in.n_events; ++e) resp += uint64_t(in.npe[2 * e]) + in.npe_tf1[2 * e];
+  const double per_event = double(resp) / double(in.n_events);
+  // measured (round 3, scripts/gexp.py): 2048-event bricks are worth +4 % at 16 responses per event (config 5), nothing
+  // at 32 (config 3: what the larger bricks save is lost in the longer tail of the launch); 4096-event bricks lose
+  int g = per_event <= 24.0 ? 2 : 1;
+  while (g > 1 && expect_events / (uint64_t(M3_GROUP) * g) < 4096) g /= 2;  // at least ~8 rounds of workgroups
+  return g;
+}
+
+int m3hip_monolith_expect_events(m3hip_handle h, uint64_t n_events) try {
+  if (!h) return M3HIP_EINVAL;
+  h->expect_events = n_events;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
 int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
                           const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                           const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
@@ -691,7 +729,10 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
-  if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
+  // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
+  if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->expect_events);
+  const int G = h->brick_groups;
+  if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err, G)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
   // Grouping.  When a sizeable part of the chunk would end up in bricks, try the chunk with its events grouped by
   // parameter list (stable sort): events of one interaction mode then sit together and form uniform (or padded)
@@ -732,7 +773,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
       in_g.npe_tf1 = npe_tf1_g.data();
       ChunkPlan plan_g;
       std::string err_g;
-      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g)) {
+      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g, G)) {
         uint64_t ragged_g = 0;
         for (const BrickHost& bh : plan_g.bricks) ragged_g += bh.n_events;
         if (ragged_g * 2 <= ragged) {  // at least halves what goes through bricks
@@ -842,7 +883,8 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     for (int i = 0; i < 4; ++i) bd.st1[i] = bd.n_stages > 1 ? bw[M3_BRICK_HDR0 + M3_STAGE_HDR + i] : 0u;
     bd.n_dict = uint32_t(plan.tf1_dict.size());
     bd.spl_last_off = bh.n_spl_f4 ? uint32_t((bh.n_spl_f4 - 1) * 16) : 0u;
-    bd.pad_[0] = bd.pad_[1] = 0;
+    bd.pad_[0] = bh.groups;
+    bd.pad_[1] = 0;
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;
@@ -879,6 +921,7 @@ int m3hip_monolith_end(m3hip_handle h) try {
   }
   for (uint64_t t = 0; t < n_tiles; ++t) h->h_tiles[t].res = h->d_resolved + h->tile_res_off[t];
   for (size_t b = 0; b < h->h_bricks.size(); ++b) h->h_bricks[b].tf1_x = h->d_resolved + h->brick_res_off[b];
+  h->expect_events = 0;  // the hint belongs to this upload
   h->list_index.clear();
   if ((rc = dev_alloc(h, &h->d_bricks, h->h_bricks.size()))) return rc;
   if (!h->h_bricks.empty())
@@ -1047,6 +1090,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
     mx = std::max<int64_t>(mx, bin_idx[i]);
   }
   h->max_bin_idx = std::max(h->max_bin_idx, mx);  // re-checked by m3hip_reweight: the bin space may be (re)defined later
+  h->evw_dirty = true;
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   if (osc_idx) {
     for (uint64_t i = 0; i < n; ++i) h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
@@ -1078,6 +1122,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
           plane[i] = (m < c) ? norm_idx[norm_off[i] + m] : int16_t(-1);
           if (m < c && plane[i] < 0) return fail(h, M3HIP_EINVAL, "upload_events: negative norm parameter index");
           h->max_norm_idx = std::max<int64_t>(h->max_norm_idx, plane[i]);
+          if (m < c) h->min_norm_idx = std::min<int64_t>(h->min_norm_idx, plane[i]);
         }
         HIPCHK(h, hipMemcpy(h->d_nidx + size_t(m) * h->E_pad + event_offset, plane.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice));
       }
@@ -1475,6 +1520,8 @@ int m3hip_compute_bins(m3hip_handle h) try {
   b.compute_nominal = 1;
   b.n_shifts = 0;
   launch_find_bins(b, h->stream);
+  h->evw_dirty = true;  // d_bin is rewritten
+  h->max_bin_idx = std::max<int64_t>(h->max_bin_idx, int64_t(h->n_bins) - 1);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, wait_stream(h->stream));
   h->bins_computed = true;
@@ -1875,10 +1922,28 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       HIPCHK(h, hipMemcpy(h->d_perm, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice));
     }
   }
+  // the brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields
+  if (!h->f64 && !h->h_bricks.empty()) {
+    if (dyn_bins) h->evw_dirty = true;  // the fused re-binning rewrites d_bin every step
+    else if (h->evw_dirty) {
+      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->M <= 3 &&
+                  (h->max_norm_idx < 0 || h->max_norm_idx - h->min_norm_idx <= 62) && h->d_bin && h->d_osc;
+      if (const char* f = getenv("M3HIP_PACKED_EVENTS")) h->evw_ok = h->evw_ok && f[0] != '0';
+      if (h->evw_ok) {
+        if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
+        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, h->M, h->E_pad, int32_t(h->max_norm_idx < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+      }
+      h->evw_dirty = false;
+    }
+  }
   ReweightArgs a = make_rw_args(h);
   if (dyn_bins && !h->f64) {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;
+  }
+  if (!h->f64 && !dyn_bins && h->evw_ok && !h->evw_dirty) {
+    a.evw = h->d_evw;
+    a.evw_norm_base = int32_t(h->max_norm_idx < 0 ? 0 : h->min_norm_idx);
   }
   if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;
@@ -2226,7 +2291,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
-  if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err)) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
+  if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err, choose_brick_groups(in, 0))) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
   sizes[0] = plan.tiles.size();
   sizes[1] = plan.spl_float4;
   sizes[2] = plan.tf1_float2;
@@ -2273,6 +2338,7 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) try {
   out->n_tiles_padded = h->n_padded;
   out->pad_responses = h->pad_responses;
   out->n_grouped_chunks = h->n_grouped_chunks;
+  out->brick_groups = uint64_t(h->brick_groups);
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

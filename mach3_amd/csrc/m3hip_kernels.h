@@ -40,7 +40,7 @@ struct TileDev {
   uint32_t first_event;  // padded global index of lane 0
 };
 
-// Device-side descriptor of one brick (ragged group of <= 1024 events), see m3hip_layout.h.  Read with scalar loads.
+// Device-side descriptor of one brick (ragged group of <= G x 1024 events), see m3hip_layout.h.  Read with scalar loads.
 struct BrickDev {
   const float4* spl;
   const float2* tf1;
@@ -129,6 +129,11 @@ struct ReweightArgs {
   const int32_t* bin;        // [E_pad]
   const int32_t* osc;        // [E_pad]
   const int16_t* nidx;       // [M][E_pad] ELL of global parameter indices, padded with n_par (-> 1.0)
+  // The three arrays above as ONE 8-byte word per event (brick kernel; null when a sample does not fit the fields):
+  // bin + 1 in bits 0..19, osc + 1 in bits 20..43, up to three norm indices in bits 44..61 as 6-bit codes idx - evw_norm_base + 1
+  // (0: none).  14 B -> 8 B per event; rebuilt on the device (k_pack_events) whenever one of the arrays changes.
+  const uint64_t* evw;
+  int32_t evw_norm_base;
   const double* params;      // [n_par + 1], last entry 1.0
   const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
   // ... or, when neighbouring events share their lists (MC ordered by spline bin), one list id per event into a
@@ -161,6 +166,7 @@ struct ReweightArgs {
                              // straight into its workgroup's global replica (thousands of bins: no contention to hide,
                              // and the LDS would cost occupancy)
   uint32_t tile_base;        // index of the first tile handled by this launch
+  uint32_t brick_groups;     // G of the engine's bricks (1, 2 or 4): events per brick = G x 1024
   BinArgs dyn;               // DYN variants only: the event's bin is recomputed from its shifted kinematics in the
                              // epilogue (functional parameters), instead of being read from `bin`
 };
@@ -244,6 +250,8 @@ struct LlhArgs {
   uint64_t ticket;
 };
 
+void launch_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots, uint64_t e_pad, int32_t norm_base,
+                        uint64_t* out, hipStream_t s);
 void launch_prep(const PrepArgs& a, hipStream_t s);
 void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s);
 // run-time tuning knobs of the reweight kernel (m3hip_debug_set_knobs)

@@ -522,22 +522,9 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
 }
 
 // ------------------------------------------------------------------------------------
-// k_reweight_brick: one 1024-lane workgroup per brick (<= 1024 events with ragged parameter lists), lane = event.
-//
-// TSpline3 responses, stage by stage (<= M3_STAGE_CAP responses): phase A evaluates the stage's responses
-// lane-per-response in PARAMETER-major order -- a run's active segment plane is contiguous, so the float4 loads
-// coalesce -- and scatters each weight to ell[rank][event] in LDS; phase B lets every event multiply its column
-// ell[0..n)[event], ascending parameter = the reference's order.  TF1 responses are read lane-per-event from the wave's
-// jagged rows straight into the register product (no segment to select, so no regrouping and no LDS).
-// HBM bytes per TSpline3 response: 16 (quad) + 2 (word) (+ the padding of the run's plane to a 128-B line);
-// per TF1 response: 8 + 1; per run: 8; per event: 1 + the sample side.
-//
-// Latency structure.  The coefficient loads of stage s+1 are issued BEFORE phase B of stage s (right after the barrier
-// that publishes the stage's resolved run table), so a workgroup has quads in flight through its barriers and LDS
-// phases; everything those loads need -- response words, run entries -- is requested one stage earlier still, and the
-// parameters' {segment, dx} sit in LDS, so no dependent round trip lies between two stages' coefficient loads.
+// k_reweight_brick (description at the kernel)
 // ------------------------------------------------------------------------------------
-constexpr int kBrickThreads = 1024;                                // one event per lane; 2 workgroups per CU = 8 waves per SIMD
+constexpr int kBrickThreads = 1024;                                // lane l owns events l, l + 1024, ...; 2 workgroups per CU = 8 waves per SIMD
 constexpr int kBrickRPL = M3_STAGE_CAP / kBrickThreads;            // responses per lane and stage = coefficient loads in flight per lane
 constexpr int kBrickHdrWords = M3_BRICK_HDR0 + M3_STAGE_HDR * (M3_BRICK_MAX_STAGES + 2);  // + 2: look-ahead reads past the last stage see zeros
 constexpr int kBrickLdsParams = 1024;                              // per-step parameter table {segment, dx} kept in LDS up to this P
@@ -546,11 +533,14 @@ constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 64 + 1;
 constexpr int kBrickGrpPerWave = 8;                                // uint16 per wave and stage: one 16-byte LDS read
 constexpr int kBrickTf1Batch = 16;                                 // TF1 rows of the first batch (the registers the quads held)
 constexpr int kBrickTf1Next = 8;                                   // ... of the following ones
+constexpr int kBrickEllSlack = 16;                                 // an event's lane reads up to 16 slots from its first one
 static_assert(M3_STAGE_CAP % kBrickThreads == 0, "a stage is a whole number of responses per lane");
 static_assert(kBrickHdrWords <= kBrickThreads, "the stage headers are fetched by one load per lane");
-static_assert(M3_STAGE_MAX_RUNS <= kBrickThreads && M3_STAGE_CAP / 64 <= kBrickThreads, "run entries and group entries: one per lane");
-static_assert(M3_GROUP == kBrickThreads, "lane = event");
+static_assert(M3_STAGE_MAX_RUNS <= kBrickThreads && M3_STAGE_PAIR_WORDS <= kBrickThreads, "run entries and pair words: one per lane");
+static_assert(M3_GROUP == kBrickThreads, "lane = event of a slab");
 static_assert(kBrickRPL <= kBrickGrpPerWave, "group entries of a wave");
+static_assert(16 * M3_BRICK_MAX_GROUPS <= M3_STAGE_PAIR_WORDS, "a wave-block's first slot travels in the high half of a pair word");
+static_assert(4 * (M3_STAGE_CAP + kBrickEllSlack) <= 0x8000, "bits 2..14 of a response word are a byte offset into the scatter array");
 // Idle lanes do not branch around their loads (see the note in the kernel): they read a few KB past the list they index.
 // m3hip_api.hip allocates every chunk's stores with this much room behind them.
 static_assert(M3_STORE_SLACK_BYTES >= 2 * M3_STAGE_CAP + 8 * kBrickThreads, "room behind the stores for idle lanes' reads");
@@ -598,21 +588,42 @@ struct RRun {      // per-step resolved run: quad address = base + r, dx of the 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// Written for instruction count (44 M -> 30 M vector instructions per launch on a 2e6-event config-3 shard took the
-// kernel from 188 to 155 us): a response word is already the byte offset of its slot in the scatter array; unused slots
-// of that array hold 1.0f, so an event's column is multiplied without counts or predicates; idle lanes load from a
-// clamped index instead of branching around the load.  With that the vector pipes are about a third busy (SQ_INSTS_VALU)
-// and the waves spend 40-48 % of their cycles in s_waitcnt (SQ_WAIT_ANY / SQ_WAIT_INST_ANY) -- waiting for a memory
-// system that delivers 6.3 TB/s of lines, 92 % of what a pure stream of the same access shape reaches.
+// k_reweight_brick: one 1024-lane workgroup per brick (<= G x 1024 events with ragged parameter lists); lane l owns the
+// events l + 1024 h of the brick's slabs h = 0 .. G-1.
+//
+// TSpline3 responses, stage by stage (<= M3_STAGE_CAP responses): phase A evaluates the stage's responses
+// lane-per-response in PARAMETER-major order -- a run's active segment plane is contiguous, so the float4 loads
+// coalesce -- and scatters each weight to its slot of a compact LDS array (one float per response; the slot is the
+// response's metadata word); phase B lets every event multiply its own responses, ascending parameter = the
+// reference's order: an event's slots lie next to each other, its first one at the wave-block's first slot + the
+// exclusive prefix sum of the events' 4-bit counts over the wave's lanes (a DPP scan), so a row costs one LDS read with
+// an immediate offset, one select and one multiply.
+// TF1 responses are read lane-per-event from the wave-block's jagged rows straight into the register product (no
+// segment to select, so no regrouping and no LDS), slab after slab, each followed by its events' CalcWeightTotal + fill.
+// HBM bytes per TSpline3 response: 16 (quad) + 2 (word) (+ the padding of the run's plane to a 128-B line);
+// per TF1 response: 8 + 1; per run: 8; per event and stage: 1/2; per event: 1 + the sample side.
+//
+// Latency structure.  The coefficient loads of stage s+1 are issued BEFORE phase B of stage s (right after the barrier
+// that publishes the stage's resolved run table), so a workgroup has quads in flight through its barriers and LDS
+// phases; everything those loads need -- response words, run entries -- is requested one stage earlier still, and the
+// parameters' {segment, dx} sit in LDS, so no dependent round trip lies between two stages' coefficient loads.
+// What a workgroup pays once -- the first round trips, filling and draining that pipeline, the parameter table, the
+// bin vector's flush, its own dispatch -- is spread over G x 1024 events; the LDS it needs does not grow with G.
+//
+// Written for instruction count: a response word is already the byte offset of its slot; idle lanes load from a clamped
+// index instead of branching around the load.
 //
 // BIGP: more spline parameters than the LDS tables hold (kBrickLdsParams): {segment, dx} and the TF1 parameter values are
 // then read from global memory where they are needed -- a dependent round trip per stage and per TF1 response; a
 // separate instantiation, because a run-time branch around those loads would cost the common case its counted waits
-template <int MODE, bool NT, bool DYN = false, bool BIGP = false>
+// PACK: the event's bin, oscillation index and norm indices come as one 8-byte word (ReweightArgs::evw) instead of from three
+// arrays; a template parameter, because both forms in one kernel cost the slabs' tails more registers than there are
+template <int MODE, bool NT, bool DYN = false, bool BIGP = false, int G = 1, bool PACK = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
-  __shared__ float ell[M3_ELL_ROWS * M3_GROUP];   // scatter array [rank][event]; 1.0f wherever no response sits
+  __shared__ float ell[M3_STAGE_CAP + kBrickEllSlack];  // compact scatter array: one slot per response of the stage
   __shared__ RRun lds_runs[2 * kBrickRunSlots];   // resolved run tables of two stages
   __shared__ __attribute__((aligned(16))) uint16_t lds_grp[2 * 16 * kBrickGrpPerWave];  // [stage & 1][wave][u]: run of the group's first response
+  __shared__ uint16_t lds_woff[2 * 16 * G];       // [stage & 1][slab][wave]: first slot of the wave-block's rows
   __shared__ __attribute__((aligned(16))) uint32_t lds_hdr[kBrickHdrWords];
   __shared__ PTab lds_ptab[kBrickLdsParams];
   __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
@@ -624,6 +635,15 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   const M3_GLOBAL char* __restrict__ wbytes = (const M3_GLOBAL char*)words;
   const M3_GLOBAL PTab* __restrict__ ptab = as_global(a.ptab);
   const uint32_t n_stages = bd.n_stages;
+  // The kernel's arguments, re-read from the kernarg segment where they are used.  hipcc loads every argument at the kernel's
+  // top and keeps it in SGPRs to its last use -- for the sample side's two dozen pointers that is the end of the last slab,
+  // and the scalar registers they would occupy through the stage loop spill into vector registers the loop does not have.
+  // Behind the empty asm the loads (scalar, served by the constant cache) cannot be hoisted.
+  auto late_args = [&]() -> const ReweightArgs& {
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const ReweightArgs*)p;
+  };
   constexpr bool tab_in_lds = !BIGP;
   constexpr int kWordRegs = (kBrickRPL + 1) / 2;
 
@@ -634,10 +654,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // do not exist have an all-zero header and read the brick's first words), and nothing is ever done with the value.
   struct Meta {
     uint32_t w[kWordRegs];  // response words, two per register
-    uint32_t grp;           // lanes < M3_STAGE_CAP / 64: run of the group's first response
+    uint32_t pair;          // lanes < M3_STAGE_PAIR_WORDS: run of the group's first response | first slot of wave-block `lane` << 16
     u32x2_t run;            // lanes < n_runs: the raw entry of run `lane`
   };
-  struct StageHdr { uint32_t h0, off_runs, off_grp, off_resp; };  // wave-uniform (SGPRs): bases of SGPR + lane-offset loads
+  struct StageHdr { uint32_t h0, off_runs, off_pairs, off_resp; };  // wave-uniform (SGPRs): bases of SGPR + lane-offset loads
   auto fetch_meta = [&](const StageHdr& hd, Meta& m) {
     // lanes past the end of a list re-read its last element (one line): an unclamped read would drag 10+ KB of foreign
     // lines per stage through the memory system
@@ -651,8 +671,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       m.w[k] = *(const M3_GLOBAL uint32_t*)(resp + 4u * kBrickThreads * (n_resp > 2u * k * kBrickThreads ? k : 0u) + 4u * l);
     }
     {
-      const uint32_t l = lane < (uint32_t)(M3_STAGE_CAP / 64 - 1) ? lane : (uint32_t)(M3_STAGE_CAP / 64 - 1);
-      m.grp = *(const M3_GLOBAL uint16_t*)(uniform_base(wbytes + 4u * hd.off_grp) + 2u * l);
+      const uint32_t l = lane < (uint32_t)(M3_STAGE_PAIR_WORDS - 1) ? lane : (uint32_t)(M3_STAGE_PAIR_WORDS - 1);
+      m.pair = *(const M3_GLOBAL uint32_t*)(uniform_base(wbytes + 4u * hd.off_pairs) + 4u * l);
     }
     {
       const uint32_t last = n_runs ? n_runs - 1u : 0u, l = lane < last ? lane : last;
@@ -660,6 +680,22 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     }
   };
   auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
+  // the responses this lane's G events hold in a stage, a nibble each.  Requested at the top of the stage itself: older than
+  // the next stage's quads, so the wait in front of the events' products leaves those in flight
+  auto fetch_counts = [&](const StageHdr& hd) -> uint32_t {
+    const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (hd.off_pairs + (uint32_t)M3_STAGE_PAIR_WORDS));
+    if (G == 1) return *(const M3_GLOBAL uint8_t*)(cb + (lane & 511u));
+    if (G == 2) return *(const M3_GLOBAL uint8_t*)(cb + lane);
+    return *(const M3_GLOBAL uint16_t*)(cb + 2u * lane);
+  };
+  auto count_of = [&](uint32_t packed, int h) -> uint32_t {
+    if (G != 1) return (packed >> (4 * h)) & 15u;
+    // G = 1: two events share a byte.  The lane's shift is recomputed where it is used: hoisted out of the stage loop it would
+    // cost a register the loop does not have (a spill there means a scratch reload = a wait for every quad in flight)
+    uint32_t l = lane;
+    asm volatile("" : "+v"(l));
+    return (packed >> ((l >> 7) & 4u)) & 15u;
+  };
 
   M3_STAMP(0);
   M3_STAMP_HWID();
@@ -675,9 +711,19 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // stage's tables need has to be older than the quads that are in flight while the tables are built
   fetch_meta(StageHdr{bd.st1[0], bd.st1[1], bd.st1[2], bd.st1[3]}, m_nxt);
   const M3_GLOBAL uint32_t* __restrict__ tf1h = words + bd.off_tf1;
-  const uint32_t tf1_cnt = (tf1h[32 + (lane >> 2)] >> (8 * (lane & 3))) & 0xFFu;  // codes of this lane's event
-  uint32_t tf1_cbase = __builtin_amdgcn_readfirstlane(tf1h[wave]);                // this wave's first slot / code dword
-  uint32_t tf1_dbase = __builtin_amdgcn_readfirstlane(tf1h[16 + wave]);
+  // TF1 bookkeeping of a slab: the code count of the lane's event (a byte) and the wave-block's first slot / first code dword.
+  // Slab 0's is requested here, slab h + 1's when slab h begins.
+  struct Tf1Book { uint32_t cnt, cbase, dbase; };
+  auto tf1_book = [&](uint32_t h) -> Tf1Book {
+    Tf1Book b;
+    uint32_t le = lane;
+    asm volatile("" : "+v"(le));  // as in tail_issue_idx: no hoisting of G slabs' addresses
+    b.cnt = *(const M3_GLOBAL uint8_t*)(uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G)) + (1024u * h + le));  // SGPR base + 32-bit offset
+    b.cbase = __builtin_amdgcn_readfirstlane(tf1h[16u * h + wave]);
+    b.dbase = __builtin_amdgcn_readfirstlane(tf1h[16u * G + 16u * h + wave]);
+    return b;
+  };
+  Tf1Book book_nxt = tf1_book(0);
   const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
@@ -689,16 +735,17 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     t_own.dx = ptab[lane].dx;
     t_own.seg = ptab[lane].seg;
   }
-#pragma unroll
-  for (int j = 0; j < M3_ELL_ROWS; ++j) ell[j * M3_GROUP + lane] = 1.0f;
   if ((MODE & kModeFill) && a.hist_lds) {
     const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
     for (int b = lane; b < nb; b += kBrickThreads) lds_hist[b] = 0.0;
   }
-  // stage s's run table and group table -> LDS; the parameters' {segment, dx} from LDS (FROM_LDS) or from global memory
+  // stage s's run table, group table and wave-block offsets -> LDS; the parameters' {segment, dx} from LDS (FROM_LDS) or
+  // from global memory
   auto publish = [&](uint32_t s, uint32_t h0, const Meta& m, auto from_lds_tag) {
     constexpr bool FROM_LDS = decltype(from_lds_tag)::value;
     const uint32_t n_runs = (h0 >> 16) & 0x3FFu;
+    uint32_t lane = threadIdx.x;
+    if (G == 4) asm volatile("" : "+v"(lane));  // G = 4 has no register to spare for LDS addresses hoisted out of the stage loop
     if (lane < n_runs + 65u) {
       const uint32_t p = m.run.y >> 16;
       PTab t;
@@ -716,7 +763,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       lds_runs[(s & 1u) * kBrickRunSlots + lane] = rr;
     }
     // group g = u * 16 + wave -> [wave][u]: a wave fetches its entries of a stage with one 16-byte read
-    if (lane < (uint32_t)(M3_STAGE_CAP / 64)) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.grp;
+    if (lane < (uint32_t)M3_STAGE_PAIR_WORDS) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.pair;
+    if (lane < (uint32_t)(16 * G)) lds_woff[(s & 1u) * 16 * G + lane] = (uint16_t)(m.pair >> 16);
   };
   publish(0, bd.st0[0], m_cur, std::false_type{});
   if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
@@ -761,10 +809,12 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   };
   issue_quads(0, m_cur, [](int) {});
 
-  // ---- TF1 side (SplineMonolith.cpp:818-825: after the TSpline3s, in the event's parameter order): one batch of rows
+  // ---- TF1 side (SplineMonolith.cpp:818-825: after the TSpline3s, in the event's parameter order): one batch of rows of
+  // the CURRENT slab's wave-block
   float2 ab[kBrickTf1Batch];
   uint32_t code[kBrickTf1Batch / 4];
   bool tf1_on[kBrickTf1Batch / 4];
+  uint32_t tf1_cnt = 0, tf1_cbase = 0, tf1_dbase = 0;
   const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
   auto tf1_issue = [&](uint32_t j0, auto nrows_tag) {  // loads of rows j0 .. j0 + N - 1 (nothing here waits)
     constexpr int N = decltype(nrows_tag)::value;
@@ -786,16 +836,29 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       tf1_cbase += (uint32_t)__popcll(act);
     }
   };
-  // ---- sample side of the event (CalcWeightTotal's inputs), requested while the TF1 rows stream: first the event's
+  // ---- sample side of the slab's event (CalcWeightTotal's inputs), requested while the TF1 rows stream: first the event's
   // indices (with the first TF1 rows), then what they point at (small tables that live in L2); the tail finds both there
   constexpr int kTailNorm = 4;  // norm slots fetched ahead; further ones are read in the tail itself
-  uint32_t ev_own = 0;  // this lane's event (an engine holds fewer than 2^32)
+  uint32_t ev_own = 0;  // this lane's event of the slab (an engine holds fewer than 2^32)
+  bool ev_valid = false;
   int32_t t_bin = -1, t_osc = -1, t_ni[kTailNorm];
+  uint64_t t_pack = 0;
   float t_oscw = 1.f;
   double t_nv[kTailNorm];
-  auto tail_issue_idx = [&]() {
-    ev_own = bd.first_event + (lane < bd.n_events ? lane : 0u);  // idle lanes shadow the brick's first event
+  auto tail_issue_idx = [&](uint32_t h) {
+    const ReweightArgs& a = late_args();
+    // (the lane number passes through an empty asm: the addresses below must be formed HERE, slab by slab; hoisted to the
+    // kernel's top for all G slabs at once they cost more registers than the stage loop leaves, i.e. spills)
+    uint32_t le = lane;
+    asm volatile("" : "+v"(le));
+    le += 1024u * h;
+    ev_valid = le < bd.n_events;
+    ev_own = bd.first_event + (ev_valid ? le : 0u);  // idle lanes shadow the brick's first event
     if (a.perm) ev_own = a.perm[ev_own];  // processing order -> event; kernel-uniform branch: only grouped uploads pay this dependent load
+    if ((MODE & (kModeFill | kModeEventW)) && PACK) {  // the event's indices in one 8-byte word
+      t_pack = a.evw[ev_own];
+      return;
+    }
     if (MODE & (kModeFill | kModeEventW)) {
       t_osc = a.osc[ev_own];
 #pragma unroll
@@ -809,6 +872,17 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if ((MODE & kModeFill) && !DYN) t_bin = a.bin[ev_own];
   };
   auto tail_issue_val = [&]() {
+    const ReweightArgs& a = late_args();
+    if ((MODE & (kModeFill | kModeEventW)) && PACK) {
+      const uint32_t lo = (uint32_t)t_pack, hi = (uint32_t)(t_pack >> 32);
+      t_bin = (int32_t)(lo & 0xFFFFFu) - 1;
+      t_osc = (int32_t)(((lo >> 20) | (hi << 12)) & 0xFFFFFFu) - 1;
+#pragma unroll
+      for (int m = 0; m < kTailNorm; ++m) {
+        const uint32_t cd = m < 3 ? (hi >> (12 + 6 * m)) & 63u : 0u;
+        t_ni[m] = cd ? a.evw_norm_base + (int32_t)cd - 1 : -1;
+      }
+    }
     if (MODE & (kModeFill | kModeEventW)) {
       // a sample without oscillated events has no table, one without norm parameters no index array: absent entries
       // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
@@ -819,47 +893,90 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
     }
   };
+  auto slab_begin = [&]() {  // the slab whose bookkeeping was requested last becomes the current one
+    tf1_cnt = book_nxt.cnt;
+    tf1_cbase = book_nxt.cbase;
+    tf1_dbase = book_nxt.dbase;
+  };
   const bool any_tf1 = bd.n_dict > 0;  // kernel-uniform
 
-  float w = 1.0f;  // SplineMonolith.cpp:798
+  float w[G];  // SplineMonolith.cpp:798, one product per slab
+#pragma unroll
+  for (int h = 0; h < G; ++h) w[h] = 1.0f;
+  // inclusive prefix sum over the wave's 64 lanes (row_shr 1, 2, 4, 8 inside the rows of 16, then the rows' totals)
+  auto wave_scan = [](uint32_t x) -> uint32_t {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2 and 3
+    return x;
+  };
+  auto column = [&](const uint32_t (&block0)[G], uint32_t counts) {
+    uint32_t cnt[G], excl[G];
+#pragma unroll
+    for (int h = 0; h < G; ++h) cnt[h] = count_of(counts, h);
+#pragma unroll
+    for (int h = 0; h < G; h += 2) {  // sums stay below 64 * 15 < 2^16
+      const uint32_t packed = cnt[h] | (h + 1 < G ? cnt[(h + 1) % G] << 16 : 0u);
+      const uint32_t incl = wave_scan(packed);
+      excl[h] = (incl & 0xFFFFu) - cnt[h];
+      if (h + 1 < G) excl[(h + 1) % G] = (incl >> 16) - cnt[(h + 1) % G];
+    }
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      const float* mine = ell + (block0[h] + excl[h]);
+      float acc = w[h];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (__ballot(cnt[h] > (uint32_t)(4 * q)) == 0ull) break;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = mine[4 * q + i];  // lanes with fewer responses read a neighbour's slot (or the slack) and drop it
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc *= cnt[h] > (uint32_t)(4 * q + i) ? v[i] : 1.0f;
+      }
+      w[h] = acc;
+    }
+  };
   // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
   // scattered to its slot of the scatter array, and its register reused at once for the next stage's load (LAST: for the
-  // first TF1 rows instead); barrier; the event's column of the scatter array, ascending parameter = reference order.
+  // first TF1 rows instead); barrier; every event's responses of the stage, ascending parameter = reference order.
   auto stage = [&](uint32_t s, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const uint32_t h0 = hdr(s).h0;
-    const uint32_t n_resp = h0 & 0xFFFFu, rows = h0 >> 26;
+    const uint32_t n_resp = h0 & 0xFFFFu;
     Meta m_nn;
+    const uint32_t counts = fetch_counts(hdr(s));
     if (!LAST) {
       publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight
       fetch_meta(hdr(s + 2), m_nn);
     }
-    __syncthreads();  // stage s+1's tables visible; every wave is through its column of stage s-1: the scatter array is free
+    __syncthreads();  // stage s+1's tables visible; every wave is through its events' products of stage s-1: the scatter array is free
+    // first slots of this wave's blocks in stage s.  Read HERE: the buffer they sit in is overwritten by the publish of stage
+    // s+2, which a fast wave reaches right after the next barrier -- possibly while a slow one is still multiplying
+    uint32_t block0[G];
+#pragma unroll
+    for (int h = 0; h < G; ++h) block0[h] = __builtin_amdgcn_readfirstlane((uint32_t)lds_woff[(s & 1u) * 16 * G + 16 * h + wave]);
     auto scatter = [&](int u) {
-      // bits 2..15 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
+      // bits 2..14 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
       if (lane + u * kBrickThreads < n_resp)
-        *(float*)((char*)ell + (word(m_cur, u) & 0xFFFCu)) = spline_poly(dx[u], c[u]);
+        *(float*)((char*)ell + (word(m_cur, u) & 0x7FFCu)) = spline_poly(dx[u], c[u]);
     };
     if (!LAST) {
       issue_quads(s + 1, m_nxt, scatter);
     } else {
 #pragma unroll
       for (int u = 0; u < kBrickRPL; ++u) scatter(u);
+      slab_begin();
       if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
-      tail_issue_idx();
+      tail_issue_idx(0);
     }
     __syncthreads();  // the stage's scatter is complete
-    // the event's column: slots without a response hold 1.0f (exact), and every slot is left at 1.0f for the next stage
-    for (uint32_t j0 = 0; j0 < rows; j0 += 4) {
-      float v[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = ell[(j0 + i) * M3_GROUP + lane];
-        ell[(j0 + i) * M3_GROUP + lane] = 1.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w *= v[i];
-    }
+    // every event's responses: they lie next to each other in the scatter array, from the wave-block's first slot + the
+    // exclusive prefix sum of the counts over the wave's lanes on (a DPP scan; two slabs' counts share a register)
+    column(block0, counts);
     if (!LAST) {
       m_cur = m_nxt;
       m_nxt = m_nn;
@@ -873,116 +990,155 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     stage(n_stages - 1, std::true_type{});
     M3_STAMP(8);
   } else {
+    slab_begin();
     if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
-    tail_issue_idx();
+    tail_issue_idx(0);
   }
-  tail_issue_val();  // waits for the indices (and with them the first TF1 rows, consumed next anyway)
 
-  if (any_tf1) {
-    uint32_t kd4 = 0;  // 4 * (1 + position in the dictionary)
-    auto tf1_rows = [&](uint32_t j0, auto nrows_tag) {
-      constexpr int N = decltype(nrows_tag)::value;
+  // ---- slab after slab: the events' TF1 rows, then CalcWeightTotal and the fill.  The next slab's first rows and indices
+  // are requested once this slab's tail is through (holding 16 rows in flight across the tail costs it its registers).
 #pragma unroll
-      for (int q = 0; q < N / 4; ++q) code[q] = tf1_on[q] ? code[q] : 0u;  // ... dropped here
+  for (uint32_t h = 0; h < (uint32_t)G; ++h) {
+    if (h + 1 < (uint32_t)G) book_nxt = tf1_book(h + 1);
+    tail_issue_val();  // waits for the indices (and with them the first TF1 rows, consumed next anyway)
+    float wh = w[0];
+    if (G > 1 && h == 1) wh = w[1 % G];
+    if (G > 2 && h == 2) wh = w[2 % G];
+    if (G > 2 && h == 3) wh = w[3 % G];
+    if (any_tf1) {
+      uint32_t kd4 = 0;  // 4 * (1 + position in the dictionary)
+      auto tf1_rows = [&](auto nrows_tag) {
+        constexpr int N = decltype(nrows_tag)::value;
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        // code 0: no response in this row (the event's list has ended: the planner zero-fills); M3_TF1_SKIP: a step of 254
-        // without a response
-        const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
-        kd4 += (cd < 254u ? cd : 254u) << 2;
-        const float x = x_in_lds ? *(const float*)((const char*)lds_tf1x + kd4) : tf1x[kd4 ? (kd4 >> 2) - 1u : 0u].f;
-        const float t = fmaf(ab[i].x, x, ab[i].y);  // SplineMonolith.cpp:779
-        w *= (cd - 1u < (uint32_t)(M3_TF1_SKIP - 1)) ? t : 1.0f;
+        for (int q = 0; q < N / 4; ++q) code[q] = tf1_on[q] ? code[q] : 0u;  // ... dropped here
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          // code 0: no response in this row (the event's list has ended: the planner zero-fills); M3_TF1_SKIP: a step of 254
+          // without a response
+          const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
+          kd4 += (cd < 254u ? cd : 254u) << 2;
+          const float x = x_in_lds ? *(const float*)((const char*)lds_tf1x + kd4) : tf1x[kd4 ? (kd4 >> 2) - 1u : 0u].f;
+          const float t = fmaf(ab[i].x, x, ab[i].y);  // SplineMonolith.cpp:779
+          wh *= (cd - 1u < (uint32_t)(M3_TF1_SKIP - 1)) ? t : 1.0f;
+        }
+      };
+      tf1_rows(std::integral_constant<int, kBrickTf1Batch>{});
+      for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Next) {
+        tf1_issue(j0, std::integral_constant<int, kBrickTf1Next>{});
+        tf1_rows(std::integral_constant<int, kBrickTf1Next>{});
       }
-    };
-    tf1_rows(0, std::integral_constant<int, kBrickTf1Batch>{});
-    for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Next) {
-      tf1_issue(j0, std::integral_constant<int, kBrickTf1Next>{});
-      tf1_rows(j0, std::integral_constant<int, kBrickTf1Next>{});
     }
-  }
-
-  M3_STAMP(9);
-  bool det_fill = false;
-  int det_b = -1;
-  float det_w = 0.f;
-  // a brick may hold fewer than M3_GROUP events and start on any tile boundary: lanes past its last event
-  // belong to somebody else's events and must touch nothing
-  if (lane < bd.n_events) {
+    if (h == (uint32_t)(G - 1)) M3_STAMP(9);
+    // what the requested values give: the norm and oscillation part of CalcWeightTotal (SampleHandlerFD.cpp:568-594: norm
+    // pointers first, double -> float cast each, then total_weight_pointers = {osc, bin-spline weights, spline total weight})
     const uint64_t ev = ev_own;
-    if (MODE & kModeEval) a.spline_w[ev] = w;
+    const bool valid = ev_valid;
+    const int32_t bin_h = t_bin;
+    float tw = 1.0f;
     if (MODE & (kModeFill | kModeEventW)) {
-      // CalcWeightTotal (SampleHandlerFD.cpp:568-594), as in k_reweight_uniform: norm pointers first (double -> float
-      // cast each), then total_weight_pointers = {osc, bin-spline weights, spline total weight}
-      float tw = 1.0f;
 #pragma unroll
       for (int m = 0; m < kTailNorm; ++m)
         if (t_ni[m] >= 0) tw *= static_cast<float>(t_nv[m]);
-      if (a.n_norm_slots > (uint32_t)kTailNorm) tw = mul_norm_weights(tw, a, ev, (uint32_t)kTailNorm);
-      if (t_osc >= 0) tw *= t_oscw;
-      tw = mul_binned_weights(tw, a, ev);
-      tw *= w;
-      if (a.n_extra) tw = mul_extra_weights(tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
-      if (MODE & kModeEventW) a.event_w[ev] = tw;
-      if (MODE & kModeFill) {
-        int b;
-        if (DYN) {
-          b = d_event_bin(a.dyn, ev);
-          a.dyn.bin[ev] = b;
-        } else {
-          b = t_bin;
-        }
-        if (a.partial) {  // deterministic mode: filled below, wave after wave
-          det_fill = !(tw <= 0.f) && b >= 0;
-          det_b = b;
-          det_w = tw;
-        } else if (!(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
-          if (a.hist_lds) {
-            atomicAdd(&lds_hist[b], (double)tw);
-            if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
-          } else {  // many bins: straight into this workgroup's replica
-            const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
-            atomicAdd(&a.hist[(size_t)rep * a.n_bins + b], (double)tw);
-            if (a.fill_w2) atomicAdd(&a.hist[(size_t)(a.hist_rep + rep) * a.n_bins + b], (double)(tw * tw));
+    }
+    const float oscw = t_oscw;
+    const bool has_osc = t_osc >= 0;
+    const ReweightArgs& a = late_args();
+    // a brick may hold fewer than G x 1024 events and start on any tile boundary: lanes past its last event
+    // belong to somebody else's events and must touch nothing
+    bool det_fill = false;
+    int det_b = -1;
+    float det_w = 0.f;
+    if (valid) {
+      if (MODE & kModeEval) a.spline_w[ev] = wh;
+      if (MODE & (kModeFill | kModeEventW)) {
+        if (a.n_norm_slots > (uint32_t)kTailNorm) tw = mul_norm_weights(tw, a, ev, (uint32_t)kTailNorm);
+        if (has_osc) tw *= oscw;
+        tw = mul_binned_weights(tw, a, ev);
+        tw *= wh;
+        if (a.n_extra) tw = mul_extra_weights(tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
+        if (MODE & kModeEventW) a.event_w[ev] = tw;
+        if (MODE & kModeFill) {
+          int b;
+          if (DYN) {
+            b = d_event_bin(a.dyn, ev);
+            a.dyn.bin[ev] = b;
+          } else {
+            b = bin_h;
+          }
+          if (a.partial) {  // deterministic mode: filled below, wave after wave
+            det_fill = !(tw <= 0.f) && b >= 0;
+            det_b = b;
+            det_w = tw;
+          } else if (!(tw <= 0.f) && b >= 0) {  // a NaN weight fills, as in the reference
+            if (a.hist_lds) {
+              atomicAdd(&lds_hist[b], (double)tw);
+              if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));
+            } else {  // many bins: straight into this workgroup's replica
+              const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+              atomicAdd(&a.hist[(size_t)rep * a.n_bins + b], (double)tw);
+              if (a.fill_w2) atomicAdd(&a.hist[(size_t)(a.hist_rep + rep) * a.n_bins + b], (double)(tw * tw));
+            }
           }
         }
       }
     }
-  }
-  if ((MODE & kModeFill) && a.hist_lds && a.partial) {
-    // deterministic mode, as in k_reweight_uniform: the waves add in turn, the bin vector goes to the brick's row of `partial`
-    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
-    for (uint32_t wv = 0; wv < kBrickThreads / 64; ++wv) {
-      if (wave == wv && det_fill) {
-        atomicAdd(&lds_hist[det_b], (double)det_w);
-        if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + det_b], (double)(det_w * det_w));
+    if ((MODE & kModeFill) && a.hist_lds && a.partial) {
+      // deterministic mode, as in k_reweight_uniform: the waves add in turn, slab after slab (kernel-uniform branch)
+      for (uint32_t wv = 0; wv < kBrickThreads / 64; ++wv) {
+        if (wave == wv && det_fill) {
+          atomicAdd(&lds_hist[det_b], (double)det_w);
+          if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + det_b], (double)(det_w * det_w));
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-    double* row = a.partial + ((size_t)a.partial_row0 + blockIdx.x) * (size_t)(2 * a.n_bins);
+    if (h + 1 < (uint32_t)G) {
+      if (h == 0) M3_STAMP(13);  // diagnostics: slab 0 is through
+      slab_begin();
+      if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
+      tail_issue_idx(h + 1);
+    }
+  }
+  const ReweightArgs& af = late_args();
+  if ((MODE & kModeFill) && af.hist_lds && af.partial) {  // deterministic mode: the bin vector goes to the brick's row of `partial`
+    const int nb = af.fill_w2 ? 2 * af.n_bins : af.n_bins;
+    double* row = af.partial + ((size_t)af.partial_row0 + blockIdx.x) * (size_t)(2 * af.n_bins);
     for (int i = lane; i < nb; i += kBrickThreads) row[i] = lds_hist[i];
     return;
   }
-  if ((MODE & kModeFill) && a.hist_lds) {
+  if ((MODE & kModeFill) && af.hist_lds) {
     __syncthreads();
     M3_STAMP(10);
-    const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
-    const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+    const int nb = af.fill_w2 ? 2 * af.n_bins : af.n_bins;
+    const int rep = (int)(blockIdx.x % (uint32_t)af.hist_rep);
     for (int i = lane; i < nb; i += kBrickThreads) {
       const double v = lds_hist[i];
-      const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
-      if (v != 0.0) atomicAdd(&a.hist[slot], v);
+      const int slot = i < af.n_bins ? rep * af.n_bins + i : (af.hist_rep + rep) * af.n_bins + (i - af.n_bins);
+      if (v != 0.0) atomicAdd(&af.hist[slot], v);
     }
   }
   M3_STAMP(11);
 }
 
+template <int MODE, bool DYN, int G>
+static void launch_brick_g(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
+  const dim3 b(kBrickThreads);
+  constexpr bool kSampleSide = (MODE & (kModeFill | kModeEventW)) != 0 && !DYN;  // only these read the packed word
+  if (kSampleSide && a.evw) {
+    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true, G, kSampleSide>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false, G, kSampleSide>), g, b, lds, s, k, a);
+    return;
+  }
+  if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true, G>), g, b, lds, s, k, a);
+  else if (k.nt || DYN || G != 1) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false, G>), g, b, lds, s, k, a);
+  else M3_LAUNCH((k_reweight_brick<MODE, false, false, false, 1>), g, b, lds, s, k, a);
+}
+
 template <int MODE, bool DYN>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  const dim3 b(kBrickThreads);
-  if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true>), g, b, lds, s, k, a);
-  else if (k.nt || DYN) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false>), g, b, lds, s, k, a);
-  else M3_LAUNCH((k_reweight_brick<MODE, false, false, false>), g, b, lds, s, k, a);
+  if (a.brick_groups == 4) launch_brick_g<MODE, DYN, 4>(a, g, lds, k, s);
+  else if (a.brick_groups == 2) launch_brick_g<MODE, DYN, 2>(a, g, lds, k, s);
+  else launch_brick_g<MODE, DYN, 1>(a, g, lds, k, s);
 }
 
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
@@ -998,6 +1154,27 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   if (mode == kModeEval) launch_brick_mode<kModeEval, false>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill, false>(a, g, lds, k, s);
   else launch_brick_mode<kModeFill | kModeEval | kModeEventW, false>(a, g, lds, k, s);
+}
+
+// ------------------------------------------------------------------------------------
+// k_pack_events: an event's bin, oscillation index and up to three norm-parameter indices as one 8-byte word
+// (ReweightArgs::evw).  Set-up time: runs when one of the three arrays has changed.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots,
+                                                     uint64_t e_pad, int32_t norm_base, uint64_t* out) {
+  const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ev >= e_pad) return;
+  uint64_t w = (uint64_t)(uint32_t)(bin[ev] + 1) | ((uint64_t)(uint32_t)(osc[ev] + 1) << 20);
+  for (uint32_t m = 0; m < n_norm_slots; ++m) {
+    const int32_t i = nidx[(uint64_t)m * e_pad + ev];
+    w |= (uint64_t)(i >= 0 ? (uint32_t)(i - norm_base + 1) : 0u) << (44 + 6 * m);
+  }
+  out[ev] = w;
+}
+void launch_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots, uint64_t e_pad, int32_t norm_base,
+                        uint64_t* out, hipStream_t s) {
+  if (e_pad == 0) return;
+  hipLaunchKernelGGL(k_pack_events, dim3((unsigned)((e_pad + 255) / 256)), dim3(256), 0, s, bin, osc, nidx, n_norm_slots, e_pad, norm_base, out);
 }
 
 // ------------------------------------------------------------------------------------

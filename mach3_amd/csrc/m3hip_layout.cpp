@@ -84,30 +84,37 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 
 
 // ------------------------------------------------------------------------------------
-// Brick metadata stream (uint32 words, offsets relative to the brick's first word):
-//   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3..7] 0
-//   [8 + 4 s ..]  stage header: n_resp | n_runs << 16 | rows << 26, off_runs, off_grp, off_resp   (rows = the most
-//             responses one event holds in the stage = the rows of the scatter array the stage uses)
+// Brick metadata stream (uint32 words, offsets relative to the brick's first word).  G = the engine's brick_groups: a brick
+// holds up to G x 1024 events, local event le = 1024 h + lane (slab h, lane of the workgroup); wave-block b = 16 h + w.
+//   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3] G   [4..7] 0
+//   [8 + 4 s ..]  stage header: n_resp | n_runs << 16 | rows << 26, off_runs, off_pairs, off_resp   (rows = the most
+//             responses one event holds in the stage, <= M3_STAGE_EVENT_MAX)
 //   off_runs  n_runs x {int32 coef_off - start_r, stride | param << 16}.  coef_off: float4 index of the run's first plane
 //             in the brick's spline store; start_r: first response of the run in the stage; so the quad of segment k of
 //             response r sits at entry[0] + k * stride + r.  stride = n_run rounded up to M3_PLANE_ALIGN.
-//   off_grp   M3_STAGE_CAP / 64 uint16 (n_runs past the stage's last group), two per word: the run of the group's first response
-//   off_resp  one uint16 per response: (rank << 10 | event) << 2 | last response of its run (bits 2..15 are the byte offset
-//             of the response's slot in the scatter array), stored two per dword the way a lane fetches them:
-//             dword [k][l] = word of response l + 2k * 1024 | word of response l + (2k + 1) * 1024 << 16; block k has
-//             one dword for every response of batch 2k (1024, fewer in the last block)
-//   off_tf1   [0..15]   float2 index (from the brick's TF1 store) of the first slot of wave w (events 64 w .. 64 w + 63)
-//             [16..31]  word offset (from the brick's first word) of wave w's first code dword
-//             [32..32 + M3_GROUP / 4)  codes per event, uint8, four per word
-//             then the code dwords: per wave, per four rows 4 q .. 4 q + 3, one dword for every lane with more than 4 q
+//   off_pairs M3_STAGE_PAIR_WORDS words: low half of word g = the run of response group g's first response (n_runs past
+//             the stage's last group); high half of word b (b < 16 G) = slot of wave-block b's first row in the stage's
+//             compact scatter array.  Then the events' response counts of the stage, a nibble each, stored the way a lane
+//             fetches them: G = 1: byte i = count of event i | count of event i + 512 << 4 (512 bytes); G = 2: byte l =
+//             event l | event l + 1024 << 4; G = 4: uint16 l = events l, l + 1024, l + 2048, l + 3072, a nibble each.
+//   off_resp  one uint16 per response: slot << 2 | last response of its run (bits 2..14 are the byte offset of the
+//             response's slot in the scatter array).  Slots: wave-block after wave-block, inside a block event after event
+//             (lane order), an event's responses in ascending parameter order.  Stored two per
+//             dword the way a lane fetches them: dword [k][l] = word of response l + 2k * 1024 | word of response
+//             l + (2k + 1) * 1024 << 16; block k has one dword for every response of batch 2k (1024, fewer in the last)
+//   off_tf1   [0 .. 16 G)       float2 index (from the brick's TF1 store) of the first slot of wave-block b
+//             [16 G .. 32 G)    word offset (from the brick's first word) of wave-block b's first code dword
+//             [32 G .. 32 G + 256 G)  codes per event, uint8, four per word (local event order)
+//             then the code dwords: per wave-block, per four rows 4 q .. 4 q + 3, one dword for every lane with more than 4 q
 //             codes (lanes packed, ascending), byte i = code of row 4 q + i.  A code is the step from the event's previous
 //             TF1 parameter to this one in the chunk's TF1 dictionary (first: from -1); M3_TF1_SKIP steps 254 without a response.
-//   TF1 store: per wave, per row j, one float2 {a,b} for every lane with more than j codes (lanes packed, ascending)
+//   TF1 store: per wave-block, per row j, one float2 {a,b} for every lane with more than j codes (lanes packed, ascending)
 // ------------------------------------------------------------------------------------
 bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const std::vector<int32_t>& dict_index, uint64_t e0,
-                uint64_t e1, BrickHost* bh, std::vector<uint32_t>* words_all, std::string* err) {
+                uint64_t e1, uint32_t G, BrickHost* bh, std::vector<uint32_t>* words_all, std::string* err) {
   const uint32_t ne = uint32_t(e1 - e0);
   bh->n_events = ne;
+  bh->groups = G;
   bh->first_event = e0;
   bh->words_off = words_all->size();
   std::vector<uint32_t> w;  // this brick's stream
@@ -151,7 +158,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   }
 
   // ---- stages: ascending parameter ranges; <= M3_STAGE_CAP responses, <= M3_STAGE_MAX_RUNS runs, no event more than
-  // M3_ELL_ROWS times.  Stages of about equal size (a brick whose responses just exceed a multiple of the cap would
+  // M3_STAGE_EVENT_MAX times.  Stages of about equal size (a brick whose responses just exceed a multiple of the cap would
   // otherwise end in a stage of a few responses that costs the same barriers as a full one).
   struct Range { int p0, p1; };
   // `n_aim` = 0: every stage as long as the limits allow (the fewest stages there can be).  Otherwise: aim at `n_aim` stages
@@ -176,7 +183,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         if (n_run == 0) { ++p1; continue; }
         if (tot > 0) {
           bool fits = tot + n_run <= uint32_t(M3_STAGE_CAP) && runs < uint32_t(M3_STAGE_MAX_RUNS);
-          for (uint32_t r = a; fits && r < b; ++r) fits = mult[inv_ev[r]] < uint8_t(M3_ELL_ROWS);
+          for (uint32_t r = a; fits && r < b; ++r) fits = mult[inv_ev[r]] < uint8_t(M3_STAGE_EVENT_MAX);
           if (!fits) break;
         }
         for (uint32_t r = a; r < b; ++r) mult[inv_ev[r]]++;
@@ -199,27 +206,40 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   const uint32_t n_stages = uint32_t(st_s.size());
   if (n_stages > uint32_t(M3_BRICK_MAX_STAGES)) {
     *err = "brick: " + std::to_string(n_stages) + " stages exceed the supported " + std::to_string(M3_BRICK_MAX_STAGES) +
-           " (more than ~250k TSpline3 responses in 1024 events)";
+           " (more than ~1.2M TSpline3 responses in one brick)";
     return false;
   }
   bh->n_stages = n_stages;
   w.assign(size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * n_stages, 0u);
   w[0] = n_stages;
+  w[3] = G;
 
-  auto push_u16 = [&](const std::vector<uint16_t>& v) {  // two per word, low half first
-    for (size_t i = 0; i < v.size(); i += 2) w.push_back(uint32_t(v[i]) | (uint32_t(i + 1 < v.size() ? v[i + 1] : 0) << 16));
-  };
   uint64_t spl_f4 = 0;
   bh->spl_src.clear();
   bh->spl_src.reserve(S);
-  std::vector<uint8_t> rank_of(ne);
+  const uint32_t n_blocks = 16u * G;  // wave-blocks of the brick
+  std::vector<uint8_t> cnt(size_t(G) * M3_GROUP), rank_of(size_t(G) * M3_GROUP);
+  std::vector<uint16_t> slot(size_t(G) * M3_GROUP * 16);  // slot of the j-th response of local event le: [le * 16 + j]
   for (uint32_t stage = 0; stage < n_stages; ++stage) {
     const Range& rg = st_s[stage];
     const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
+    // the events' counts in the stage, then the slots: wave-block after wave-block, event after event inside a block
+    std::fill(cnt.begin(), cnt.end(), uint8_t(0));
+    for (uint32_t r = r0; r < r1; ++r) cnt[inv_ev[r]]++;
+    std::vector<uint16_t> woff(n_blocks, uint16_t(0));
+    uint32_t next_slot = 0, rows = 0;
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+      woff[blk] = uint16_t(next_slot);
+      const uint32_t l0 = blk * uint32_t(M3_WAVE);
+      for (uint32_t i = 0; i < uint32_t(M3_WAVE); ++i) {
+        rows = std::max<uint32_t>(rows, cnt[l0 + i]);
+        for (uint32_t j = 0; j < cnt[l0 + i]; ++j) slot[size_t(l0 + i) * 16 + j] = uint16_t(next_slot++);
+      }
+    }
     std::fill(rank_of.begin(), rank_of.end(), uint8_t(0));
     std::vector<uint32_t> runs;
-    std::vector<uint16_t> resp(n_resp), grp(size_t(M3_STAGE_CAP) / 64, uint16_t(0));  // groups past the end: filled below
-    uint32_t n_runs = 0, rows = 0;
+    std::vector<uint16_t> resp(n_resp), grp(size_t(M3_STAGE_PAIR_WORDS), uint16_t(0));  // groups past the end: filled below
+    uint32_t n_runs = 0;
     for (int p = rg.p0; p < rg.p1; ++p) {
       const uint32_t a = cnt_s[p], b = cnt_s[p + 1];
       if (a == b) continue;
@@ -234,8 +254,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         const uint32_t ev = inv_ev[r], i = r - r0;
         if (i % 64 == 0) grp[i / 64] = uint16_t(n_runs);
         const uint32_t rk = rank_of[ev]++;
-        rows = std::max(rows, rk + 1);
-        resp[i] = uint16_t((ev | (rk << 10)) << 2);
+        resp[i] = uint16_t(uint32_t(slot[size_t(ev) * 16 + rk]) << 2);
         bh->spl_src.push_back(inv_s[r]);
       }
       resp[b - 1 - r0] |= uint16_t(1u);  // last response of its run
@@ -247,8 +266,28 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     if (w.size() & 1) w.push_back(0u);  // run entries are read as 8-byte pairs
     const uint32_t off_runs = uint32_t(w.size());
     w.insert(w.end(), runs.begin(), runs.end());
-    const uint32_t off_grp = uint32_t(w.size());
-    push_u16(grp);
+    const uint32_t off_pairs = uint32_t(w.size());
+    for (uint32_t g = 0; g < uint32_t(M3_STAGE_PAIR_WORDS); ++g) w.push_back(uint32_t(grp[g]) | (g < n_blocks ? uint32_t(woff[g]) << 16 : 0u));
+    if (G == 1) {
+      for (uint32_t i = 0; i < 512; i += 4) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < 4; ++k) d |= (uint32_t(cnt[i + k]) | uint32_t(cnt[i + k + 512]) << 4) << (8 * k);
+        w.push_back(d);
+      }
+    } else if (G == 2) {
+      for (uint32_t l = 0; l < 1024; l += 4) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < 4; ++k) d |= (uint32_t(cnt[l + k]) | uint32_t(cnt[l + k + 1024]) << 4) << (8 * k);
+        w.push_back(d);
+      }
+    } else {
+      for (uint32_t l = 0; l < 1024; l += 2) {
+        uint32_t d = 0;
+        for (uint32_t k = 0; k < 2; ++k)
+          d |= (uint32_t(cnt[l + k]) | uint32_t(cnt[l + k + 1024]) << 4 | uint32_t(cnt[l + k + 2048]) << 8 | uint32_t(cnt[l + k + 3072]) << 12) << (16 * k);
+        w.push_back(d);
+      }
+    }
     // response words, two per dword the way a lane fetches them: lane l of the workgroup works on responses
     // l, l + 1024, l + 2048, ... of the stage; dword [k][l] = word of response l + 2k * 1024 | word of response
     // l + (2k + 1) * 1024 << 16.  Block k holds one dword for every response of batch 2k (1024 but for the last block).
@@ -261,7 +300,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     uint32_t* h = &w[size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * stage];
     h[0] = n_resp | (n_runs << 16) | (rows << 26);
     h[1] = off_runs;
-    h[2] = off_grp;
+    h[2] = off_pairs;
     h[3] = off_resp;
   }
   bh->n_spl_f4 = spl_f4;
@@ -293,8 +332,8 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   }
   const uint32_t off_tf1 = uint32_t(w.size());
   w[1] = off_tf1;
-  const uint32_t n_waves = uint32_t(M3_GROUP / M3_WAVE);
-  w.resize(w.size() + 2 * n_waves + size_t(M3_GROUP) / 4, 0u);
+  const uint32_t n_waves = n_blocks;  // wave-blocks
+  w.resize(w.size() + 2 * n_waves + size_t(G) * M3_GROUP / 4, 0u);
   for (uint32_t le = 0; le < ne; ++le) w[off_tf1 + 2 * n_waves + le / 4] |= uint32_t(codes[le].size()) << (8 * (le % 4));
   uint64_t tf1_f2 = 0;
   for (uint32_t wv = 0; wv < n_waves; ++wv) {
@@ -365,7 +404,9 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
 double g_pad_min_fill = kPadMinFillDefault;
 
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
-                std::string* err) {
+                std::string* err, int brick_groups) {
+  if (brick_groups != 1 && brick_groups != 2 && brick_groups != 4) { *err = "brick_groups must be 1, 2 or 4"; return false; }
+  const uint32_t G = uint32_t(brick_groups);
   plan->tiles.clear();
   plan->tiles.reserve((in.n_events + M3_TE - 1) / M3_TE);
   plan->spl_float4 = plan->tf1_float2 = plan->meta_int32 = 0;
@@ -426,7 +467,8 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
     }
   });
   // Tiles that are uniform (exactly or after identity padding) stay tiles; every maximal run of the other
-  // tiles, cut at M3_GROUP events, becomes one brick.  (Mode blocks of a few thousand events therefore lose one
+  // tiles, cut at G x M3_GROUP events (sooner when the events are so heavy that the brick's stage headers would not fit
+  // the header block), becomes one brick.  (Mode blocks of a few thousand events therefore lose one
   // 256-event tile at each boundary, not a whole 1024-event group.)
   const uint64_t tiles_per_group = M3_GROUP / M3_TE;
   plan->bricks.clear();
@@ -437,10 +479,21 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
   // of planning a ragged chunk, and bricks do not depend on one another) ...
   struct BrickJob { uint64_t t0, t1; BrickHost bh; std::vector<uint32_t> words; std::string err; bool ok = true; };
   std::vector<BrickJob> jobs;
+  auto tile_resp = [&](uint64_t t) {  // TSpline3 responses of a tile's events
+    uint64_t n = 0;
+    for (uint64_t e = t * M3_TE, e1 = std::min<uint64_t>(in.n_events, (t + 1) * M3_TE); e < e1; ++e) n += in.npe[2 * e];
+    return n;
+  };
   for (uint64_t t0 = 0; t0 < n_tiles;) {
     uint64_t t1 = t0 + 1;
     if (!uniform[t0]) {
-      while (t1 < n_tiles && t1 - t0 < tiles_per_group && !uniform[t1]) ++t1;
+      // stages hold 3 000 - 5 120 responses (an event may hold 15 of a stage): stay well inside M3_BRICK_MAX_STAGES
+      uint64_t resp = tile_resp(t0);
+      while (t1 < n_tiles && t1 - t0 < tiles_per_group * G && !uniform[t1] &&
+             (t1 - t0 < tiles_per_group || resp + tile_resp(t1) <= 3000ull * uint64_t(M3_BRICK_MAX_STAGES))) {
+        resp += tile_resp(t1);
+        ++t1;
+      }
       jobs.emplace_back();
       jobs.back().t0 = t0;
       jobs.back().t1 = t1;
@@ -469,7 +522,7 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
   parallel_for(jobs.size(), [&](uint64_t j) {
     BrickJob& job = jobs[j];
     const uint64_t e0 = job.t0 * M3_TE, e1 = std::min<uint64_t>(in.n_events, job.t1 * M3_TE);
-    job.ok = plan_brick(n_params, npts, in, dict_index, e0, e1, &job.bh, &job.words, &job.err);
+    job.ok = plan_brick(n_params, npts, in, dict_index, e0, e1, G, &job.bh, &job.words, &job.err);
   });
   for (const BrickJob& job : jobs)
     if (!job.ok) { *err = job.err; return false; }  // the first failing brick in event order

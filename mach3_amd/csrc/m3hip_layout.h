@@ -15,7 +15,10 @@
 //       wavefront's 64 loads are one 1 KB line-aligned burst.  TF1: tf1[j * M3_TE + lane]
 //       float2 {a,b}.  Lane = event inside the tile; the per-event product runs over j in
 //       the reference's order (splines in event order, then TF1s).
-//   BRICK (ragged parameter lists; one per M3_GROUP = 1024 consecutive events in which the lists differ).
+//   BRICK (ragged parameter lists): G x 1024 consecutive events in which the lists differ, G = 1, 2 or 4 (the planner's
+//   `brick_groups`); lane l of the brick's 1024-lane workgroup owns events l, l + 1024, ... ("slabs" h = 0 .. G-1).  Larger
+//   bricks spread the fixed phases of a workgroup's life (first round trips, pipeline fill and drain, flush, dispatch)
+//   over more events and lengthen the runs below.
 //   TSpline3 responses: a per-brick CSC.  They are regrouped by PARAMETER so that the quads a step needs for
 //   (parameter p, segment seg[p]) are again contiguous:
 //       run (p) = the n_run events of the brick that carry p, ascending event order;
@@ -23,12 +26,14 @@
 //       (stride = n_run rounded up to 8 quads: every plane starts on a 128-B line, the unit the memory side fetches --
 //       tools/sector_fetch.hip: a line costs the same whether 16 or 128 of its bytes are used).
 //   Runs are packed into STAGES (ascending parameter ranges) of <= M3_STAGE_CAP responses in which no event holds more
-//   than M3_ELL_ROWS responses.  A stage's weights are evaluated lane-per-response (coalesced) and scattered into an LDS
-//   array ell[rank][event], rank = index of the response among its event's responses of the stage; the event's lane then
-//   multiplies ell[0..n)[event] -- ascending parameter order, the reference's order, so the float product is
-//   bit-identical.  Per response: ONE uint16 {event:10 | rank:4 | last-of-its-event-in-the-stage:1 | last-of-its-run:1}.
+//   than M3_STAGE_EVENT_MAX responses.  A stage's weights are evaluated lane-per-response (coalesced) and scattered into a
+//   COMPACT LDS array of one float per response, ordered so that the event's lane can multiply its own responses in
+//   ascending parameter order (the reference's order: the float product is bit-identical): wave-block after wave-block
+//   (slab h, wave w = events 1024 h + 64 w ... + 63), event after event, an event's responses next to each other.  Per response: ONE uint16 {slot:13 << 2 | last-of-its-run:1} (bits 2..14 are the byte
+//   offset of the response's slot); per event and stage: a 4-bit count; per wave-block and stage: the uint16 slot of its
+//   first row.  The array holds M3_STAGE_CAP floats whatever the brick's size (round 2's [rank][event] array grew with it).
 //   TF1 responses have no segment -- every step reads all of them -- so they need no regrouping: they are stored
-//   event-major per WAVE of 64 events as jagged rows (row j = the j-th TF1 of each event that has one, lanes packed),
+//   event-major per wave-block as jagged rows (row j = the j-th TF1 of each event that has one, lanes packed),
 //   read lane-per-event straight into the register product.  Per response: ONE byte, the step from the previous
 //   parameter of the event in the chunk's dictionary of TF1 parameters (255: step 254 and no response).
 //   Per-brick metadata is a uint32 word stream (layout in m3hip_layout.cpp).
@@ -44,8 +49,10 @@ constexpr int M3_TE = 256;       // events per tile (= workgroup size of the rew
 constexpr int M3_GROUP = 1024;   // classification granularity; chunk sizes are multiples of it
 constexpr int M3_STAGE_CAP = 5120;       // TSpline3 responses per brick stage (5 per lane of the 1024-lane workgroup)
 constexpr int M3_STAGE_MAX_RUNS = 512;   // runs per stage (the resolved run table lives in LDS)
-constexpr int M3_ELL_ROWS = 12;          // responses one event may hold in a stage (rows of the LDS scatter array)
-constexpr int M3_BRICK_MAX_STAGES = 62;  // stage headers are staged in LDS
+constexpr int M3_STAGE_EVENT_MAX = 15;   // responses one event may hold in a stage (its count is a nibble)
+constexpr int M3_BRICK_MAX_GROUPS = 4;   // a brick holds up to 4 x M3_GROUP events
+constexpr int M3_STAGE_PAIR_WORDS = M3_STAGE_CAP / 64;  // {run of the group's first response, first slot of wave-block} pairs per stage
+constexpr int M3_BRICK_MAX_STAGES = 250; // stage headers are staged in LDS (one load per lane of the workgroup)
 constexpr int M3_BRICK_HDR0 = 8;         // words in front of the stage headers
 constexpr int M3_STAGE_HDR = 4;          // words per stage header
 constexpr int M3_RUN_WORDS = 2;          // words per run entry
@@ -90,6 +97,7 @@ struct BrickHost {
   std::vector<uint32_t> spl_src;   // per spline response (run-major): index into the chunk's spline arrays
   std::vector<uint32_t> tf1_src;   // per TF1 slot (wave-major, jagged rows inside); 0xFFFFFFFF: skip slot -> identity {0,1}
   uint32_t n_stages = 0;           // TSpline3 stages
+  uint32_t groups = 1;             // G: the brick spans up to G x M3_GROUP events
 };
 
 struct ChunkInput {
@@ -134,8 +142,10 @@ extern double g_pad_min_fill;
 
 // Validates the chunk against (n_params, npts) and sizes the tile store.
 // Returns false and sets err on inconsistent input.
+// brick_groups: G of the bricks (1, 2 or 4); a brick whose TSpline3 responses would need more stages than the header block
+// holds falls back to a smaller G.
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
-                std::string* err);
+                std::string* err, int brick_groups = 1);
 
 // Fills caller-provided stores (sizes from the plan).  Multi-threaded.
 void fill_chunk(int n_params, const int16_t* npts, const ChunkInput& in, const ChunkPlan& plan, float* spl /*float4*/,

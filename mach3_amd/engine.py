@@ -56,6 +56,11 @@ class Engine:
             _ptr(ch["coeff_tf1"], np.float32), _ptr(ch["param_no_tf1"], np.int16), ch["n_tf1"],
             _ptr(ch["npe"], np.uint32), _ptr(ch["npe_tf1"], np.uint32)))
 
+    def monolith_expect_events(self, n_events: int):
+        """optional hint before the first append: the events this device will hold (picks the brick size)"""
+        if hasattr(self.lib, "m3hip_monolith_expect_events"):  # absent only in older builds loaded through M3HIP_LIB
+            self._chk(self.lib.m3hip_monolith_expect_events(self.h, int(n_events)))
+
     def monolith_end(self):
         self._chk(self.lib.m3hip_monolith_end(self.h))
 
@@ -122,12 +127,13 @@ class SMonolith:
     constructor takes the flattened arrays PrepareForGPU would have produced (one dict per
     event chunk, see synth.monolith_chunk) instead of a MasterSpline of ROOT objects."""
 
-    def __init__(self, engine: Engine, n_params, max_knots, coeff_x, npts, chunks):
+    def __init__(self, engine: Engine, n_params, max_knots, coeff_x, npts, chunks, expect_events=0):
         self.eng = engine
         self.nParams = int(n_params)
         self._max_knots = int(max_knots)
         self.coeff_x = np.ascontiguousarray(coeff_x, np.float32)
         self.npts = np.ascontiguousarray(npts, np.int16)
+        engine.monolith_expect_events(expect_events)
         engine.monolith_begin(n_params, max_knots, self.coeff_x, self.npts)
         for ch in chunks:
             engine.monolith_append(ch)
@@ -450,7 +456,7 @@ def build_from_synth(spec, device_id=0, chunk_events=131072, event_range=None, e
         for a in range(e0, e1, chunk_events):
             yield synth.monolith_chunk(spec, a, min(e1, a + chunk_events))
 
-    mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, chunks())
+    mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, chunks(), expect_events=e1 - e0)
     par = synth.params(spec, 0)
     mono.setSplinePointers(par)
     sh = SampleHandlerFD(eng, spec.n_samples, synth.sample_bin_offsets(spec), par, spec.test_statistic)

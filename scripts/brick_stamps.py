@@ -29,9 +29,14 @@ buf = np.zeros(n * 16, np.uint64)
 rc = eng.lib.m3hip_debug_read_stamps(C.c_void_p(buf.ctypes.data), C.c_uint64(buf.size))
 assert rc == 0, rc
 t = buf.reshape(n, 16).astype(np.int64)
+G = int(eng.info().brick_groups)
 names = {1: "prologue: first round trip, tables of stage 0, barrier", 2: "(stamp 2: unused)", 3: "stage 0 (waits for the first quads)", 4: "stage 1", 5: "stage 2",
          6: "stage 3", 8: "last stage", 9: "TF1 rows", 10: "event tail (norm, osc, bin, LDS fill) + barrier", 11: "flush of the bin vector"}
 tot = (t[:, 11] - t[:, 0]) / 100.0
+if G > 1:
+    d13 = (t[:, 13] - t[:, 8]) / 100.0
+    ok = (t[:, 13] >= t[:, 8]) & (t[:, 13] <= t[:, 11])
+    print(f"  G = {G}: slab 0 (TF1 rows + tail) after the last stage: mean {d13[ok].mean():.2f} us")
 print(f"{cfg} E={ev}: {nb} bricks; brick lifetime mean {tot.mean():.1f} us, median {np.median(tot):.1f} us")
 # a brick writes only the stamps of the stages it has (3 + s for its first four stages except the last one, 8 after the last);
 # slots it did not write hold what an earlier launch left there: a stamp counts when it lies between its predecessor and the end

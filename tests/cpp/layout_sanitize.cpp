@@ -18,7 +18,8 @@ struct Chunk {
   std::vector<int16_t> param_no, param_no_tf1;
 };
 
-static int run_case(uint64_t seed, uint64_t n_events, int n_params, double occupancy, bool mixed, bool uniform_lists, double pad_min_fill = kPadMinFillDefault) {
+static int run_case(uint64_t seed, uint64_t n_events, int n_params, double occupancy, bool mixed, bool uniform_lists, double pad_min_fill = kPadMinFillDefault,
+                    int groups = 1) {
   g_pad_min_fill = pad_min_fill;
   std::mt19937_64 rng(seed);
   std::uniform_real_distribution<double> U(0.0, 1.0);
@@ -60,15 +61,15 @@ static int run_case(uint64_t seed, uint64_t n_events, int n_params, double occup
   in.npe_tf1 = c.npe_tf1.data();
   ChunkPlan plan;
   std::string err;
-  if (!plan_chunk(n_params, K, npts.data(), in, &plan, &err)) {
+  if (!plan_chunk(n_params, K, npts.data(), in, &plan, &err, groups)) {
     std::printf("seed %llu: plan refused: %s\n", (unsigned long long)seed, err.c_str());
     return 0;  // a refusal is a valid outcome (e.g. too many stages); crashing is not
   }
   std::vector<float> spl(plan.spl_float4 * 4), tf1(plan.tf1_float2 * 2);
   std::vector<int32_t> meta(plan.meta_int32);
   fill_chunk(n_params, npts.data(), in, plan, spl.data(), tf1.data(), meta.data());
-  std::printf("seed %llu: E=%llu P=%d occ=%.2f mixed=%d uniform=%d -> %llu uniform tiles, %llu bricks, %zu words, %.1f MB\n",
-              (unsigned long long)seed, (unsigned long long)n_events, n_params, occupancy, int(mixed), int(uniform_lists),
+  std::printf("seed %llu: E=%llu P=%d occ=%.2f mixed=%d uniform=%d G=%d -> %llu uniform tiles, %llu bricks, %zu words, %.1f MB\n",
+              (unsigned long long)seed, (unsigned long long)n_events, n_params, occupancy, int(mixed), int(uniform_lists), groups,
               (unsigned long long)plan.n_uniform, (unsigned long long)plan.n_brick, plan.brick_words.size(), double(spl.size()) * 4e-6);
   return 0;
 }
@@ -80,7 +81,10 @@ int main() {
   rc |= run_case(3, 2048 + 300, 48, 0.2, true, false);  // ragged, three groups
   rc |= run_case(4, 1500, 40, 0.3, false, false);     // ragged, TSpline3 only
   rc |= run_case(5, 1024, 200, 0.9, true, false, 2.0);     // deep brick (many stages; identity padding off)
-  rc |= run_case(6, 1024, 700, 0.95, false, false, 2.0);   // beyond the stage limit: must be refused cleanly
+  rc |= run_case(6, 1024, 1500, 0.95, false, false, 2.0);  // beyond the stage limit: must be refused cleanly
+  rc |= run_case(9, 4096 + 2048 + 300, 48, 0.2, true, false, kPadMinFillDefault, 2);  // bricks of 2048 events, a short last one
+  rc |= run_case(10, 2 * 4096 + 1500, 64, 0.1, true, false, kPadMinFillDefault, 4);   // bricks of 4096 events
+  rc |= run_case(11, 4096, 300, 0.9, false, false, 2.0, 4);  // heavy events: the planner cuts the bricks short of 4096 events
   rc |= run_case(8, 2048 + 300, 60, 0.85, true, false);    // nearly uniform lists: identity-padded uniform tiles
   rc |= run_case(7, 3000, 16, 0.0, true, false);      // no responses at all
   std::printf("OK\n");

@@ -106,7 +106,16 @@ def _run_case(fresh_engine, c, seed):
     if E > 2048 and seed % 2:
         cut = 1024 * int(rng.integers(1, E // 1024))
         chunks = [make_monolith(P, 7, c["xs"], c["events"][:cut])[2], make_monolith(P, 7, c["xs"], c["events"][cut:])[2]]
-    mono = SMonolith(fresh_engine, P, 7, cx, npts, chunks)
+    # bricks of 1024, 2048 or 4096 events, by the seed (the engine reads the switch when the first chunk arrives)
+    forced = os.environ.get("M3HIP_BRICK_GROUPS")
+    os.environ["M3HIP_BRICK_GROUPS"] = forced or str((1, 2, 4)[seed % 3])
+    # the events' {bin, osc, norm} indices as one packed word (the default when they fit) or as three arrays
+    os.environ["M3HIP_PACKED_EVENTS"] = "0" if seed % 4 == 3 else "1"
+    try:
+        mono = SMonolith(fresh_engine, P, 7, cx, npts, chunks)
+    finally:
+        if forced is None:
+            del os.environ["M3HIP_BRICK_GROUPS"]
     mono.setSplinePointers(par)
     off = (np.arange(c["n_samples"] + 1) * c["nb"]).astype(np.int32)
     sh = SampleHandlerFD(fresh_engine, c["n_samples"], off, par, c["stat"], update_w2=c["update_w2"])
@@ -146,6 +155,7 @@ def _run_case(fresh_engine, c, seed):
     assert np.array_equal(mono.cpu_total_weights.view(np.uint32), omono.total_weights.view(np.uint32)), tag
     osamp.close()
     omono.close()
+    os.environ.pop("M3HIP_PACKED_EVENTS", None)
 
 
 @pytest.mark.parametrize("seed", range(24 * SCALE))

@@ -416,14 +416,17 @@ def test_api_error_paths(fresh_engine):
         sh.Reweight()
 
 
+@pytest.mark.parametrize("groups", [1, 2, 4])
 @pytest.mark.parametrize("cfg,n_events,n_params", [("c3", 5000, 96), ("c5", 3000, 512), ("c3", 1024 * 9 + 77, 512)])
-def test_ragged_bricks_match_oracle(fresh_engine, cfg, n_events, n_params):
+def test_ragged_bricks_match_oracle(fresh_engine, monkeypatch, cfg, n_events, n_params, groups):
     """Configs 3-5 shape: random sparse occupancy, mixed TSpline3 / TF1, Barlow-Beeston.  Goes
-    through the brick kernel; weights bit-exact, bins 1e-12, LLH 1e-9."""
+    through the brick kernel, in bricks of 1024, 2048 and 4096 events; weights bit-exact, bins 1e-12, LLH 1e-9."""
+    monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
     spec = synth.CONFIGS[cfg].scaled(n_events, n_params=n_params)
     eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine, chunk_events=4096)
     info = eng.info()
-    assert info.n_tiles_brick == (n_events + 1023) // 1024 and info.n_tiles_uniform == 0
+    assert info.brick_groups == groups
+    assert info.n_tiles_brick == sum(-(-min(4096, n_events - a) // (1024 * groups)) for a in range(0, n_events, 4096)) and info.n_tiles_uniform == 0
     omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
     assert info.n_splines == ch["n_splines"] and info.n_tf1 == ch["n_tf1"]
     sh.RecordEventWeights(True)
@@ -746,9 +749,10 @@ def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkey
     omono.close()
 
 
-def test_brick_stage_limit_is_reported(fresh_engine):
-    """more responses in a sparse 1024-event group than the 62 stage headers hold: the upload is refused with a
-    message, nothing is silently truncated"""
+def test_brick_of_ninety_stages(fresh_engine):
+    """~390 000 responses in a sparse 1024-event group: one brick of ~90 stages (round 2's header block refused it at
+    62); every weight bit-exact.  The refusal beyond M3_BRICK_MAX_STAGES = 250 (1.3 M responses in one brick) is
+    exercised on the CPU by tests/cpp/layout_sanitize.cpp."""
     rng = np.random.default_rng(9)
     P = 640
     X3 = np.array([-1.0, 0, 1])
@@ -756,8 +760,8 @@ def test_brick_stage_limit_is_reported(fresh_engine):
     events = _ragged_events(rng, 1024, P, 0.6, xs)
     assert sum(len(e) for e in events) > 62 * 5120
     cx, npts, ch = make_monolith(P, 3, xs, events)
-    with pytest.raises(capi.M3HipError, match="stages"):
-        SMonolith(fresh_engine, P, 3, cx, npts, [ch])
+    info = _eval_matches(fresh_engine, P, 3, cx, npts, ch, rng, laps=2)
+    assert info.n_tiles_brick == 1 and info.n_tiles_uniform == 0
 
 
 def test_uniform_and_ragged_groups_in_one_sample(fresh_engine):

@@ -124,28 +124,46 @@ def test_layout_rejects_inconsistent_input():
     assert rc != 0 and "knot count" in err
 
 
-ELL_ROWS, STAGE_CAP, STAGE_MAX_RUNS, HDR0, TF1_SKIP = 12, 5120, 512, 8, 255
+STAGE_EVENT_MAX, STAGE_CAP, STAGE_MAX_RUNS, HDR0, TF1_SKIP, PAIR_WORDS = 15, 5120, 512, 8, 255, 80
 
 
 def brick_event_lists(npts, ch, lay, b):
     """Replay a brick's metadata stream on the CPU with coefficient quads instead of weights, the way
     k_reweight_brick walks it: returns, per event of the brick, the ordered list of (param, kind,
-    coefficients) the kernel would multiply.  TSpline3 stages: phase A scatters response r to
-    ell[rank][event], phase B reads the event's column; TF1: the wave's jagged rows, lane per event."""
+    coefficients) the kernel would multiply.  TSpline3 stages: phase A scatters response r to its slot of
+    the compact array, phase B lets every lane read its event's slots (they lie next to each other); TF1: the wave-block's jagged rows, lane per event."""
     spl, tf1, words, tdict = lay["spl"], lay["tf1"], lay["words"], lay["tf1_dict"]
     spl_off, tf1_off, w_off, n_f4, n_f2, nev, e0, nw = [int(v) for v in lay["bdesc"][b]]
     assert w_off % 32 == 0 and nw % 32 == 0            # every brick's stream starts on a 128-byte line
     w = words[w_off: w_off + nw]
     out = [[] for _ in range(nev)]
-    n_stages, off_tf1 = int(w[0]), int(w[1])
+    n_stages, off_tf1, G = int(w[0]), int(w[1]), int(w[3])
+    assert G in (1, 2, 4) and nev <= 1024 * G
+    n_blocks = 16 * G
     used = np.zeros(max(1, n_f4), bool)
     for s in range(n_stages):
-        h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
+        h0, off_runs, off_pairs, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
         n_resp, n_runs, rows = h0 & 0xFFFF, (h0 >> 16) & 0x3FF, h0 >> 26
         assert 0 < n_resp <= STAGE_CAP and 0 < n_runs <= STAGE_MAX_RUNS and off_runs % 2 == 0
         runs = w[off_runs: off_runs + 2 * n_runs].reshape(-1, 2)
-        grp = w[off_grp: off_grp + STAGE_CAP // 128].view(np.uint16)
+        pairs = w[off_pairs: off_pairs + PAIR_WORDS]
+        grp = (pairs & 0xFFFF).astype(np.int64)
+        woff = (pairs[:n_blocks] >> 16).astype(np.int64)
+        assert not (pairs[n_blocks:] >> 16).any()
         assert (grp[(n_resp + 63) // 64:] == n_runs).all()
+        cb = w[off_pairs + PAIR_WORDS: off_pairs + PAIR_WORDS + 128 * G]
+        cnt = np.zeros(1024 * G, np.int64)                # the way a lane fetches its G nibbles
+        if G == 1:
+            by = cb.view(np.uint8)
+            cnt[:512], cnt[512:] = by & 15, by >> 4
+        elif G == 2:
+            by = cb.view(np.uint8)
+            cnt[:1024], cnt[1024:] = by & 15, by >> 4
+        else:
+            hw = cb.view(np.uint16)
+            for h in range(4):
+                cnt[1024 * h: 1024 * (h + 1)] = (hw >> (4 * h)) & 15
+        assert cnt.sum() == n_resp and not cnt[nev:].any() and cnt.max() == rows <= STAGE_EVENT_MAX
         resp = np.zeros(n_resp, np.uint16)                # two per dword, the way a lane fetches them
         for k in range((n_resp + 2047) // 2048):
             ln = min(1024, n_resp - 2048 * k)
@@ -155,15 +173,13 @@ def brick_event_lists(npts, ch, lay, b):
             resp[2048 * k + 1024: 2048 * k + 1024 + hi] = blk[:hi] >> 16
             assert not (blk[hi:] >> 16).any()
         ell = {}
-        cnt = {}
-        run, prev_param = -1, -1
+        run = -1
         for r in range(n_resp):
             if r % 64 == 0:
                 run = int(grp[r // 64])                  # the kernel: run of the group's first response ...
             wd = int(resp[r])
-            ev, rk, last_run = (wd >> 2) & 0x3FF, wd >> 12, wd & 1
-            assert not wd & 2
-            assert ev < nev and rk < ELL_ROWS
+            slot, last_run = (wd & 0x7FFC) >> 2, wd & 1
+            assert not wd & 0x8002 and slot < n_resp
             base = int(np.int32(runs[run][0]))
             stride, p = int(runs[run][1]) & 0xFFFF, int(runs[run][1]) >> 16
             assert stride % 8 == 0
@@ -171,29 +187,34 @@ def brick_event_lists(npts, ch, lay, b):
             idx = [base + k * stride + r for k in range(nseg)]
             assert all(0 <= i < n_f4 for i in idx) and not used[idx].any()
             used[idx] = True
-            assert (rk, ev) not in ell
-            ell[(rk, ev)] = (p, "spl", np.stack([spl[spl_off + i] for i in idx]))
-            cnt[ev] = max(cnt.get(ev, 0), rk + 1)
+            assert slot not in ell                       # one slot per response
+            ell[slot] = (p, "spl", np.stack([spl[spl_off + i] for i in idx]))
             run += last_run                              # ... + the runs that ended before this response
         assert run == n_runs                             # the last response closes the last run
-        for e in range(nev):
-            col = [ell.pop((j, e)) for j in range(cnt.get(e, 0))]
-            assert [x[0] for x in col] == sorted(x[0] for x in col)
-            out[e] += col
+        # phase B: every lane reads its event's slots: first slot of the wave-block + exclusive prefix sum of the counts
+        # over the block's lanes (a wave scan in the kernel) + j
+        for blk_i in range(n_blocks):
+            lanes = np.arange(64 * blk_i, 64 * blk_i + 64)
+            excl = np.cumsum(cnt[lanes]) - cnt[lanes]
+            for i, le in enumerate(lanes):
+                for j in range(int(cnt[le])):
+                    out[le].append(ell.pop(int(woff[blk_i]) + int(excl[i]) + j))
         assert not ell                                   # every scattered weight is consumed by its event
-        assert rows == max(cnt.values()) <= ELL_ROWS      # the rows of the scatter array the stage uses
+        for e in range(nev):
+            ps = [x[0] for x in out[e] if x[1] == "spl"]
+            assert ps == sorted(ps)
         # planes start on 128-byte lines (start_r of a run = index of its first response, recovered from the words)
         ends = np.flatnonzero(resp & 1) + 1
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
             assert (int(np.int32(runs[rn][0])) + int(first_r[rn])) % 8 == 0
-    # TF1: jagged rows per wave of 64 events
-    hdr = w[off_tf1: off_tf1 + 32 + 256]
-    cnts = hdr[32:].view(np.uint8)
+    # TF1: jagged rows per wave-block of 64 events
+    hdr = w[off_tf1: off_tf1 + 32 * G + 256 * G]
+    cnts = hdr[32 * G:].view(np.uint8)
     assert all(int(c) == 0 for c in cnts[nev:])
     slots = 0
-    for wv in range(16):
-        cbase, dbase = int(hdr[wv]), int(hdr[16 + wv])
+    for wv in range(n_blocks):
+        cbase, dbase = int(hdr[wv]), int(hdr[16 * G + wv])
         lanes = [le for le in range(64 * wv, min(nev, 64 * wv + 64))]
         kd = {le: -1 for le in lanes}
         rows = max([int(cnts[le]) for le in lanes], default=0)
@@ -317,17 +338,33 @@ def test_ragged_requires_ascending_parameters():
     assert rc != 0 and "ascending" in err
 
 
-def test_brick_stage_limit_is_reported():
-    """more responses in a sparse 1024-event group than the 62 stage headers hold: refused with a message
-    (a group whose events carry at least 88 % of the union list would be identity-padded into uniform tiles instead)"""
+def test_deep_brick_many_stages():
+    """~390 000 responses in a sparse 1024-event group: a brick of ~90 stages (round 2's header block refused it at 62);
+    the refusal beyond M3_BRICK_MAX_STAGES = 250 is exercised by tests/cpp/layout_sanitize.cpp (1.4 M responses)."""
     rng = np.random.default_rng(9)
     P, X3 = 640, np.array([-1.0, 0, 1])
     c = natural_cubic(X3, [0.9, 1.0, 1.2])
     events = [[(p, "spl", c) for p in range(P) if rng.random() < 0.6] for _ in range(1024)]
     assert sum(len(e) for e in events) > 62 * STAGE_CAP
     cx, npts, ch = make_monolith(P, 3, {p: X3 for p in range(P)}, events)
-    rc, err, _ = debug_layout(P, 3, npts, ch)
-    assert rc != 0 and "stages" in err
+    rc, err, lay = debug_layout(P, 3, npts, ch)
+    assert rc == 0, err
+    assert lay["n_bricks"] == 1 and 62 < int(lay["words"][int(lay["bdesc"][0][2])]) <= 250
+
+
+@pytest.mark.parametrize("groups,n_events,cfg", [(2, 2048 + 1024 + 300, "c3"), (4, 4096 + 1500, "c5"), (4, 4096, "c3")])
+def test_bricks_of_several_event_groups(monkeypatch, groups, n_events, cfg):
+    """G = 2 / 4: bricks of 2048 / 4096 events (lane l owns events l, l + 1024, ...), a short brick at the end;
+    replayed event by event like the 1024-event ones."""
+    monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
+    spec = synth.CONFIGS[cfg].scaled(n_events)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, n_events)
+    rc, err, lay = debug_layout(spec.n_params, spec.n_knots, npts, ch)
+    assert rc == 0, err
+    assert lay["n_bricks"] == -(-n_events // (1024 * groups)) and lay["n_tiles"] == 0
+    assert [int(d[5]) for d in lay["bdesc"]] == [min(1024 * groups, n_events - 1024 * groups * b) for b in range(lay["n_bricks"])]
+    check_bricks(npts, ch, lay)
 
 
 def test_layout_under_sanitizers(tmp_path):
