@@ -61,13 +61,13 @@ def pmc_traffic(config_name, per_gpu):
             d = json.load(open(f))
             for k, v in d["kernels"].items():
                 if "k_reweight" in k and "hbm_bytes_per_launch" in v and d.get("events_per_gpu", 1_000_000) == per_gpu:
-                    best = {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT)}
+                    best = {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "round": d.get("round")}
         except Exception:
             pass
     return best
 
 
-EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "4"))
+EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "2"))  # a 20-step driver run times 10 launches
 
 
 def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
@@ -134,13 +134,20 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
     }
 
 
-def shard_of(spec, rank, n_ranks):
+def shard_of(spec, rank, n_ranks, tdist=None):
     """[e0, e1) of this rank: contiguous blocks on 1024-event boundaries, balanced by responses.  The
-    weights come from the generator's own counts in blocks of 65536 events (event data are a pure function of the
-    event number, so every rank computes the same cuts)."""
+    weights come from the generator's own counts in blocks of 65536 events.  With a process group (`tdist`) rank 0
+    counts once and broadcasts the cuts (eight ranks counting 4e7 events each is eight times the set-up work on one
+    host); without one every rank computes the same cuts by itself (event data are a pure function of the event number)."""
     from mach3_amd import dist, synth
     if n_ranks == 1:
         return 0, spec.n_events
+    if tdist is not None:
+        cuts = [None]
+        if rank == 0:
+            cuts = [[shard_of(spec, r, n_ranks) for r in range(n_ranks)]]
+        tdist.broadcast_object_list(cuts, src=0)
+        return tuple(cuts[0][rank])
     blk = 65536
     edges = list(range(0, spec.n_events, blk)) + [spec.n_events]
     w = np.empty(spec.n_events, np.float32)
@@ -160,7 +167,7 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
     from mach3_amd import synth
     from mach3_amd.engine import build_from_synth
 
-    e0, e1 = shard_of(spec, rank, n_ranks)
+    e0, e1 = shard_of(spec, rank, n_ranks, dist if n_ranks > 1 else None)
     t_setup = time.perf_counter()
     eng, mono, sh, par = build_from_synth(spec, device_id=local_rank, chunk_events=args.chunk, event_range=(e0, e1))
     info = eng.info()
@@ -238,13 +245,28 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         reduce_bins()
         return sh.GetLikelihood()
 
+    # The exchange validates itself on the untimed steps: every rank's partial bin vector is all-gathered and summed on
+    # the host in rank order, and the all-reduced vector must agree per bin (m3hip_comm_set_validate); a mismatch fails
+    # the step.  Off again for the timed region (it costs an all-gather and a device-to-host copy per step).
+    in_library = comm_mode.startswith("rccl")
+    if in_library:
+        eng.comm_set_validate(True)
     t_spin = time.perf_counter()
     n_spin = 0
     while time.perf_counter() - t_spin < args.spinup_seconds:
         step(n_spin)
         n_spin += 1
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 2 if in_library else 0)):
         step(i)
+    comm_val = None
+    if in_library:
+        rel, n_val = eng.comm_last_validation()
+        eng.comm_set_validate(False)
+        v = torch.tensor([rel, float(n_val)], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(v[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(v[1:], op=dist.ReduceOp.MIN)
+        comm_val = {"validated_steps": int(v[1].item()), "max_rel": float(v[0].item())}
     eng.timing_enable(EVENT_EVERY)  # hipEvents around every EVENT_EVERY-th launch of the timed region
     eng.timing_reset()
     if dist is not None:
@@ -263,13 +285,21 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     k_ms, k_n = eng.timing_read(0)
+    gap_ms, gap_n = eng.timing_read(2) if in_library else (0.0, 0)
     eng.timing_enable(False)
+    k_all = [k_ms]
+    if dist is not None and n_ranks > 1:
+        t = torch.zeros(n_ranks, dtype=torch.float64, device="cuda")
+        t[rank] = k_ms
+        dist.all_reduce(t)
+        k_all = [float(x) for x in t.cpu()]
     check = None
     if args.check:  # LLH of a few laps, for the comparison with a one-rank run of the same sample
         check = []
         for i in range(3):
             check.append(step(1000 + i))
-    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check)
+    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val,
+               comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all)
     eng.close()
     return out
 
@@ -304,6 +334,8 @@ def roofline(base_name, m, per_gpu):
         "frac": ach / HBM_PEAK_GBS if ach else None,
         "traffic": tr["bytes"] if tr else None,
         "traffic_source": tr["source"] if tr else None,
+        "traffic_measured_in_run": False,  # a constant from the committed rocprofv3 --pmc passes of this workload (counters cannot be read in-process)
+        "traffic_profile_round": tr.get("round") if tr else None,
         "alg_bytes_per_launch": int(info.alg_bytes_fused),
         "avg_kernel_ms": k_ms,
         "launches_timed": m["k_n"],
@@ -407,9 +439,19 @@ def main():
                 "responses_rank0": int(m["info"].n_splines + m["info"].n_tf1),
                 "comm": m["comm"],
                 "last_llh": m["llh"],
+                "brick_events": 1024 * int(m["info"].brick_groups or 1),
             },
             "roofline": roofline(base.name, m, per_gpu),
         }
+        if m["comm_val"] is not None:
+            # self-validation of the exchange on the untimed steps (every rank; the worst bin of the worst rank), the time the
+            # exchange adds between the reweight kernel's end and the bin likelihood's start, and every rank's kernel time
+            out["config"]["comm_validated"] = bool(m["comm_val"]["validated_steps"] > 0)
+            out["config"]["comm_validated_steps"] = m["comm_val"]["validated_steps"]
+            out["config"]["comm_max_rel"] = m["comm_val"]["max_rel"]
+            out["config"]["comm_us"] = m["comm_us"]
+        if len(m["k_all"]) > 1:
+            out["roofline"]["avg_kernel_ms_by_rank"] = {"min": min(m["k_all"]), "max": max(m["k_all"])}
         if check is not None:
             out["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:

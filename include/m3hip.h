@@ -364,7 +364,9 @@ typedef struct {
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,
  * measured with hipEvents on the stream the kernel runs on.  which: 0 = fused reweight
- * kernel, 1 = spline-eval kernel.  enable = N > 0 times every N-th fused launch (1: all of them), 0 switches
+ * kernel, 1 = spline-eval kernel, 2 = with a communicator: from the end of the fused reweight kernel to the point where the
+ * bin likelihood may start (replica fold + all-reduce + un-park, taken on the same sampled steps from an event recorded in
+ * front of the likelihood kernel).  enable = N > 0 times every N-th fused launch (1: all of them), 0 switches
  * the events off.  The fused launch is an extended launch whose two events receive the dispatch's own
  * start / end timestamps -- what a profiler reports -- at ~3 us per timed step; events recorded around the
  * launch instead cost ~8 us and read 2-3 % long. */

@@ -250,10 +250,11 @@ struct m3hip_ctx {
   // timing
   int timing = 0;           // 0: off, N: bracket every N-th launch with hipEvents
   uint64_t timing_ctr = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // reweight dispatch start / end; marker in front of k_llh (exchange gap)
+  bool gap_pending = false;       // this step's reweight launch was timed and an exchange followed it
   int pending = -1;
-  double acc_ms[2] = {0, 0};
-  uint64_t cnt[2] = {0, 0};
+  double acc_ms[3] = {0, 0, 0};   // [0] fused reweight kernel, [1] seam-2 evaluation, [2] reweight end -> k_llh ready (fold + all-reduce + unpark)
+  uint64_t cnt[3] = {0, 0, 0};
   ReweightKnobs knobs;
   double host_t[6] = {0, 0, 0, 0, 0, 0};  // host-side seconds of the last step's phases (debug)
   double host_abs[2] = {0, 0};             // absolute host time (s): k_prep launch call, flag seen
@@ -330,6 +331,11 @@ void collect_timing(m3hip_handle h) {
       h->acc_ms[h->pending] += ms;
       h->cnt[h->pending]++;
     }
+    if (h->gap_pending && hipEventElapsedTime(&ms, h->ev1, h->ev2) == hipSuccess) {
+      h->acc_ms[2] += ms;
+      h->cnt[2]++;
+    }
+    h->gap_pending = false;
     h->pending = -1;
   }
 }
@@ -558,7 +564,7 @@ int m3hip_create(int device_id, m3hip_handle* out) try {
   m3hip_ctx* h = new m3hip_ctx();
   h->device = device_id;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+      (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess || (e = hipEventCreate(&h->ev2)) != hipSuccess) {
     std::string m = hipGetErrorString(e);
     delete h;
     return fail(nullptr, M3HIP_EHIP, "device initialisation failed: " + m);
@@ -598,6 +604,7 @@ int m3hip_destroy(m3hip_handle h) try {
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return M3HIP_OK;
@@ -1994,17 +2001,16 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     if (h->hist_rep > 1) launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, with_w2 ? 1 : 0, parked ? 1 : 0, h->stream);  // one replica: nothing to fold
     if (with_w2) h->w2_spread = false;
     const size_t n_msg = size_t(h->n_bins) * (with_w2 ? 2 : 1);  // one replica: w2 sits behind mc as it is
-    if (h->comm_validate) {
-      const int rc = comm_validate_begin(h, n_msg);
-      if (rc) return rc;
+    // whatever fails below, w2 goes back to where k_llh and m3hip_get_bins look for it before the error is returned
+    int rc_comm = h->comm_validate ? comm_validate_begin(h, n_msg) : M3HIP_OK;
+    if (rc_comm == M3HIP_OK) {
+      ncclResult_t r = g_rccl.AllReduce(h->d_hist, h->d_hist, n_msg, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
+      if (r != ncclSuccess) rc_comm = fail(h, M3HIP_ECOMM, "ncclAllReduce: " + g_rccl.why(r));
     }
-    ncclResult_t r = g_rccl.AllReduce(h->d_hist, h->d_hist, n_msg, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream);
-    if (r != ncclSuccess) return fail(h, M3HIP_ECOMM, "ncclAllReduce: " + g_rccl.why(r));
-    if (h->comm_validate) {
-      const int rc = comm_validate_end(h, n_msg);
-      if (rc) return rc;
-    }
+    if (rc_comm == M3HIP_OK && h->comm_validate) rc_comm = comm_validate_end(h, n_msg);
     if (parked) launch_unpark_w2(h->d_hist, h->hist_rep, h->n_bins, h->stream);
+    if (rc_comm != M3HIP_OK) return rc_comm;
+    h->gap_pending = timed && (n_tiles || n_bricks);  // m3hip_get_likelihood drops a marker in front of k_llh
   }
   if (!h->update_w2) h->first_w2 = false;  // SampleHandlerFD.cpp:342
   const double t_d = now_s();
@@ -2036,6 +2042,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.ticket = ++h->llh_ticket;
   l.dbg_clock = h->d_dbg_clock;
   const double t_a = now_s();
+  if (h->gap_pending) (void)hipEventRecord(h->ev2, h->stream);  // sampled steps with an exchange: reweight end -> here
   launch_llh(l, h->stream);
   if (l.w2_mode == kW2FoldInPlace) h->w2_spread = false;
   HIPCHK(h, hipGetLastError());
@@ -2181,7 +2188,7 @@ int m3hip_comm_init(m3hip_handle h, const void* unique_id, int rank, int n_ranks
   h->comm = comm;
   h->rank = rank;
   h->n_ranks = n_ranks;
-  { const char* f = getenv("M3HIP_COMM_VALIDATE"); h->comm_validate = f && f[0] == '1'; }
+  { const char* f = getenv("M3HIP_COMM_VALIDATE"); if (f && f[0] == '1') h->comm_validate = true; }  // ORed into a setting made before the init
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -2350,7 +2357,7 @@ int m3hip_timing_enable(m3hip_handle h, int enable) try {
 } M3_API_CATCH(h)
 
 int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_launches) try {
-  if (!h || which < 0 || which > 1) return M3HIP_EINVAL;
+  if (!h || which < 0 || which > 2) return M3HIP_EINVAL;
   if (avg_ms) *avg_ms = h->cnt[which] ? h->acc_ms[which] / double(h->cnt[which]) : 0.0;
   if (n_launches) *n_launches = h->cnt[which];
   return M3HIP_OK;
@@ -2358,8 +2365,8 @@ int m3hip_timing_read(m3hip_handle h, int which, double* avg_ms, uint64_t* n_lau
 
 int m3hip_timing_reset(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
-  h->acc_ms[0] = h->acc_ms[1] = 0;
-  h->cnt[0] = h->cnt[1] = 0;
+  h->acc_ms[0] = h->acc_ms[1] = h->acc_ms[2] = 0;
+  h->cnt[0] = h->cnt[1] = h->cnt[2] = 0;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

@@ -33,6 +33,13 @@ def _worker(rank, world, port, n_events, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
     e0, e1 = m3dist.shard_ranges(n_events, world)[rank]
+    # bench.py's cuts: rank 0 counts the responses once and broadcasts; must equal what a rank would compute by itself
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("m3_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    big = synth.CONFIGS["c3"].scaled(300_000)
+    cut_bcast, cut_own = bench.shard_of(big, rank, world, dist), bench.shard_of(big, rank, world)
     mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, e0, e1)
     lib = ob.load("serial")
     out = []
@@ -46,7 +53,7 @@ def _worker(rank, world, port, n_events, q):
             data = mc.copy()
         llh = sum(lib.m3o_test_stat_llh(capi.kBarlowBeeston, data[i], mc[i], w2[i]) for i in range(len(mc)))
         out.append((llh, mc.sum()))
-    q.put((rank, (e0, e1), out))
+    q.put((rank, (e0, e1), out, tuple(cut_bcast), tuple(cut_own)))
     dist.destroy_process_group()
 
 
@@ -68,6 +75,9 @@ def test_two_rank_event_sharding_matches_unsharded():
         assert p.exitcode == 0
     # shards tile the sample on 1024-event boundaries
     assert res[0][1] == (0, 3072) and res[1][1] == (3072, 5000)
+    # bench.py's broadcast cuts: what each rank would have computed alone, contiguous, covering the sample
+    assert all(r[3] == r[4] for r in res)
+    assert res[0][3][0] == 0 and res[0][3][1] == res[1][3][0] and res[1][3][1] == 300_000 and res[0][3][1] % 1024 == 0
     # unsharded reference
     spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
     mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)

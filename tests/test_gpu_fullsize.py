@@ -129,7 +129,7 @@ def test_config3_full_size_properties():
     spec = synth.CONFIGS["c3"]
     E = spec.n_events
     info = _check_full_size(spec, 0, E, [(0, 2500), (5_000_000, 5_002_048), (E - 3000, E)])
-    assert info.n_tiles_brick == (E + 1023) // 1024 and info.n_tiles_uniform == 0
+    assert info.brick_groups == 1 and info.n_tiles_brick == (E + 1023) // 1024 and info.n_tiles_uniform == 0
     assert info.n_splines * spec.n_knots * 4 > 2 ** 32
 
 
@@ -147,4 +147,6 @@ def test_config5_shard_properties():
     spec = synth.CONFIGS["c5"]
     per = spec.n_events // 8
     info = _check_full_size(spec, 5 * per, 6 * per, [(0, 3000), (per - 2048, per)], laps=(1,), shard_check=False)
-    assert info.n_params == 1024 and info.n_tiles_brick == (per + 1023) // 1024
+    # 16 responses per event and 12 208 groups of 1024 events: the engine lays this shard out in bricks of 2048 events (chunk by chunk)
+    assert info.n_params == 1024 and info.brick_groups == 2
+    assert info.n_tiles_brick == sum(-(-min(131072, per - a) // 2048) for a in range(0, per, 131072))
