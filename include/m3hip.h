@@ -343,6 +343,22 @@ int m3hip_comm_destroy(m3hip_handle h);
  * sums them there in rank order and fails with M3HIP_ECOMM if the all-reduced vector differs by more than
  * a few ulps per bin.  Costs a device synchronisation per step: for tests and first runs on a new node. */
 int m3hip_comm_set_validate(m3hip_handle h, int on);
+
+/* One-shot exchange of the bin vector (the message is 1.6 - 6.4 KB, latency-bound; a ring all-reduce is
+ * 2 (N-1) hops, this is one).  Every rank owns a buffer of 2 x N slots in fine-grained device memory; per step a rank
+ * stores its folded [mc | w2] vector and a ticket into its slot of EVERY rank's buffer (peer stores over xGMI through
+ * IPC mappings), and the bin likelihood starts once the N tickets of its own buffer carry the step number, from the
+ * rank-ordered sum of the N slots: bit-identical bins on every rank.  Transport-free like m3hip_comm_init: the caller
+ * carries the 64-byte handles between the ranks (MPI, torch.distributed, a file).
+ *   m3hip_xch_create  after the bin space is defined; allocates this rank's buffer, returns its IPC handle
+ *   m3hip_xch_open    handles of all ranks in rank order (this rank's own entry is ignored); from here on
+ *                     m3hip_reweight / m3hip_step exchange through the buffers instead of RCCL
+ * A peer that never pushes (a dead rank) is reported after 2 s as M3HIP_ECOMM by m3hip_get_likelihood / m3hip_step;
+ * nothing on the device waits for ever.  The reference has no counterpart (one device: Manager/gpuUtils.cu:71). */
+#define M3HIP_XCH_HANDLE_BYTES 64
+int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out /* M3HIP_XCH_HANDLE_BYTES */);
+int m3hip_xch_open(m3hip_handle h, const void* handles /* n_ranks x M3HIP_XCH_HANDLE_BYTES */);
+int m3hip_xch_destroy(m3hip_handle h);
 int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n_checked);
 
 /* ------------------------------------------------------------------------------------

@@ -246,6 +246,16 @@ struct m3hip_ctx {
   double validate_max_rel = 0;
   uint64_t validate_count = 0;
   int rank = 0, n_ranks = 1;
+  // one-shot exchange (m3hip_xch_*): own buffer xch[2][N][slot] in fine-grained device memory, the peers' buffers mapped
+  // through IPC, the slots this rank pushes into, the step counter and the time-out word
+  double* xch_own = nullptr;
+  std::vector<void*> xch_peer;     // [N] base of every rank's buffer as mapped here (own: xch_own)
+  double** d_xch_targets = nullptr;  // [2][N] device array: slot [parity][rank] of every rank's buffer
+  int xch_ranks = 0, xch_rank = 0, xch_slot = 0;  // slot: doubles per slot (2 * n_bins + 2)
+  bool xch_active = false;
+  uint64_t xch_step = 0;
+  uint64_t* h_xch_status = nullptr;  // mapped pinned host word (0: fine; else the step whose tickets did not arrive)
+  uint64_t* d_xch_status = nullptr;
 
   // timing
   int timing = 0;           // 0: off, N: bracket every N-th launch with hipEvents
@@ -579,6 +589,7 @@ int m3hip_destroy(m3hip_handle h) try {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   m3hip_comm_destroy(h);
+  m3hip_xch_destroy(h);
   free_monolith(h);
   for (int i = 0; i < kRing; ++i) {
     if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
@@ -1992,7 +2003,22 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   }
   if (timed && (n_tiles || n_bricks)) h->pending = 0;
   HIPCHK(h, hipGetLastError());
-  if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
+  if (h->xch_active) {
+    // one-shot exchange: fold, push this rank's [mc | w2] into every rank's buffer, pull the rank-ordered sum of the N slots
+    if (h->n_bins * 2 + 2 != h->xch_slot) return fail(h, M3HIP_ESTATE, "reweight: the bin space changed after m3hip_xch_create");
+    const bool with_w2 = h->first_w2;
+    const bool parked = with_w2 && h->hist_rep > 1;
+    if (h->hist_rep > 1) launch_fold_hist(h->d_hist, h->hist_rep, h->n_bins, with_w2 ? 1 : 0, parked ? 1 : 0, h->stream);
+    if (with_w2) h->w2_spread = false;
+    // the message always has the slot's layout [mc | w2]; w2's half is only meaningful (and only used) while it accumulates
+    const int n_msg = h->n_bins * (with_w2 ? 2 : 1);
+    const uint64_t step = ++h->xch_step;
+    launch_xch_push(h->d_hist, n_msg, h->d_xch_targets + size_t(step & 1) * h->xch_ranks, h->xch_ranks, h->xch_slot, step, h->stream);
+    launch_xch_pull(h->d_hist, n_msg, h->xch_own + size_t(step & 1) * h->xch_ranks * h->xch_slot, h->xch_ranks, h->xch_slot, step,
+                    h->d_xch_status, h->stream);
+    if (parked) launch_unpark_w2(h->d_hist, h->hist_rep, h->n_bins, h->stream);
+    h->gap_pending = timed && (n_tiles || n_bricks);
+  } else if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
     // Fold the flush replicas first: the message is n_bins doubles (1.6 KB at 200 bins).  While w2 is still being
     // accumulated it travels in the SAME all-reduce: the fold parks its sum right behind mc's (in mc's second replica,
     // which the fold has just emptied), one call moves [mc | w2], and k_unpark_w2 puts it back where k_llh looks for it.
@@ -2067,6 +2093,11 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   // HIP command list only grows and a later launch stalls for ~1 ms when it has to be trimmed.
   (void)hipStreamQuery(h->stream);
   h->ticket_done = h->ticket;  // everything submitted before k_llh has completed (stream order)
+  if (h->xch_active && h->h_xch_status && *h->h_xch_status) {
+    const uint64_t late = *h->h_xch_status;
+    *h->h_xch_status = 0;
+    return fail(h, M3HIP_ECOMM, "one-shot exchange: a peer's bin vector of step " + std::to_string(late) + " did not arrive within 2 s");
+  }
   const double t_c = now_s();
   h->host_abs[1] = t_c;
   collect_timing(h);
@@ -2216,6 +2247,90 @@ int m3hip_comm_destroy(m3hip_handle h) try {
   h->gather_cap = 0;
   h->rank = 0;
   h->n_ranks = 1;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+/* ---------------------------------------------------------------- one-shot exchange */
+
+int m3hip_xch_destroy(m3hip_handle h) try {
+  if (!h) return M3HIP_EINVAL;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int r = 0; r < int(h->xch_peer.size()); ++r)
+    if (h->xch_peer[r] && h->xch_peer[r] != (void*)h->xch_own) (void)hipIpcCloseMemHandle(h->xch_peer[r]);
+  h->xch_peer.clear();
+  if (h->xch_own) (void)hipFree(h->xch_own);
+  h->xch_own = nullptr;
+  if (h->d_xch_targets) (void)hipFree(h->d_xch_targets);
+  h->d_xch_targets = nullptr;
+  if (h->h_xch_status) (void)hipHostFree(h->h_xch_status);
+  h->h_xch_status = h->d_xch_status = nullptr;
+  h->xch_active = false;
+  h->xch_ranks = h->xch_rank = h->xch_slot = 0;
+  h->xch_step = 0;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) try {
+  if (!h || !handle_out) return M3HIP_EINVAL;
+  if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(h, M3HIP_EINVAL, "xch_create: bad rank / n_ranks");
+  if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "xch_create before set_binning (the slots are sized by the bin space)");
+  static_assert(sizeof(hipIpcMemHandle_t) <= M3HIP_XCH_HANDLE_BYTES, "IPC handle size");
+  HIPCHK(h, hipSetDevice(h->device));
+  m3hip_xch_destroy(h);
+  h->xch_ranks = n_ranks;
+  h->xch_rank = rank;
+  h->xch_slot = 2 * h->n_bins + 2;
+  const size_t bytes = sizeof(double) * 2 * size_t(n_ranks) * size_t(h->xch_slot);
+  // fine-grained: a peer's stores must become visible INSIDE a running kernel (coarse-grained memory only promises
+  // visibility at kernel boundaries)
+  hipError_t e = hipExtMallocWithFlags((void**)&h->xch_own, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { h->xch_own = nullptr; return fail(h, M3HIP_EHIP, std::string("xch_create: fine-grained allocation: ") + hipGetErrorString(e)); }
+  HIPCHK(h, hipMemset(h->xch_own, 0, bytes));  // tickets start at 0, steps at 1
+  HIPCHK(h, hipDeviceSynchronize());
+  hipIpcMemHandle_t ipc;
+  e = hipIpcGetMemHandle(&ipc, h->xch_own);
+  if (e != hipSuccess) {
+    const std::string why = std::string("xch_create: hipIpcGetMemHandle: ") + hipGetErrorString(e);
+    m3hip_xch_destroy(h);
+    return fail(h, M3HIP_ECOMM, why);
+  }
+  memset(handle_out, 0, M3HIP_XCH_HANDLE_BYTES);
+  memcpy(handle_out, &ipc, sizeof(ipc));
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_xch_open(m3hip_handle h, const void* handles) try {
+  if (!h || !handles) return M3HIP_EINVAL;
+  if (!h->xch_own) return fail(h, M3HIP_ESTATE, "xch_open before xch_create");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int N = h->xch_ranks;
+  h->xch_peer.assign(size_t(N), nullptr);
+  for (int r = 0; r < N; ++r) {
+    if (r == h->xch_rank) { h->xch_peer[r] = h->xch_own; continue; }
+    hipIpcMemHandle_t ipc;
+    memcpy(&ipc, static_cast<const char*>(handles) + size_t(r) * M3HIP_XCH_HANDLE_BYTES, sizeof(ipc));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      const std::string why = "xch_open: hipIpcOpenMemHandle of rank " + std::to_string(r) + ": " + hipGetErrorString(e);
+      m3hip_xch_destroy(h);
+      return fail(h, M3HIP_ECOMM, why);
+    }
+    h->xch_peer[r] = p;
+  }
+  // slot [parity][this rank] of every rank's buffer
+  std::vector<double*> tg(size_t(2) * N);
+  for (int par = 0; par < 2; ++par)
+    for (int r = 0; r < N; ++r)
+      tg[size_t(par) * N + r] = static_cast<double*>(h->xch_peer[r]) + (size_t(par) * N + size_t(h->xch_rank)) * size_t(h->xch_slot);
+  HIPCHK(h, hipMalloc((void**)&h->d_xch_targets, sizeof(double*) * tg.size()));
+  HIPCHK(h, hipMemcpy(h->d_xch_targets, tg.data(), sizeof(double*) * tg.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_xch_status, sizeof(uint64_t), hipHostMallocMapped));
+  *h->h_xch_status = 0;
+  HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_xch_status, h->h_xch_status, 0));
+  h->xch_step = 0;
+  h->xch_active = true;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

@@ -110,6 +110,21 @@ class Engine:
     def comm_destroy(self):
         self._chk(self.lib.m3hip_comm_destroy(self.h))
 
+    def xch_create(self, rank: int, n_ranks: int) -> bytes:
+        """one-shot exchange: allocate this rank's buffer, return its IPC handle (to be all-gathered by the caller)"""
+        buf = C.create_string_buffer(capi.XCH_HANDLE_BYTES)
+        self._chk(self.lib.m3hip_xch_create(self.h, rank, n_ranks, buf))
+        return buf.raw
+
+    def xch_open(self, handles):
+        """handles of all ranks in rank order; switches the engine's exchange to the one-shot form"""
+        blob = b"".join(handles)
+        assert len(blob) % capi.XCH_HANDLE_BYTES == 0
+        self._chk(self.lib.m3hip_xch_open(self.h, C.c_char_p(blob)))
+
+    def xch_destroy(self):
+        self._chk(self.lib.m3hip_xch_destroy(self.h))
+
     def comm_set_validate(self, on=True):
         self._chk(self.lib.m3hip_comm_set_validate(self.h, int(on)))
 

@@ -1,9 +1,12 @@
-"""The in-library exchange (m3hip_comm_init: k_fold_hist -> ONE ncclAllReduce of [mc | w2] -> k_unpark_w2) on the GPU.
+"""The in-library exchanges on the GPU: m3hip_comm_init (k_fold_hist -> ONE ncclAllReduce of [mc | w2] -> k_unpark_w2) and the
+one-shot form m3hip_xch_* (k_fold_hist -> every rank stores its vector into every rank's buffer -> rank-ordered sum).
 
-One rank: the whole code path, including the w2 parking while w2 accumulates and the host-side validator.
-Two ranks: two processes, each with its own engine and event shard, on the ONE card of the test box.  RCCL may refuse
-two ranks on one device (NCCL's "duplicate GPU" check); the test then skips with RCCL's message -- the multi-card run is
-the driver's -- but where it is allowed this is a real two-rank all-reduce through the library."""
+One rank: the whole RCCL code path, including the w2 parking while w2 accumulates and the host-side validator.
+Two ranks: two processes, each with its own engine and event shard, on the ONE card of the test box.  RCCL refuses two
+ranks on one device (NCCL's "duplicate GPU" check): that test skips with RCCL's message -- the multi-card run is the
+driver's.  The one-shot exchange needs only IPC-mapped memory, which two processes on one card have: there the engine's
+N = 2 logic (w2 in the same message while it accumulates, the first_w2 transition, the replica fold, the parities) runs
+on a device."""
 import os
 import subprocess
 import sys
@@ -54,45 +57,55 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import numpy as np
 from mach3_amd import synth, dist as m3dist
 from mach3_amd.engine import build_from_synth
-rank, world, tmp = int(sys.argv[1]), 2, sys.argv[2]
+rank, world, tmp, mode, update_w2 = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3], sys.argv[4] == "1"
 spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
 e0, e1 = m3dist.shard_ranges(spec.n_events, world)[rank]
 eng, mono, sh, par = build_from_synth(spec, device_id=0, event_range=(e0, e1))
-uid_file = os.path.join(tmp, "uid")
-if rank == 0:
-    uid = eng.comm_unique_id()
-    open(uid_file + ".tmp", "wb").write(uid); os.rename(uid_file + ".tmp", uid_file)
-else:
-    t0 = time.time()
-    while not os.path.exists(uid_file):
+sh.SetTestStatistic(spec.test_statistic, update_w2)
+
+def publish(name, blob):
+    f = os.path.join(tmp, name)
+    open(f + ".tmp", "wb").write(blob); os.rename(f + ".tmp", f)
+
+def fetch(name):
+    f, t0 = os.path.join(tmp, name), time.time()
+    while not os.path.exists(f):
         time.sleep(0.05)
         assert time.time() - t0 < 60
-    uid = open(uid_file, "rb").read()
+    return open(f, "rb").read()
+
 try:
-    eng.comm_init(uid, rank, world)
+    if mode == "rccl":
+        if rank == 0:
+            publish("uid", eng.comm_unique_id())
+        eng.comm_init(fetch("uid"), rank, world)
+        eng.comm_set_validate(True)
+    else:  # one-shot exchange: the 64-byte IPC handles travel through files here (any transport will do)
+        publish(f"handle{{rank}}", eng.xch_create(rank, world))
+        eng.xch_open([fetch(f"handle{{r}}") for r in range(world)])
 except Exception as e:
     open(os.path.join(tmp, f"refused{{rank}}"), "w").write(str(e))
     sys.exit(0)
-eng.comm_set_validate(True)
 out = []
-sh.Reweight(); data = sh.GetMCArray().copy(); sh.AddData(data)
-for lap in (1, 2, 3):
+sh.Reweight(); data = sh.GetMCArray().copy(); w2_first = sh.GetW2Array().copy(); sh.AddData(data)
+for lap in (1, 2, 3, 4, 5):
     par[:] = synth.params(spec, lap)
     llh = sh.Step()
     out.append((llh, sh.GetMCArray().copy(), sh.GetW2Array().copy()))
-rel, n = eng.comm_last_validation()
+rel, n = eng.comm_last_validation() if mode == "rccl" else (0.0, 99)
 np.savez(os.path.join(tmp, f"rank{{rank}}.npz"), llh=[o[0] for o in out], mc=np.stack([o[1] for o in out]), w2=np.stack([o[2] for o in out]),
-         data=data, rel=rel, n=n)
+         data=data, w2_first=w2_first, rel=rel, n=n)
 eng.close()
 """
 
 
-def test_two_ranks_all_reduce_matches_unsharded():
+def _two_ranks(mode, update_w2):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         open(script, "w").write(_WORKER.format(root=ROOT))
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs = [subprocess.Popen([sys.executable, script, str(r), tmp], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
+        procs = [subprocess.Popen([sys.executable, script, str(r), tmp, mode, "1" if update_w2 else "0"], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in (0, 1)]
         outs = []
         for p in procs:
             try:
@@ -100,24 +113,86 @@ def test_two_ranks_all_reduce_matches_unsharded():
             except subprocess.TimeoutExpired:
                 for q in procs:
                     q.kill()
-                pytest.fail("two-rank RCCL workers timed out")
+                pytest.fail(f"two-rank {mode} workers timed out")
         refused = [f for f in os.listdir(tmp) if f.startswith("refused")]
         if refused:
-            pytest.skip("RCCL refuses two ranks on one device: " + open(os.path.join(tmp, refused[0])).read()[:200])
+            why = open(os.path.join(tmp, refused[0])).read()[:300]
+            if mode == "rccl":
+                pytest.skip("RCCL refuses two ranks on one device: " + why)
+            pytest.fail("the one-shot exchange could not be set up: " + why)
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
         r0, r1 = (np.load(os.path.join(tmp, f"rank{r}.npz")) for r in (0, 1))
-        # every rank holds the same all-reduced vectors and the same likelihood
+        # every rank holds the same exchanged vectors and the same likelihood (the one-shot sum is rank-ordered: bit-identical)
         assert np.array_equal(r0["mc"], r1["mc"]) and np.array_equal(r0["w2"], r1["w2"]) and np.array_equal(r0["llh"], r1["llh"])
+        assert np.array_equal(r0["data"], r1["data"]) and np.array_equal(r0["w2_first"], r1["w2_first"])
         assert r0["rel"] <= 1e-15 and r0["n"] >= 4
         # ... equal to one engine over the whole sample
         spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
         eng, mono, sh, par = build_from_synth(spec, device_id=0)
+        sh.SetTestStatistic(spec.test_statistic, update_w2)
         sh.Reweight()
-        assert np.allclose(sh.GetMCArray(), r0["data"], rtol=1e-12)
+        assert np.allclose(sh.GetMCArray(), r0["data"], rtol=1e-12) and np.allclose(sh.GetW2Array(), r0["w2_first"], rtol=1e-12)
         sh.AddData(r0["data"])
-        for i, lap in enumerate((1, 2, 3)):
+        for i, lap in enumerate((1, 2, 3, 4, 5)):
             par[:] = synth.params(spec, lap)
             llh = sh.Step()
             assert np.allclose(sh.GetMCArray(), r0["mc"][i], rtol=1e-12) and np.allclose(sh.GetW2Array(), r0["w2"][i], rtol=1e-12)
             assert llh == pytest.approx(float(r0["llh"][i]), rel=1e-9)
+            if not update_w2:
+                assert np.array_equal(r0["w2"][i], r0["w2_first"])   # frozen after the first Reweight, on every rank
         eng.close()
+
+
+def test_two_ranks_all_reduce_matches_unsharded():
+    _two_ranks("rccl", False)
+
+
+@pytest.mark.parametrize("update_w2", [False, True])
+def test_two_ranks_one_shot_exchange_matches_unsharded(update_w2):
+    """two processes on one card through m3hip_xch_*: w2 travels with mc while it accumulates (first Reweight, or every one
+    with UpdateW2), then the message shrinks to mc alone"""
+    _two_ranks("oneshot", update_w2)
+
+
+_SILENT_PEER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+from mach3_amd import synth
+from mach3_amd.engine import build_from_synth
+tmp = sys.argv[1]
+spec = synth.CONFIGS["c3"].scaled(3000, n_params=32)
+eng, mono, sh, par = build_from_synth(spec, device_id=0)
+f = os.path.join(tmp, "handle1")
+open(f + ".tmp", "wb").write(eng.xch_create(1, 2)); os.rename(f + ".tmp", f)
+t0 = time.time()
+while not os.path.exists(os.path.join(tmp, "done")) and time.time() - t0 < 90:
+    time.sleep(0.1)            # owns a buffer, never pushes
+eng.close()
+"""
+
+
+def test_one_shot_exchange_reports_a_missing_peer(fresh_engine):
+    """a rank whose peer never pushes gets M3HIP_ECOMM after the time-out instead of a hung device"""
+    import time
+    spec = synth.CONFIGS["c3"].scaled(3000, n_params=32)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "peer.py")
+        open(script, "w").write(_SILENT_PEER.format(root=ROOT))
+        peer = subprocess.Popen([sys.executable, script, tmp], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        try:
+            h0 = eng.xch_create(0, 2)
+            t0 = time.time()
+            while not os.path.exists(os.path.join(tmp, "handle1")):
+                time.sleep(0.05)
+                assert time.time() - t0 < 80 and peer.poll() is None, peer.stdout.read().decode() if peer.poll() is not None else "peer too slow"
+            eng.xch_open([h0, open(os.path.join(tmp, "handle1"), "rb").read()])
+            with pytest.raises(capi.M3HipError, match="did not arrive"):
+                sh.Step()
+            eng.xch_destroy()
+        finally:
+            open(os.path.join(tmp, "done"), "w").write("x")
+            peer.wait(timeout=60)
+    sh.Reweight()                   # back to the one-rank path
+    assert np.isfinite(sh.GetLikelihood())
