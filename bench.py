@@ -293,15 +293,74 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         t[rank] = k_ms
         dist.all_reduce(t)
         k_all = [float(x) for x in t.cpu()]
+    oneshot = None
+    if in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
+        oneshot = oneshot_leg(eng, step, rank, n_ranks, dist, torch, args)
     check = None
     if args.check:  # LLH of a few laps, for the comparison with a one-rank run of the same sample
         check = []
         for i in range(3):
             check.append(step(1000 + i))
-    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val,
+    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=oneshot,
                comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all)
     eng.close()
     return out
+
+
+def oneshot_leg(eng, step, rank, n_ranks, dist, torch, args):
+    """After the timed region of an N > 1 (or rehearsal) run: the same steps once more through the ONE-SHOT exchange
+    (m3hip_xch_*: every rank stores its bin vector into every rank's IPC-mapped buffer, rank-ordered sum) -- its
+    likelihoods against the RCCL path's on the same laps, its step time and the time it adds between the reweight kernel
+    and the bin likelihood.  Reported under `extra`, never as `value`; any failure is reported as text (a peer that does
+    not push times out after 2 s on the device, nothing hangs)."""
+    res = {"exchange": "one-shot peer stores into IPC-mapped fine-grained buffers + rank-ordered sum (m3hip_xch_*)"}
+    try:
+        laps = [5000 + i for i in range(3)]
+        ref = [step(i) for i in laps]                      # through RCCL
+        ok, hdl = 1.0, b""
+        try:
+            hdl = eng.xch_create(rank, n_ranks)
+        except Exception as e:                             # every rank still takes part in the collectives below
+            ok, res["error"] = 0.0, f"rank {rank}: {e}"
+        flag = torch.tensor([ok], device="cuda")
+        handles = [hdl]
+        if dist is not None and n_ranks > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            handles = [None] * n_ranks
+            dist.all_gather_object(handles, hdl)
+        if float(flag.item()) <= 0:
+            res.setdefault("error", "m3hip_xch_create failed on another rank")
+            eng.xch_destroy()
+            return res
+        eng.xch_open(handles)
+        got = [step(i) for i in laps]
+        res["llh_max_rel_diff_vs_rccl"] = max(abs(a - b) / max(abs(b), 1.0) for a, b in zip(got, ref))
+        n = max(10, min(args.steps, 100))
+        eng.timing_enable(EVENT_EVERY)
+        eng.timing_reset()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(6000 + i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        gap_ms, gap_n = eng.timing_read(2)
+        eng.timing_enable(False)
+        res.update({"steps": n, "ms_per_step": 1e3 * el / n, "steps_per_s": n / el, "comm_us": 1e3 * gap_ms if gap_n else None,
+                    "ok": bool(res["llh_max_rel_diff_vs_rccl"] <= 1e-9)})
+    except Exception as e:
+        res["error"] = f"rank {rank}: {e}"
+    try:
+        eng.xch_destroy()
+    except Exception:
+        pass
+    return res
 
 
 def kernel_name(info):
@@ -450,6 +509,8 @@ def main():
             out["config"]["comm_validated_steps"] = m["comm_val"]["validated_steps"]
             out["config"]["comm_max_rel"] = m["comm_val"]["max_rel"]
             out["config"]["comm_us"] = m["comm_us"]
+        if m.get("oneshot") is not None:
+            out.setdefault("extra", {})["oneshot_exchange"] = m["oneshot"]
         if len(m["k_all"]) > 1:
             out["roofline"]["avg_kernel_ms_by_rank"] = {"min": min(m["k_all"]), "max": max(m["k_all"])}
         if check is not None:
@@ -467,10 +528,10 @@ def main():
                 a2.spinup_seconds = min(args.spinup_seconds, 0.5)
                 c2 = synth.CONFIGS["c2"]
                 m2 = measure(c2, 0, 1, local_rank, a2, None, torch, False)
-                out["extra"] = {"configs[1]": {"workload": workload_text(c2, c2, 1), "value": args.steps / m2["el"], "unit": "steps/s",
-                                               "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}}
+                out.setdefault("extra", {})["configs[1]"] = {"workload": workload_text(c2, c2, 1), "value": args.steps / m2["el"], "unit": "steps/s",
+                                               "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}
             except Exception as e:
-                out["extra"] = {"configs[1]": {"failed": str(e)}}
+                out.setdefault("extra", {})["configs[1]"] = {"failed": str(e)}
         print(json.dumps(out), file=json_out, flush=True)
         if check is not None and not check["ok"]:
             raise SystemExit(4)

@@ -9,8 +9,10 @@
 //   MCMCBase / MR2T2       Fitters/MCMCBase.cpp:32-216, Fitters/MR2T2.cpp:11-115
 //   DelayedMR2T2           Fitters/DelayedMR2T2.cpp:95-235 (delayed rejection, DRAM acceptance)
 //
-// Not here: YAML configuration, ROOT output trees (steps are kept in memory), PCA, parameter
-// flips / circular bounds, tunes, Robbins-Monro scaling, block-wise adaption, multi-chain tools.
+// Also here: the two special proposals (circular bounds and parameter flips, EnableCircularBounds / EnableFlip), fixed
+// parameters, flat priors, simulated annealing.
+// Not here: YAML configuration, ROOT output trees (steps are kept in memory), PCA, tunes, Robbins-Monro scaling,
+// block-wise adaption, multi-chain tools.
 #pragma once
 
 #include <algorithm>
@@ -268,13 +270,19 @@ M3_OMP(omp simd)
   }
 
   /// throw matrix -> its lower Cholesky factor (ref: SetThrowMatrix, ParameterHandlerBase.cpp:1140-1200).  A matrix that
-  /// cannot be decomposed gets 1e-9 added to its diagonal until it can, as M3::MakeMatrixPosDef does
-  /// (Parameters/ParameterHandlerUtils.h:512-545; an adaptive covariance from fewer steps than parameters is singular).
+  /// cannot be decomposed gets its diagonal shifted until it can, as M3::MakeMatrixPosDef does
+  /// (Parameters/ParameterHandlerUtils.h:512-545; an adaptive covariance from fewer steps than parameters is singular):
+  /// the reference's steps of 1e-9 for the first 64 attempts, then doubling, up to the reference's total of 1e-4
+  /// (1e5 steps of 1e-9 there; at 1 040 parameters one attempt is an O(n^3) factorisation of ~0.2 s, so the linear walk
+  /// could take hours).  A non-finite entry can never be repaired by a shift: refused at once.
   void SetThrowMatrix(const std::vector<double>& cov) {
     std::vector<double> L(size_t(_fNumPar) * _fNumPar, 0.0);
-    constexpr int MaxAttempts = 100000;
+    for (int i = 0; i < _fNumPar; ++i)
+      for (int j = 0; j <= i; ++j)
+        if (!std::isfinite(cov[size_t(i) * _fNumPar + j])) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix has a non-finite entry");
+    constexpr double MaxShift = 1e-4;
     double shift = 0.0;
-    for (int attempt = 0;; ++attempt, shift += 1e-9) {
+    for (int attempt = 0;; ++attempt, shift = attempt <= 64 ? shift + 1e-9 : 2 * shift) {
       bool ok = true;
       for (int i = 0; i < _fNumPar && ok; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -294,7 +302,7 @@ M3_OMP(omp simd reduction(+ : dot))
           }
         }
       if (ok) break;
-      if (attempt + 1 >= MaxAttempts) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
+      if (shift >= MaxShift) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
     }
     throwMatrixCholDecomp = L;
     throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)

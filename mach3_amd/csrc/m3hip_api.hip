@@ -17,7 +17,25 @@
 #include "../../include/m3hip.h"
 #include "m3hip_kernels.h"
 
-#include <rccl/rccl.h>  // types and enum values only: the library itself is loaded with dlopen
+// RCCL: types and enum values only -- the library itself is loaded with dlopen.  A build host without the RCCL development
+// headers (single-GPU installs) gets the handful of declarations the loader needs, written out from RCCL's public ABI.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclAllGather(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 #include "m3hip_layout.h"
 
 using namespace m3hip;
@@ -58,6 +76,7 @@ struct Rccl {
       *err = "librccl lacks nccl* symbols";
       dlclose(lib);
       lib = nullptr;
+      GetUniqueId = nullptr; CommInitRank = nullptr; AllReduce = nullptr; AllGather = nullptr; CommDestroy = nullptr; GetErrorString = nullptr;
       return false;
     }
     return true;
@@ -571,6 +590,12 @@ int m3hip_create(int device_id, m3hip_handle* out) try {
     return fail(nullptr, M3HIP_EHIP, std::string("no HIP device available (") + hipGetErrorString(e) +
                                          "); this engine has no CPU fallback");
   if (device_id < 0 || device_id >= n) return fail(nullptr, M3HIP_EINVAL, "device_id out of range");
+  {  // the library's code objects and its LDS budget (two 1024-lane workgroups of up to 66 KB per CU) are gfx950's
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(nullptr, M3HIP_EHIP, std::string("device ") + std::to_string(device_id) + " is " + prop.gcnArchName +
+                                           ": this library is built for gfx950 (MI355X) only; this engine has no CPU fallback");
+  }
   m3hip_ctx* h = new m3hip_ctx();
   h->device = device_id;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -747,6 +772,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
+  { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
   if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->expect_events);
   const int G = h->brick_groups;
@@ -902,7 +928,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     bd.n_dict = uint32_t(plan.tf1_dict.size());
     bd.spl_last_off = bh.n_spl_f4 ? uint32_t((bh.n_spl_f4 - 1) * 16) : 0u;
     bd.pad_[0] = bh.groups;
-    bd.pad_[1] = 0;
+    bd.pad_[1] = bh.tf1_sorted ? 1u : 0u;
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;
@@ -1737,6 +1763,8 @@ int m3hip_set_weight_table(m3hip_handle h, int slot, const float* table, uint64_
   if (n != x.n_tab) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     dev_free(x.d_tab); x.d_tab = nullptr;
+    x.n_tab = 0;  // the size follows the buffers: an allocation that fails below leaves an empty table, not a stale size
+    h->extras_dirty = true;
     for (int i = 0; i < 2; ++i) {
       if (x.h_stage[i]) (void)hipHostFree(x.h_stage[i]);
       x.h_stage[i] = nullptr;
@@ -2413,6 +2441,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
+  { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err, choose_brick_groups(in, 0))) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
   sizes[0] = plan.tiles.size();
   sizes[1] = plan.spl_float4;

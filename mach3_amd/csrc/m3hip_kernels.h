@@ -54,7 +54,7 @@ struct BrickDev {
   uint32_t st1[4];            // the header block
   uint32_t n_dict;
   uint32_t spl_last_off;      // byte offset of the spline store's last quad (idle lanes' offsets are clamped to it)
-  uint32_t pad_[2];
+  uint32_t pad_[2];           // [0] G of the brick's format, [1] 1: the TF1 lane-slots are sorted by code count (sigma in use)
 };
 
 // ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307
@@ -280,7 +280,7 @@ void launch_xch_push(const double* src, int n_msg, double* const* targets, int n
 void launch_xch_pull(double* dst, int n_msg, const double* slots, int n_ranks, int slot_doubles, uint64_t step, uint64_t* status, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2, hipStream_t s);
 void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s);
-// deterministic mode: ordered sum of the workgroups' rows into replica 0 (scratch: ceil(n_rows / 64) rows)
+// deterministic mode: ordered sum of the workgroups' rows into replica 0, 32 rows at a time (scratch: ceil(n_rows / 32) rows)
 void launch_fold_partials(const double* partial, int n_rows, int n_bins, int with_w2, double* scratch, double* hist, int hist_rep, hipStream_t s);
 
 }  // namespace m3hip

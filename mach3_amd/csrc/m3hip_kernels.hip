@@ -541,6 +541,12 @@ static_assert(M3_GROUP == kBrickThreads, "lane = event of a slab");
 static_assert(kBrickRPL <= kBrickGrpPerWave, "group entries of a wave");
 static_assert(16 * M3_BRICK_MAX_GROUPS <= M3_STAGE_PAIR_WORDS, "a wave-block's first slot travels in the high half of a pair word");
 static_assert(4 * (M3_STAGE_CAP + kBrickEllSlack) <= 0x8000, "bits 2..14 of a response word are a byte offset into the scatter array");
+// LDS budget: two workgroups per CU (what __launch_bounds__(1024, 8) and the 64-VGPR kernel are tuned for) leave each 80 KB of
+// gfx950's 160 KB.  The static arrays below take 46 KB at any G; the dynamic bin vector of a fill launch is capped at
+// M3_HIST_LDS_MAX_BYTES, so the sum fits whatever the bin space (round 2's [rank][event] scatter array did not leave that room).
+constexpr size_t kBrickStaticLds = sizeof(float) * (M3_STAGE_CAP + kBrickEllSlack) + 8 * 2 * (size_t)kBrickRunSlots + 2 * 2 * 16 * kBrickGrpPerWave +
+                                   2 * 2 * 16 * M3_BRICK_MAX_GROUPS + 4 * (size_t)kBrickHdrWords + 8 * (size_t)kBrickLdsParams + 4 * ((size_t)kBrickLdsParams + 1);
+static_assert(kBrickStaticLds + M3_HIST_LDS_MAX_BYTES <= 80 * 1024, "two brick workgroups per CU: static LDS + the largest LDS bin vector must fit 80 KB");
 // Idle lanes do not branch around their loads (see the note in the kernel): they read a few KB past the list they index.
 // m3hip_api.hip allocates every chunk's stores with this much room behind them.
 static_assert(M3_STORE_SLACK_BYTES >= 2 * M3_STAGE_CAP + 8 * kBrickThreads, "room behind the stores for idle lanes' reads");
@@ -713,12 +719,16 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   const M3_GLOBAL uint32_t* __restrict__ tf1h = words + bd.off_tf1;
   // TF1 bookkeeping of a slab: the code count of the lane's event (a byte) and the wave-block's first slot / first code dword.
   // Slab 0's is requested here, slab h + 1's when slab h begins.
+  // cnt: code count of the lane-slot | the slot's event (relative to the slab) << 16.  The slots of a slab take its events in
+  // order of descending count (m3hip_layout.cpp), so that the events of a wave have about equal counts
   struct Tf1Book { uint32_t cnt, cbase, dbase; };
   auto tf1_book = [&](uint32_t h) -> Tf1Book {
     Tf1Book b;
     uint32_t le = lane;
     asm volatile("" : "+v"(le));  // as in tail_issue_idx: no hoisting of G slabs' addresses
-    b.cnt = *(const M3_GLOBAL uint8_t*)(uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G)) + (1024u * h + le));  // SGPR base + 32-bit offset
+    const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));  // SGPR base + 32-bit offsets
+    b.cnt = *(const M3_GLOBAL uint8_t*)(cb + (1024u * h + le));
+    b.cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * (1024u * h + le))) << 16;
     b.cbase = __builtin_amdgcn_readfirstlane(tf1h[16u * h + wave]);
     b.dbase = __builtin_amdgcn_readfirstlane(tf1h[16u * G + 16u * h + wave]);
     return b;
@@ -815,6 +825,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t code[kBrickTf1Batch / 4];
   bool tf1_on[kBrickTf1Batch / 4];
   uint32_t tf1_cnt = 0, tf1_cbase = 0, tf1_dbase = 0;
+  uint32_t ev_slot = 0;  // the event (relative to its slab) this lane works on from here on: sigma[slot]
   const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
   auto tf1_issue = [&](uint32_t j0, auto nrows_tag) {  // loads of rows j0 .. j0 + N - 1 (nothing here waits)
     constexpr int N = decltype(nrows_tag)::value;
@@ -849,9 +860,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     const ReweightArgs& a = late_args();
     // (the lane number passes through an empty asm: the addresses below must be formed HERE, slab by slab; hoisted to the
     // kernel's top for all G slabs at once they cost more registers than the stage loop leaves, i.e. spills)
-    uint32_t le = lane;
-    asm volatile("" : "+v"(le));
-    le += 1024u * h;
+    uint32_t le = ev_slot + 1024u * h;
     ev_valid = le < bd.n_events;
     ev_own = bd.first_event + (ev_valid ? le : 0u);  // idle lanes shadow the brick's first event
     if (a.perm) ev_own = a.perm[ev_own];  // processing order -> event; kernel-uniform branch: only grouped uploads pay this dependent load
@@ -894,7 +903,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     }
   };
   auto slab_begin = [&]() {  // the slab whose bookkeeping was requested last becomes the current one
-    tf1_cnt = book_nxt.cnt;
+    tf1_cnt = book_nxt.cnt & 0xFFu;
+    ev_slot = book_nxt.cnt >> 16;
     tf1_cbase = book_nxt.cbase;
     tf1_dbase = book_nxt.dbase;
   };
@@ -995,6 +1005,15 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     tail_issue_idx(0);
   }
 
+  // ---- the TSpline3 products change lanes: up to here lane l held event l of every slab, from here on it holds the event of
+  // its lane-slot (sigma).  Through the scatter array, which the stages are done with.
+  const bool resorted = bd.pad_[1] != 0;  // brick-uniform; otherwise sigma is the identity and the products stay where they are
+  if (n_stages > 0 && resorted) {
+    __syncthreads();  // every wave is through its events' products of the last stage
+#pragma unroll
+    for (int h = 0; h < G; ++h) ell[1024 * h + lane] = w[h];
+    __syncthreads();
+  }
   // ---- slab after slab: the events' TF1 rows, then CalcWeightTotal and the fill.  The next slab's first rows and indices
   // are requested once this slab's tail is through (holding 16 rows in flight across the tail costs it its registers).
 #pragma unroll
@@ -1005,6 +1024,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if (G > 1 && h == 1) wh = w[1 % G];
     if (G > 2 && h == 2) wh = w[2 % G];
     if (G > 2 && h == 3) wh = w[3 % G];
+    if (n_stages > 0 && resorted) wh = ell[1024u * h + ev_slot];
     if (any_tf1) {
       uint32_t kd4 = 0;  // 4 * (1 + position in the dictionary)
       auto tf1_rows = [&](auto nrows_tag) {
@@ -1465,7 +1485,7 @@ void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s) {
   hipLaunchKernelGGL(k_unpark_w2, dim3(1), dim3(256), 0, s, hist, hist_rep, n_bins);
 }
 
-// Deterministic mode: the bin vector as an ordered sum of the workgroups' rows.  Level 1: every 64 consecutive rows into one
+// Deterministic mode: the bin vector as an ordered sum of the workgroups' rows.  Level 1: every 32 (kFoldGroup) consecutive rows into one
 // (thread = bin, rows added in index order); level 2: one workgroup adds the level-1 rows in order into replica 0.  No
 // atomics anywhere: the result depends on nothing but the rows.
 constexpr int kFoldGroup = 32;

@@ -86,7 +86,8 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 // ------------------------------------------------------------------------------------
 // Brick metadata stream (uint32 words, offsets relative to the brick's first word).  G = the engine's brick_groups: a brick
 // holds up to G x 1024 events, local event le = 1024 h + lane (slab h, lane of the workgroup); wave-block b = 16 h + w.
-//   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3] G   [4..7] 0
+//   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3] G   [4] 1: the TF1 lane-slots
+//   take the slab's events in order of descending code count (sigma below), 0: in their own order   [5..7] 0
 //   [8 + 4 s ..]  stage header: n_resp | n_runs << 16 | rows << 26, off_runs, off_pairs, off_resp   (rows = the most
 //             responses one event holds in the stage, <= M3_STAGE_EVENT_MAX)
 //   off_runs  n_runs x {int32 coef_off - start_r, stride | param << 16}.  coef_off: float4 index of the run's first plane
@@ -104,7 +105,10 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 //             l + (2k + 1) * 1024 << 16; block k has one dword for every response of batch 2k (1024, fewer in the last)
 //   off_tf1   [0 .. 16 G)       float2 index (from the brick's TF1 store) of the first slot of wave-block b
 //             [16 G .. 32 G)    word offset (from the brick's first word) of wave-block b's first code dword
-//             [32 G .. 32 G + 256 G)  codes per event, uint8, four per word (local event order)
+//             [32 G .. 32 G + 256 G)  codes per lane-slot, uint8, four per word (slot k = 1024 h + l: what lane l works on in slab h)
+//             [.. + 512 G)      sigma: the slot's event relative to its slab, uint16, two per word.  Inside a slab the events are
+//                               handed to the slots in order of descending code count, so that a wave-block's 64 events have
+//                               about equal counts (a wave executes as many rows as its longest event has codes)
 //             then the code dwords: per wave-block, per four rows 4 q .. 4 q + 3, one dword for every lane with more than 4 q
 //             codes (lanes packed, ascending), byte i = code of row 4 q + i.  A code is the step from the event's previous
 //             TF1 parameter to this one in the chunk's TF1 dictionary (first: from -1); M3_TF1_SKIP steps 254 without a response.
@@ -330,30 +334,66 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
       return false;
     }
   }
+  // Lane-slots of the TF1 phase: slot k = 1024 h + l is what lane l works on in slab h.  Inside a slab the events are handed
+  // to the slots in order of DESCENDING code count (stable), so that the 64 events of a wave-block have about equal counts:
+  // a wave executes as many rows as its longest event has codes, and with the events in their own order every wave of a
+  // config-3 brick ran ~27 rows for 16 codes per event on average.  sigma[k] = the slot's event, relative to its slab.
+  std::vector<uint16_t> sigma(size_t(G) * M3_GROUP);
+  // ... when that pays: the first batch of the kernel's TF1 phase holds 16 rows, every further 8 rows are one more exposed
+  // round trip per wave; with every wave inside the first batch either way (config 5: 8 codes per event) the sorted order only
+  // costs (its events' sample words are gathered instead of streamed, the products change lanes through LDS)
+  bool sort_slots = g_tf1_sort == 1;
+  if (g_tf1_sort == 2) {
+    for (uint32_t le = 0; le < ne && !sort_slots; ++le) sort_slots = codes[le].size() > 16;
+  }
+  auto slot_event = [&](uint32_t k) -> uint32_t { return (k / uint32_t(M3_GROUP)) * uint32_t(M3_GROUP) + sigma[k]; };  // local event (may be >= ne)
+  for (uint32_t h = 0; h < G; ++h) {
+    std::vector<uint16_t> idx(static_cast<size_t>(M3_GROUP), uint16_t(0));
+    for (uint32_t i = 0; i < uint32_t(M3_GROUP); ++i) idx[i] = uint16_t(i);
+    auto key = [&](uint16_t i) -> uint32_t {  // existing events first, longest first
+      const uint32_t le = h * uint32_t(M3_GROUP) + i;
+      return le < ne ? uint32_t(codes[le].size()) + 1u : 0u;
+    };
+    if (sort_slots) std::stable_sort(idx.begin(), idx.end(), [&](uint16_t x, uint16_t y) { return key(x) > key(y); });
+    std::copy(idx.begin(), idx.end(), sigma.begin() + size_t(h) * M3_GROUP);
+  }
+  auto slot_codes = [&](uint32_t k) -> const std::vector<uint8_t>* { const uint32_t le = slot_event(k); return le < ne ? &codes[le] : nullptr; };
   const uint32_t off_tf1 = uint32_t(w.size());
   w[1] = off_tf1;
   const uint32_t n_waves = n_blocks;  // wave-blocks
-  w.resize(w.size() + 2 * n_waves + size_t(G) * M3_GROUP / 4, 0u);
-  for (uint32_t le = 0; le < ne; ++le) w[off_tf1 + 2 * n_waves + le / 4] |= uint32_t(codes[le].size()) << (8 * (le % 4));
+  const uint32_t n_slots = G * uint32_t(M3_GROUP);
+  w.resize(w.size() + 2 * n_waves + size_t(n_slots) / 4 + size_t(n_slots) / 2, 0u);
+  for (uint32_t k = 0; k < n_slots; ++k) {
+    const std::vector<uint8_t>* c = slot_codes(k);
+    w[off_tf1 + 2 * n_waves + k / 4] |= uint32_t(c ? c->size() : 0) << (8 * (k % 4));
+    w[off_tf1 + 2 * n_waves + n_slots / 4 + k / 2] |= uint32_t(sigma[k]) << (16 * (k % 2));
+  }
   uint64_t tf1_f2 = 0;
   for (uint32_t wv = 0; wv < n_waves; ++wv) {
     w[off_tf1 + wv] = uint32_t(tf1_f2);
     w[off_tf1 + n_waves + wv] = uint32_t(w.size());
-    const uint32_t l0 = wv * uint32_t(M3_WAVE), l1 = std::min(ne, l0 + uint32_t(M3_WAVE));
+    const uint32_t k0 = wv * uint32_t(M3_WAVE), k1 = k0 + uint32_t(M3_WAVE);
     size_t rows = 0;
-    for (uint32_t le = l0; le < l1; ++le) rows = std::max(rows, codes[le].size());
+    for (uint32_t k = k0; k < k1; ++k)
+      if (const std::vector<uint8_t>* c = slot_codes(k)) rows = std::max(rows, c->size());
     for (size_t j = 0; j < rows; ++j)
-      for (uint32_t le = l0; le < l1; ++le)
-        if (codes[le].size() > j) { bh->tf1_src.push_back(srcs[le][j]); ++tf1_f2; }
+      for (uint32_t k = k0; k < k1; ++k) {
+        const std::vector<uint8_t>* c = slot_codes(k);
+        if (c && c->size() > j) { bh->tf1_src.push_back(srcs[slot_event(k)][j]); ++tf1_f2; }
+      }
     for (size_t q = 0; 4 * q < rows; ++q)
-      for (uint32_t le = l0; le < l1; ++le)
-        if (codes[le].size() > 4 * q) {
+      for (uint32_t k = k0; k < k1; ++k) {
+        const std::vector<uint8_t>* c = slot_codes(k);
+        if (c && c->size() > 4 * q) {
           uint32_t d = 0;
-          for (size_t i = 0; i < 4 && 4 * q + i < codes[le].size(); ++i) d |= uint32_t(codes[le][4 * q + i]) << (8 * i);
+          for (size_t i = 0; i < 4 && 4 * q + i < c->size(); ++i) d |= uint32_t((*c)[4 * q + i]) << (8 * i);
           w.push_back(d);
         }
+      }
   }
   w[2] = uint32_t(tf1_f2);
+  w[4] = sort_slots ? 1u : 0u;
+  bh->tf1_sorted = sort_slots;
   bh->n_tf1_f2 = tf1_f2;
   while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);  // the next brick's stream starts on a line
   bh->n_words = w.size();
@@ -402,6 +442,7 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
 }  // namespace
 
 double g_pad_min_fill = kPadMinFillDefault;
+int g_tf1_sort = 2;
 
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
                 std::string* err, int brick_groups) {

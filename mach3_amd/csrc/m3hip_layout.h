@@ -98,6 +98,7 @@ struct BrickHost {
   std::vector<uint32_t> tf1_src;   // per TF1 slot (wave-major, jagged rows inside); 0xFFFFFFFF: skip slot -> identity {0,1}
   uint32_t n_stages = 0;           // TSpline3 stages
   uint32_t groups = 1;             // G: the brick spans up to G x M3_GROUP events
+  bool tf1_sorted = false;         // the TF1 lane-slots take the events in order of descending code count
 };
 
 struct ChunkInput {
@@ -139,6 +140,9 @@ struct ChunkPlan {
 // padding off).
 constexpr double kPadMinFillDefault = 0.88;
 extern double g_pad_min_fill;
+// TF1 lane-slots by descending code count: 0 never, 1 always, 2 (default) when an event of the brick has more than 16 codes
+// (M3HIP_TF1_SORT; experiments)
+extern int g_tf1_sort;
 
 // Validates the chunk against (n_params, npts) and sizes the tile store.
 // Returns false and sets err on inconsistent input.

@@ -150,3 +150,12 @@ def test_config5_shard_properties():
     # 16 responses per event and 12 208 groups of 1024 events: the engine lays this shard out in bricks of 2048 events (chunk by chunk)
     assert info.n_params == 1024 and info.brick_groups == 2
     assert info.n_tiles_brick == sum(-(-min(131072, per - a) // 2048) for a in range(0, per, 131072))
+
+
+def test_more_than_1024_parameters_at_mid_size():
+    """the BIGP instantiation of the brick kernel (more spline parameters than its LDS tables hold: {segment, dx} and the TF1
+    parameter values come from global memory) beyond toy size: 150 000 events x 1 536 mixed parameters at occupancy 1/64,
+    two windows bit for bit against the serial oracle, conservation, W2 freeze, shard additivity"""
+    spec = synth.CONFIGS["c5"].scaled(150_000, n_params=1536)
+    info = _check_full_size(spec, 0, spec.n_events, [(0, 3000), (spec.n_events - 2500, spec.n_events)], chunk_events=65536)
+    assert info.n_params == 1536 and info.n_tiles_brick > 0 and info.n_tiles_uniform == 0

@@ -208,32 +208,43 @@ def brick_event_lists(npts, ch, lay, b):
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
             assert (int(np.int32(runs[rn][0])) + int(first_r[rn])) % 8 == 0
-    # TF1: jagged rows per wave-block of 64 events
-    hdr = w[off_tf1: off_tf1 + 32 * G + 256 * G]
-    cnts = hdr[32 * G:].view(np.uint8)
-    assert all(int(c) == 0 for c in cnts[nev:])
+    # TF1: jagged rows per wave-block of 64 lane-slots; slot k = 1024 h + l works on event 1024 h + sigma[k] of the brick
+    n_slots = 1024 * G
+    hdr = w[off_tf1: off_tf1 + 32 * G + n_slots // 4 + n_slots // 2]
+    cnts = hdr[32 * G: 32 * G + n_slots // 4].view(np.uint8)
+    sigma = hdr[32 * G + n_slots // 4:].view(np.uint16).astype(np.int64)
+    ev_of = (np.arange(n_slots) // 1024) * 1024 + sigma
+    for h in range(G):                                  # a permutation of every slab, existing events first, longest first
+        sl = slice(1024 * h, 1024 * (h + 1))
+        assert sorted(sigma[sl]) == list(range(1024))
+        key = [(int(cnts[k]) + 1 if ev_of[k] < nev else 0) for k in range(1024 * h, 1024 * (h + 1))]
+        if int(w[4]):                                   # sorted by code count ...
+            assert key == sorted(key, reverse=True)
+        else:                                           # ... or left in their own order (no event beyond the first batch of 16 rows)
+            assert list(sigma[sl]) == list(range(1024)) and max(key) <= 17
+    assert all(int(cnts[k]) == 0 for k in range(n_slots) if ev_of[k] >= nev)
     slots = 0
     for wv in range(n_blocks):
         cbase, dbase = int(hdr[wv]), int(hdr[16 * G + wv])
-        lanes = [le for le in range(64 * wv, min(nev, 64 * wv + 64))]
-        kd = {le: -1 for le in lanes}
-        rows = max([int(cnts[le]) for le in lanes], default=0)
+        lanes = [k for k in range(64 * wv, 64 * wv + 64) if ev_of[k] < nev]
+        kd = {k: -1 for k in lanes}
+        rows = max([int(cnts[k]) for k in lanes], default=0)
         for j in range(rows):
-            act = [le for le in lanes if int(cnts[le]) > j]
+            act = [k for k in lanes if int(cnts[k]) > j]
             if j % 4 == 0:
                 actq = act
-                codes = {le: int(w[dbase + i]) for i, le in enumerate(actq)}
+                codes = {k: int(w[dbase + i]) for i, k in enumerate(actq)}
                 dbase += len(actq)
-            for i, le in enumerate(act):
-                cd = (codes[le] >> (8 * (j % 4))) & 0xFF
+            for i, k in enumerate(act):
+                cd = (codes[k] >> (8 * (j % 4))) & 0xFF
                 ab = tf1[tf1_off + cbase + i]
                 if cd == TF1_SKIP:
-                    kd[le] += 254
+                    kd[k] += 254
                     assert np.array_equal(ab, np.array([0, 1], np.float32))
                 else:
                     assert cd > 0
-                    kd[le] += cd
-                    out[le].append((int(tdict[kd[le]]), "tf1", ab))
+                    kd[k] += cd
+                    out[int(ev_of[k])].append((int(tdict[kd[k]]), "tf1", ab))
             cbase += len(act)
             slots += len(act)
     assert slots == int(w[2]) == n_f2
