@@ -95,6 +95,7 @@ class SMonolithGPU {
       if (np != 0 && np != n) throw MaCh3Exception(__FILE__, __LINE__, "splines of one parameter differ in their number of knots");
       np = n;
     }
+    M3HIP_CALL(h, m3hip_monolith_expect_events(h, uint64_t(n_events)));  // the total is known here; the engine's streamed upload cannot see it
     M3HIP_CALL(h, m3hip_monolith_begin(h, n_params, spline_size, cpu_spline_handler->coeff_x.data(), npts.data()));
     const uint64_t slice = upload_slice_events();
     for (uint64_t e0 = 0; e0 < uint64_t(n_events); e0 += slice) {

@@ -732,10 +732,12 @@ static int choose_brick_groups(const ChunkInput& in, uint64_t expect_events) {
   uint64_t resp = 0;
   for (uint64_t e = 0; e < in.n_events; ++e) resp += uint64_t(in.npe[2 * e]) + in.npe_tf1[2 * e];
   const double per_event = double(resp) / double(in.n_events);
-  // measured (round 3, scripts/gexp.py): 2048-event bricks are worth +4 % at 16 responses per event (config 5), nothing
-  // at 32 (config 3: what the larger bricks save is lost in the longer tail of the launch); 4096-event bricks lose
-  int g = per_event <= 24.0 ? 2 : 1;
-  while (g > 1 && expect_events / (uint64_t(M3_GROUP) * g) < 4096) g /= 2;  // at least ~8 rounds of workgroups
+  // measured (round 3, scripts/gexp.py, one GPU's share of config 5 -- 16 responses per event, 1.25e7 events): bricks of 1024 /
+  // 2048 / 4096 events stream at 0.542 / 0.566 / 0.586 of the HBM peak (runs four times as long, a quarter of the per-brick
+  // phases); at 32 responses per event (config 3) 0.672 / 0.664 / 0.655: what larger bricks save there is lost in the longer
+  // tail of the launch and the second slab's exposed first round trip
+  int g = per_event <= 24.0 ? 4 : 1;
+  while (g > 1 && expect_events / (uint64_t(M3_GROUP) * g) < 2048) g /= 2;  // at least four rounds of the 512 resident workgroups
   return g;
 }
 

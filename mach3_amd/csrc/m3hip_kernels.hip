@@ -531,7 +531,7 @@ constexpr int kBrickLdsParams = 1024;                              // per-step p
 // a lane past a stage's end works on whatever word follows the stage's list; its run index can be off by up to 64 runs
 constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 64 + 1;
 constexpr int kBrickGrpPerWave = 8;                                // uint16 per wave and stage: one 16-byte LDS read
-constexpr int kBrickTf1Batch = 16;                                 // TF1 rows of the first batch (the registers the quads held)
+constexpr int kBrickTf1BatchMax = 16;                              // TF1 rows of the first batch (the registers the quads held); 12 at G = 4
 constexpr int kBrickTf1Next = 8;                                   // ... of the following ones
 constexpr int kBrickEllSlack = 16;                                 // an event's lane reads up to 16 slots from its first one
 static_assert(M3_STAGE_CAP % kBrickThreads == 0, "a stage is a whole number of responses per lane");
@@ -733,7 +733,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     b.dbase = __builtin_amdgcn_readfirstlane(tf1h[16u * G + 16u * h + wave]);
     return b;
   };
-  Tf1Book book_nxt = tf1_book(0);
+  // G = 1 requests slab 0's bookkeeping here; with more slabs per lane the stage loop has no register for it (one more
+  // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
+  // requested at the top of the last stage instead
+  Tf1Book book_nxt = {0u, 0u, 0u};
+  if (G == 1 || n_stages == 0) book_nxt = tf1_book(0);
   const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 
   // ---- TF1 side (SplineMonolith.cpp:818-825: after the TSpline3s, in the event's parameter order): one batch of rows of
   // the CURRENT slab's wave-block
+  constexpr int kBrickTf1Batch = G == 4 ? 12 : kBrickTf1BatchMax;  // four products live through the slabs leave G = 4 a register short of 16 rows
   float2 ab[kBrickTf1Batch];
   uint32_t code[kBrickTf1Batch / 4];
   bool tf1_on[kBrickTf1Batch / 4];
@@ -958,6 +963,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     const uint32_t h0 = hdr(s).h0;
     const uint32_t n_resp = h0 & 0xFFFFu;
     Meta m_nn;
+    if (LAST && G > 1) book_nxt = tf1_book(0);
     const uint32_t counts = fetch_counts(hdr(s));
     if (!LAST) {
       publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight

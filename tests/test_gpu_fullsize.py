@@ -147,9 +147,9 @@ def test_config5_shard_properties():
     spec = synth.CONFIGS["c5"]
     per = spec.n_events // 8
     info = _check_full_size(spec, 5 * per, 6 * per, [(0, 3000), (per - 2048, per)], laps=(1,), shard_check=False)
-    # 16 responses per event and 12 208 groups of 1024 events: the engine lays this shard out in bricks of 2048 events (chunk by chunk)
-    assert info.n_params == 1024 and info.brick_groups == 2
-    assert info.n_tiles_brick == sum(-(-min(131072, per - a) // 2048) for a in range(0, per, 131072))
+    # 16 responses per event and 12 208 groups of 1024 events: the engine lays this shard out in bricks of 4096 events (chunk by chunk)
+    assert info.n_params == 1024 and info.brick_groups == 4
+    assert info.n_tiles_brick == sum(-(-min(131072, per - a) // 4096) for a in range(0, per, 131072))
 
 
 def test_more_than_1024_parameters_at_mid_size():
