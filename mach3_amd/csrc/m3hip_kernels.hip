@@ -532,7 +532,6 @@ constexpr int kBrickLdsParams = 1024;                              // per-step p
 constexpr int kBrickRunSlots = M3_STAGE_MAX_RUNS + 64 + 1;
 constexpr int kBrickGrpPerWave = 8;                                // uint16 per wave and stage: one 16-byte LDS read
 constexpr int kBrickTf1BatchMax = 16;                              // TF1 rows of the first batch (the registers the quads held); 12 at G = 4
-constexpr int kBrickTf1Next = 8;                                   // ... of the following ones
 constexpr int kBrickEllSlack = 16;                                 // an event's lane reads up to 16 slots from its first one
 static_assert(M3_STAGE_CAP % kBrickThreads == 0, "a stage is a whole number of responses per lane");
 static_assert(kBrickHdrWords <= kBrickThreads, "the stage headers are fetched by one load per lane");
@@ -737,7 +736,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
   // requested at the top of the last stage instead
   Tf1Book book_nxt = {0u, 0u, 0u};
-  if (G == 1 || n_stages == 0) book_nxt = tf1_book(0);
+  if (n_stages == 0) book_nxt = tf1_book(0);
   const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
@@ -958,13 +957,15 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
   // scattered to its slot of the scatter array, and its register reused at once for the next stage's load (LAST: for the
   // first TF1 rows instead); barrier; every event's responses of the stage, ascending parameter = reference order.
+  uint32_t counts_nxt = fetch_counts(StageHdr{bd.st0[0], bd.st0[1], bd.st0[2], bd.st0[3]});
   auto stage = [&](uint32_t s, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     const uint32_t h0 = hdr(s).h0;
     const uint32_t n_resp = h0 & 0xFFFFu;
     Meta m_nn;
-    if (LAST && G > 1) book_nxt = tf1_book(0);
-    const uint32_t counts = fetch_counts(hdr(s));
+    if (LAST) book_nxt = tf1_book(0);
+    const uint32_t counts = counts_nxt;                    // requested a stage ago
+    if (!LAST) counts_nxt = fetch_counts(hdr(s + 1));
     if (!LAST) {
       publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight
       fetch_meta(hdr(s + 2), m_nn);
@@ -1049,6 +1050,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         }
       };
       tf1_rows(std::integral_constant<int, kBrickTf1Batch>{});
+      // further rows in batches of 8 (16 at a time measured 1.6 % slower on config 3: the extra loads of rows nobody has)
+      constexpr int kBrickTf1Next = 8;
       for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Next) {
         tf1_issue(j0, std::integral_constant<int, kBrickTf1Next>{});
         tf1_rows(std::integral_constant<int, kBrickTf1Next>{});
