@@ -25,12 +25,12 @@ HDR0 = 8
 par = synth.params(spec, 1)[: spec.n_params].astype(np.float32)
 xk = cx.reshape(spec.n_params, spec.n_knots)
 seg = np.array([min(max(int(np.searchsorted(xk[p, : npts[p]], par[p], side="left")) - 1, 0), int(npts[p]) - 2) if npts[p] > 1 else 0 for p in range(spec.n_params)])
-tot = dict(quads_used=0, quad_lines=0, tf1_used=0, tf1_lines=0, words=0, resp_words=0, run_tab=0, grp_tab=0, hdr=0, tf1_hdr=0, tf1_codes=0, runs=0, stages=0)
+tot = dict(quads_used=0, quad_lines=0, tf1_used=0, tf1_lines=0, words=0, resp_words=0, run_tab=0, pair_tab=0, stage_counts=0, hdr=0, tf1_hdr=0, tf1_sigma=0, tf1_codes=0, runs=0, stages=0)
 nb = lay["n_bricks"]
 for b in range(nb):
     spl_off, tf1_off, w_off, n_f4, n_f2, nev, e0, nw = [int(v) for v in lay["bdesc"][b]]
     w = words[w_off: w_off + nw]
-    n_stages, off_tf1 = int(w[0]), int(w[1])
+    n_stages, off_tf1, G = int(w[0]), int(w[1]), int(w[3])
     lines = set()
     for s in range(n_stages):
         h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
@@ -54,7 +54,8 @@ for b in range(nb):
                 lines.add(L)
         tot["resp_words"] += 4 * ((n_resp + 1) // 2)
         tot["run_tab"] += 8 * n_runs
-        tot["grp_tab"] += 2 * (5120 // 64)
+        tot["pair_tab"] += 4 * (5120 // 64)
+        tot["stage_counts"] += 512 * G
         tot["runs"] += n_runs
         tot["stages"] += 1
     tot["quad_lines"] += 128 * len(lines)
@@ -62,15 +63,16 @@ for b in range(nb):
     tot["tf1_lines"] += 128 * ((8 * (tf1_off + n_f2) + 127) // 128 - (8 * tf1_off) // 128)
     tot["words"] += 4 * nw
     tot["hdr"] += 4 * (HDR0 + 4 * n_stages)
-    tot["tf1_hdr"] += 4 * (32 + 256)
-    tot["tf1_codes"] += 4 * (nw - off_tf1 - 32 - 256)   # upper bound: to the end of the (128-B padded) stream
+    tot["tf1_hdr"] += 4 * (32 * G + 256 * G)            # wave-block bases + one count byte per lane-slot
+    tot["tf1_sigma"] += 2 * 1024 * G
+    tot["tf1_codes"] += 4 * (nw - off_tf1 - 32 * G - 256 * G - 512 * G)   # upper bound: to the end of the (128-B padded) stream
 S, T = ch["n_splines"], ch["n_tf1"]
 alg = 16 * S + 8 * T + 8 * ev
-sample_side = ev * (4 + 4 + 2 * spec.max_norm_per_event)
+sample_side = ev * 8   # the packed word {bin, osc, <= 3 norm indices}; the three arrays it replaces were 4 + 4 + 2 * slots bytes
 print(f"{cfg} E={ev}: {nb} bricks, S={S} T={T}; per brick (KB): algorithmic {alg / nb / 1e3:.1f}")
-for k in ("quads_used", "quad_lines", "tf1_used", "tf1_lines", "words", "resp_words", "run_tab", "grp_tab", "hdr", "tf1_hdr", "tf1_codes"):
+for k in ("quads_used", "quad_lines", "tf1_used", "tf1_lines", "words", "resp_words", "run_tab", "pair_tab", "stage_counts", "hdr", "tf1_hdr", "tf1_sigma", "tf1_codes"):
     print(f"  {k:12s} {tot[k] / nb / 1e3:8.2f}")
-print(f"  sample side (bin, osc, {spec.max_norm_per_event} norm slots) {sample_side / nb / 1e3:8.2f}")
+print(f"  sample side (packed word)       {sample_side / nb / 1e3:8.2f}")
 total = tot["quad_lines"] + tot["tf1_lines"] + tot["words"] + sample_side
 print(f"  distinct lines in total {total / nb / 1e3:.1f} KB per brick = {total / alg:.3f} x algorithmic; runs per brick {tot['runs'] / nb:.0f}, stages {tot['stages'] / nb:.2f}, "
       f"responses per run {S / max(tot['runs'], 1):.1f}")
