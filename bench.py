@@ -128,7 +128,9 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
         "sample": f"first {n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
                   f"{best['threads']} threads ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
                   f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; arrays first-touched in "
-                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
+                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}; one FULL-SIZE lap of "
+                  f"this build on record (all 1e7 events of configs[2], 16 threads, profiles/r03_cpu_full_c3.log): 161.6 ms = 0.970 of the "
+                  f"event-scaled 3e5-event sample measured in the same process",
         "steps_per_s_by_threads": {str(r["threads"]): r["steps_per_s"] for r in runs},
         "host_cores": cores,
     }

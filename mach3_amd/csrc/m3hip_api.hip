@@ -1934,15 +1934,17 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     ba.par_map = h->d_parmap;
     launch_binned_weights(ba, h->stream);
   }
-  // functional shifts: every event is re-binned from its shifted kinematics, inside the reweight kernels'
-  // epilogue (the float_t = double variant keeps the separate k_find_bins pass)
-  const bool dyn_bins = !h->h_shifts.empty();
-  if (dyn_bins) {
-    if (h->f64) {
-      BinArgs b = make_bin_args(h);
-      b.compute_nominal = 0;
-      launch_find_bins(b, h->stream);
-    }
+  // functional shifts: every event is re-binned from its shifted kinematics -- inside the uniform reweight kernel's epilogue
+  // when the sample has uniform tiles only; as a pass of its own (k_find_bins, then the events' packed words are rebuilt)
+  // when it has bricks or is the float_t = double variant: the brick kernel has no register to spare for the binning cascade
+  // (its fused form spilled 56-90 registers, and a kernel that uses scratch at all is slow out of proportion)
+  const bool dyn_any = !h->h_shifts.empty();
+  const bool dyn_pass = dyn_any && (h->f64 || !h->h_bricks.empty());
+  const bool dyn_bins = dyn_any && !dyn_pass;  // fused
+  if (dyn_pass) {
+    BinArgs b = make_bin_args(h);
+    b.compute_nominal = 0;
+    launch_find_bins(b, h->stream);
   }
   const double t_c = now_s();
 
@@ -1972,9 +1974,9 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   }
   // the brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields
   if (!h->f64 && !h->h_bricks.empty()) {
-    if (dyn_bins) h->evw_dirty = true;  // the fused re-binning rewrites d_bin every step
-    else if (h->evw_dirty) {
-      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->M <= 3 &&
+    if (dyn_pass) h->evw_dirty = true;  // the re-binning pass has just rewritten d_bin
+    if (h->evw_dirty) {
+      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->M <= 3 &&
                   (h->max_norm_idx < 0 || h->max_norm_idx - h->min_norm_idx <= 62) && h->d_bin && h->d_osc;
       if (const char* f = getenv("M3HIP_PACKED_EVENTS")) h->evw_ok = h->evw_ok && f[0] != '0';
       if (h->evw_ok) {
@@ -1989,7 +1991,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;
   }
-  if (!h->f64 && !dyn_bins && h->evw_ok && !h->evw_dirty) {
+  if (!h->f64 && h->evw_ok && !h->evw_dirty) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx < 0 ? 0 : h->min_norm_idx);
   }

@@ -1175,11 +1175,7 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   size_t lds = ((mode & kModeFill) && a.hist_lds) ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
-  if (dyn_bins && (mode & kModeFill)) {
-    if (mode == kModeFill) launch_brick_mode<kModeFill, true>(a, g, lds, k, s);
-    else launch_brick_mode<kModeFill | kModeEval | kModeEventW, true>(a, g, lds, k, s);
-    return;
-  }
+  (void)dyn_bins;  // ragged samples are re-binned by a pass of their own (m3hip_api.hip): no fused form of the brick kernel
   if (mode == kModeEval) launch_brick_mode<kModeEval, false>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill, false>(a, g, lds, k, s);
   else launch_brick_mode<kModeFill | kModeEval | kModeEventW, false>(a, g, lds, k, s);
