@@ -313,52 +313,67 @@ def oneshot_leg(eng, step, rank, n_ranks, dist, torch, args):
     """After the timed region of an N > 1 (or rehearsal) run: the same steps once more through the ONE-SHOT exchange
     (m3hip_xch_*: every rank stores its bin vector into every rank's IPC-mapped buffer, rank-ordered sum) -- its
     likelihoods against the RCCL path's on the same laps, its step time and the time it adds between the reweight kernel
-    and the bin likelihood.  Reported under `extra`, never as `value`; any failure is reported as text (a peer that does
-    not push times out after 2 s on the device, nothing hangs)."""
+    and the bin likelihood.  Reported under `extra`, never as `value`.  Any failure is reported as text: a peer that does
+    not push times out after 2 s on the device (nothing hangs), and the ranks agree after every phase whether all of them
+    are still in it, so that no rank enters a collective the others have left."""
     res = {"exchange": "one-shot peer stores into IPC-mapped fine-grained buffers + rank-ordered sum (m3hip_xch_*)"}
-    try:
-        laps = [5000 + i for i in range(3)]
-        ref = [step(i) for i in laps]                      # through RCCL
-        ok, hdl = 1.0, b""
-        try:
-            hdl = eng.xch_create(rank, n_ranks)
-        except Exception as e:                             # every rank still takes part in the collectives below
-            ok, res["error"] = 0.0, f"rank {rank}: {e}"
-        flag = torch.tensor([ok], device="cuda")
-        handles = [hdl]
+
+    def agree(ok, what):  # every rank calls this the same number of times, whatever happened to it
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
         if dist is not None and n_ranks > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            handles = [None] * n_ranks
-            dist.all_gather_object(handles, hdl)
         if float(flag.item()) <= 0:
-            res.setdefault("error", "m3hip_xch_create failed on another rank")
-            eng.xch_destroy()
-            return res
-        eng.xch_open(handles)
-        got = [step(i) for i in laps]
+            res.setdefault("error", f"{what} failed on another rank")
+            return False
+        return True
+
+    def attempt(what, fn):
+        try:
+            return True, fn()
+        except Exception as e:
+            res["error"] = f"rank {rank}: {what}: {e}"
+            return False, None
+
+    laps = [5000 + i for i in range(3)]
+    ok, ref = attempt("RCCL reference laps", lambda: [step(i) for i in laps])
+    ok, hdl = attempt("m3hip_xch_create", lambda: eng.xch_create(rank, n_ranks)) if ok else (False, None)
+    handles = [hdl if hdl is not None else b""]
+    if dist is not None and n_ranks > 1:
+        handles = [None] * n_ranks
+        dist.all_gather_object(handles, hdl if hdl is not None else b"")
+    alive = agree(ok, "m3hip_xch_create")
+    if alive:
+        ok, _ = attempt("m3hip_xch_open", lambda: eng.xch_open(handles))
+        alive = agree(ok, "m3hip_xch_open")
+    if alive:
+        ok, got = attempt("first steps through the one-shot exchange", lambda: [step(i) for i in laps])
+        alive = agree(ok, "the first steps through the one-shot exchange")
+    if alive:
         res["llh_max_rel_diff_vs_rccl"] = max(abs(a - b) / max(abs(b), 1.0) for a, b in zip(got, ref))
         n = max(10, min(args.steps, 100))
-        eng.timing_enable(EVENT_EVERY)
-        eng.timing_reset()
+
+        def timed():
+            eng.timing_enable(EVENT_EVERY)
+            eng.timing_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                step(6000 + i)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n):
-            step(6000 + i)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        gap_ms, gap_n = eng.timing_read(2)
-        eng.timing_enable(False)
-        res.update({"steps": n, "ms_per_step": 1e3 * el / n, "steps_per_s": n / el, "comm_us": 1e3 * gap_ms if gap_n else None,
-                    "ok": bool(res["llh_max_rel_diff_vs_rccl"] <= 1e-9)})
-    except Exception as e:
-        res["error"] = f"rank {rank}: {e}"
+        ok, el = attempt("timed steps through the one-shot exchange", timed)
+        if agree(ok, "the timed steps through the one-shot exchange"):
+            if dist is not None and n_ranks > 1:
+                t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            gap_ms, gap_n = eng.timing_read(2)
+            res.update({"steps": n, "ms_per_step": 1e3 * el / n, "steps_per_s": n / el, "comm_us": 1e3 * gap_ms if gap_n else None,
+                        "ok": bool(res["llh_max_rel_diff_vs_rccl"] <= 1e-9)})
     try:
+        eng.timing_enable(False)
         eng.xch_destroy()
     except Exception:
         pass
