@@ -275,6 +275,7 @@ struct m3hip_ctx {
   uint64_t xch_step = 0;
   uint64_t* h_xch_status = nullptr;  // mapped pinned host word (0: fine; else the step whose tickets did not arrive)
   uint64_t* d_xch_status = nullptr;
+  unsigned long long* d_xch_pushed = nullptr;  // this rank's finished push blocks (n_ranks per step)
 
   // timing
   int timing = 0;           // 0: off, N: bracket every N-th launch with hipEvents
@@ -2045,9 +2046,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     // the message always has the slot's layout [mc | w2]; w2's half is only meaningful (and only used) while it accumulates
     const int n_msg = h->n_bins * (with_w2 ? 2 : 1);
     const uint64_t step = ++h->xch_step;
-    launch_xch_push(h->d_hist, n_msg, h->d_xch_targets + size_t(step & 1) * h->xch_ranks, h->xch_ranks, h->xch_slot, step, h->stream);
-    launch_xch_pull(h->d_hist, n_msg, h->xch_own + size_t(step & 1) * h->xch_ranks * h->xch_slot, h->xch_ranks, h->xch_slot, step,
-                    h->d_xch_status, h->stream);
+    launch_xch(h->d_hist, h->d_hist, n_msg, h->d_xch_targets + size_t(step & 1) * h->xch_ranks, h->xch_ranks,
+               h->xch_own + size_t(step & 1) * h->xch_ranks * h->xch_slot, h->xch_slot, step, h->d_xch_status, h->d_xch_pushed, h->stream);
     if (parked) launch_unpark_w2(h->d_hist, h->hist_rep, h->n_bins, h->stream);
     h->gap_pending = timed && (n_tiles || n_bricks);
   } else if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
@@ -2297,6 +2297,8 @@ int m3hip_xch_destroy(m3hip_handle h) try {
   h->d_xch_targets = nullptr;
   if (h->h_xch_status) (void)hipHostFree(h->h_xch_status);
   h->h_xch_status = h->d_xch_status = nullptr;
+  if (h->d_xch_pushed) (void)hipFree(h->d_xch_pushed);
+  h->d_xch_pushed = nullptr;
   h->xch_active = false;
   h->xch_ranks = h->xch_rank = h->xch_slot = 0;
   h->xch_step = 0;
@@ -2361,6 +2363,8 @@ int m3hip_xch_open(m3hip_handle h, const void* handles) try {
   HIPCHK(h, hipHostMalloc((void**)&h->h_xch_status, sizeof(uint64_t), hipHostMallocMapped));
   *h->h_xch_status = 0;
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_xch_status, h->h_xch_status, 0));
+  HIPCHK(h, hipMalloc((void**)&h->d_xch_pushed, sizeof(unsigned long long)));
+  HIPCHK(h, hipMemset(h->d_xch_pushed, 0, sizeof(unsigned long long)));
   h->xch_step = 0;
   h->xch_active = true;
   return M3HIP_OK;

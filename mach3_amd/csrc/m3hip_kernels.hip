@@ -1280,31 +1280,42 @@ void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------
 // One-shot exchange ("avoid ring, use ... P2P all-gather + local sum"; the reference has one device only,
 // Manager/gpuUtils.cu:71).  The message is 1.6 - 6.4 KB: a ring all-reduce is 2 (N-1) latency-bound hops, this is one.
-// k_xch_push: block t stores this rank's folded vector [mc | w2] into slot [step & 1][rank] of rank t's buffer
+// k_xch, blocks 0 .. N-1 (push): block t stores this rank's folded vector [mc | w2] into slot [step & 1][rank] of rank t's buffer
 // (fine-grained memory mapped through IPC: the stores of N-1 blocks cross N-1 different xGMI links at once), fences at
 // system scope and release-stores the step number into the slot's ticket word.
-// k_xch_pull: acquire-loads the N tickets of the parity in this rank's OWN buffer until all carry the step number, then
+// k_xch, block N (pull): acquire-loads the N tickets of the parity in this rank's OWN buffer until all carry the step number, then
 // adds the N vectors in rank order -- bit-identical bins on every rank by construction.
 // Two parities suffice: a rank pushes step t+2 only after its pull of t+1, which needed every peer's push of t+1, which
 // each peer issued behind its own pull of t on its stream.  Every spin has a time-out (2 s of the 100 MHz clock).
 // ------------------------------------------------------------------------------------
 // A slot is [2 * n_bins data | ticket | pad]: the ticket has a fixed place whatever the length of the step's message.
-__global__ __launch_bounds__(256) void k_xch_push(const double* __restrict__ src, int n_msg, double* const* targets, int ticket_off, uint64_t step) {
-  double* dst = targets[blockIdx.x];
-  for (int i = threadIdx.x; i < n_msg; i += 256) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store((uint64_t*)(dst + ticket_off), step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__global__ __launch_bounds__(256) void k_xch_pull(double* __restrict__ dst, int n_msg, const double* slots, int n_ranks, int slot_doubles,
-                                                  uint64_t step, uint64_t* status) {
+// push and pull as ONE launch: blocks 0 .. N-1 push, block N pulls (its own rank's push is one of the tickets it waits for;
+// the grid is at most 65 blocks, all resident at once)
+// `pushed`: counts this rank's finished push blocks (monotonic: n_ranks per step); the pull block overwrites the vector the
+// push blocks read from, so it also waits for all of them.
+__global__ __launch_bounds__(256) void k_xch(const double* src, double* dst, int n_msg, double* const* targets, int n_ranks,
+                                             const double* slots, int slot_doubles, uint64_t step, uint64_t* status, unsigned long long* pushed) {
   __shared__ int late;
+  if ((int)blockIdx.x < n_ranks) {
+    double* t = targets[blockIdx.x];
+    for (int i = threadIdx.x; i < n_msg; i += 256) __hip_atomic_store(&t[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_store((uint64_t*)(t + (slot_doubles - 2)), step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_fetch_add(pushed, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // this block is through with src
+    }
+    return;
+  }
   if (threadIdx.x == 0) late = 0;
   __syncthreads();
-  for (int r = threadIdx.x; r < n_ranks; r += 256) {
-    const uint64_t* ticket = (const uint64_t*)(slots + (size_t)r * slot_doubles + (slot_doubles - 2));
+  for (int r = threadIdx.x; r <= n_ranks; r += 256) {  // lanes 0 .. N-1: the peers' tickets; lane N: this rank's own push blocks
     const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step) {
+    for (;;) {
+      bool there;
+      if (r < n_ranks) there = __hip_atomic_load((const uint64_t*)(slots + (size_t)r * slot_doubles + (slot_doubles - 2)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= step;
+      else there = __hip_atomic_load(pushed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)n_ranks * step;
+      if (there) break;
       if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer that never pushed must not hang the device
         late = 1;
         break;
@@ -1317,17 +1328,16 @@ __global__ __launch_bounds__(256) void k_xch_pull(double* __restrict__ dst, int 
     if (threadIdx.x == 0) __hip_atomic_store(status, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
+  // src == dst: every push block of this rank has finished reading src (lane N above), so it may be overwritten
   for (int i = threadIdx.x; i < n_msg; i += 256) {
     double acc = 0.0;
     for (int r = 0; r < n_ranks; ++r) acc += __hip_atomic_load(&slots[(size_t)r * slot_doubles + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     dst[i] = acc;
   }
 }
-void launch_xch_push(const double* src, int n_msg, double* const* targets, int n_targets, int slot_doubles, uint64_t step, hipStream_t s) {
-  hipLaunchKernelGGL(k_xch_push, dim3(n_targets), dim3(256), 0, s, src, n_msg, targets, slot_doubles - 2, step);
-}
-void launch_xch_pull(double* dst, int n_msg, const double* slots, int n_ranks, int slot_doubles, uint64_t step, uint64_t* status, hipStream_t s) {
-  hipLaunchKernelGGL(k_xch_pull, dim3(1), dim3(256), 0, s, dst, n_msg, slots, n_ranks, slot_doubles, step, status);
+void launch_xch(const double* src, double* dst, int n_msg, double* const* targets, int n_ranks, const double* slots, int slot_doubles, uint64_t step,
+                uint64_t* status, unsigned long long* pushed, hipStream_t s) {
+  hipLaunchKernelGGL(k_xch, dim3(n_ranks + 1), dim3(256), 0, s, src, dst, n_msg, targets, n_ranks, slots, slot_doubles, step, status, pushed);
 }
 
 // ------------------------------------------------------------------------------------
