@@ -213,6 +213,13 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
                 raise SystemExit(3)
             fallback = True
             comm_mode = "torch.distributed all_reduce of the bin vector through the host (FALLBACK, --allow-host-fallback)"
+    elif n_ranks > 1 and os.environ.get("M3_BENCH_EXCHANGE") == "oneshot":
+        # rehearsal on one card: RCCL refuses two ranks on one device, the one-shot exchange does not need it.  The handles
+        # travel through the rehearsal backend (gloo); timing means nothing with two ranks on one GPU, --check does.
+        handles = [None] * n_ranks
+        dist.all_gather_object(handles, eng.xch_create(rank, n_ranks))
+        eng.xch_open(handles)
+        comm_mode = "one-shot peer stores through IPC-mapped buffers (m3hip_xch_*), rehearsal: ranks share one card"
     elif n_ranks > 1:
         comm_mode = "none (rehearsal backend: ranks do not exchange bins)"
 

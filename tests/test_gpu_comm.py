@@ -196,3 +196,22 @@ def test_one_shot_exchange_reports_a_missing_peer(fresh_engine):
             peer.wait(timeout=60)
     sh.Reweight()                   # back to the one-rank path
     assert np.isfinite(sh.GetLikelihood())
+
+
+def test_bench_two_ranks_on_one_card_with_check():
+    """bench.py's N = 2 path end to end on the one card of the test box: two ranks (torch.distributed over gloo for the
+    rendez-vous, the engine's one-shot exchange for the bins -- RCCL refuses two ranks on one device), events sharded by
+    responses with the cuts counted on rank 0 and broadcast, `--check`: the sharded likelihood of three laps equals the
+    one-rank likelihood of the same sample (1e-9 relative).  Timing means nothing with two ranks on one GPU; the logic does."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, M3_BENCH_BACKEND="gloo", M3_BENCH_EXCHANGE="oneshot", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3", "--events", "300000",
+                        "--steps", "10", "--warmup", "2", "--spinup-seconds", "0.2", "--check"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and "one-shot" in line["config"]["comm"]
+    assert line["check"]["ok"] and line["check"]["max_rel_diff"] <= 1e-9
+    assert line["config"]["events_per_gpu"] < 300000 and line["roofline"]["avg_kernel_ms_by_rank"]["min"] > 0
