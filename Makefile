@@ -37,7 +37,7 @@ isa: $(CSRC)/m3hip_kernels.hip
 	    -o build/m3hip_kernels.o $(CSRC)/m3hip_kernels.hip
 
 clean:
-	rm -f $(LIBDIR)/*.so build/*
+	rm -rf $(LIBDIR)/*.so build/*
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean isa stamps
