@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
     std::vector<float> cx(size_t(P) * 7);
     std::vector<int16_t> npts(P);
     m3synth_knots(&cfg, cx.data(), npts.data());
+    CK(m3hip_monolith_expect_events(h, E));  // the total is known here: light events (16 responses each) go into bricks of 4096
     CK(m3hip_monolith_begin(h, P, 7, cx.data(), npts.data()));
     const uint64_t chunk = 131072;
     for (uint64_t e0 = 0; e0 < E; e0 += chunk) {
