@@ -846,7 +846,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const unsigned long long act = __ballot(tf1_cnt > j0 + i);
       const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
       const M3_GLOBAL f32x2_t* gp = (const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos);
-      const f32x2_t v = NT ? __builtin_nontemporal_load(gp) : *gp;
+      // plain (cached) loads: the lines at the seams of two rows are wanted twice.  With the slots sorted by code count the rows
+      // of a wave are full for longer and this wins on both configurations (config 3 -0.7 %, config 5 -1.1 %); round 2's unsorted
+      // rows preferred non-temporal loads on config 3
+      const f32x2_t v = *gp;
       ab[i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
     }
