@@ -341,8 +341,17 @@ def oneshot_leg(eng, step, rank, n_ranks, dist, torch, args):
             res["error"] = f"rank {rank}: {what}: {e}"
             return False, None
 
+    def peers_reachable():  # one process per card: every other card must be able to map this one's buffer
+        n_dev, me = torch.cuda.device_count(), torch.cuda.current_device()
+        if n_ranks > 1 and n_dev >= n_ranks:
+            blind = [d for d in range(n_ranks) if d != me and not torch.cuda.can_device_access_peer(me, d)]
+            if blind:
+                raise RuntimeError(f"device {me} has no peer access to devices {blind}")
+        return True
+
     laps = [5000 + i for i in range(3)]
-    ok, ref = attempt("RCCL reference laps", lambda: [step(i) for i in laps])
+    ok, _ = attempt("peer access", peers_reachable)
+    ok, ref = attempt("RCCL reference laps", lambda: [step(i) for i in laps]) if ok else (False, None)
     ok, hdl = attempt("m3hip_xch_create", lambda: eng.xch_create(rank, n_ranks)) if ok else (False, None)
     handles = [hdl if hdl is not None else b""]
     if dist is not None and n_ranks > 1:
