@@ -776,6 +776,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
   { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
+  { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
   // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
   if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->expect_events);
   const int G = h->brick_groups;
@@ -2450,6 +2451,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
   { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
+  { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
   if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err, choose_brick_groups(in, 0))) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
   sizes[0] = plan.tiles.size();
   sizes[1] = plan.spl_float4;

@@ -165,6 +165,17 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   // M3_STAGE_EVENT_MAX times.  Stages of about equal size (a brick whose responses just exceed a multiple of the cap would
   // otherwise end in a stage of a few responses that costs the same barriers as a full one).
   struct Range { int p0, p1; };
+  // Extent of a run in a stage's response list.  Padded: its length rounded up to whole 128-byte lines, i.e. the list is laid
+  // out like the memory behind it, a group of 64 responses is eight whole lines and no line is asked for by two waves
+  // (config 3 -0.7 %, config 5 -1.2 % kernel time; the padding entries load the plane's padding, evaluate it and drop the
+  // result into the scatter array's slack).  Only where the runs are long enough for that to cost few extra entries:
+  // g_pad_runs = 2 pads the bricks whose lists grow by at most 8 %.
+  auto round_line = [](uint32_t n) -> uint32_t { return (n + uint32_t(M3_PLANE_ALIGN) - 1) & ~uint32_t(M3_PLANE_ALIGN - 1); };
+  uint32_t S_lines = 0;
+  for (int p = 0; p < n_params; ++p) S_lines += round_line(cnt_s[p + 1] - cnt_s[p]);
+  const bool pad_runs = g_pad_runs == 1 || (g_pad_runs == 2 && uint64_t(S_lines) * 100 <= uint64_t(S) * 108);
+  auto ext = [&](uint32_t n) -> uint32_t { return pad_runs ? round_line(n) : n; };
+  const uint32_t S_ext = pad_runs ? S_lines : S;
   // `n_aim` = 0: every stage as long as the limits allow (the fewest stages there can be).  Otherwise: aim at `n_aim` stages
   // of equal size, re-aimed after every stage (one that the row limit closed early must not leave a stub of a few
   // responses behind: it would cost the same barriers as a full stage).
@@ -176,14 +187,14 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     while (p0 < n_params) {
       uint32_t soft = uint32_t(M3_STAGE_CAP);
       if (n_aim) {
-        const uint32_t left = S - done, n_left = n_aim > st.size() ? n_aim - uint32_t(st.size()) : 1u;
+        const uint32_t left = S_ext - done, n_left = n_aim > st.size() ? n_aim - uint32_t(st.size()) : 1u;
         soft = std::min<uint32_t>(soft, (left + n_left - 1) / n_left);
       }
       std::fill(mult.begin(), mult.end(), uint8_t(0));
       uint32_t tot = 0, runs = 0;
       int p1 = p0;
       while (p1 < n_params) {
-        const uint32_t a = cnt_s[p1], b = cnt_s[p1 + 1], n_run = b - a;
+        const uint32_t a = cnt_s[p1], b = cnt_s[p1 + 1], n_run = ext(b - a);
         if (n_run == 0) { ++p1; continue; }
         if (tot > 0) {
           bool fits = tot + n_run <= uint32_t(M3_STAGE_CAP) && runs < uint32_t(M3_STAGE_MAX_RUNS);
@@ -226,7 +237,9 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   std::vector<uint16_t> slot(size_t(G) * M3_GROUP * 16);  // slot of the j-th response of local event le: [le * 16 + j]
   for (uint32_t stage = 0; stage < n_stages; ++stage) {
     const Range& rg = st_s[stage];
-    const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1], n_resp = r1 - r0;
+    const uint32_t r0 = cnt_s[rg.p0], r1 = cnt_s[rg.p1];
+    uint32_t n_resp = 0;
+    for (int p = rg.p0; p < rg.p1; ++p) n_resp += ext(cnt_s[p + 1] - cnt_s[p]);
     // the events' counts in the stage, then the slots: wave-block after wave-block, event after event inside a block
     std::fill(cnt.begin(), cnt.end(), uint8_t(0));
     for (uint32_t r = r0; r < r1; ++r) cnt[inv_ev[r]]++;
@@ -243,7 +256,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     std::fill(rank_of.begin(), rank_of.end(), uint8_t(0));
     std::vector<uint32_t> runs;
     std::vector<uint16_t> resp(n_resp), grp(size_t(M3_STAGE_PAIR_WORDS), uint16_t(0));  // groups past the end: filled below
-    uint32_t n_runs = 0;
+    uint32_t n_runs = 0, i0 = 0;  // i0: the run's first entry in the stage's list
     for (int p = rg.p0; p < rg.p1; ++p) {
       const uint32_t a = cnt_s[p], b = cnt_s[p + 1];
       if (a == b) continue;
@@ -252,16 +265,23 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
       // fetches whole lines, so an unaligned plane would drag in the neighbouring planes' lines at both ends
       const uint32_t stride = (n_run + uint32_t(M3_PLANE_ALIGN) - 1) & ~uint32_t(M3_PLANE_ALIGN - 1);
       if (spl_f4 + uint64_t(stride) * nseg > 0x06000000ull) { *err = "brick: spline store exceeds 1.6 GB"; return false; }
-      runs.push_back(uint32_t(int32_t(spl_f4) - int32_t(a - r0)));
+      runs.push_back(uint32_t(int32_t(spl_f4) - int32_t(i0)));
       runs.push_back(stride | (uint32_t(p) << 16));
-      for (uint32_t r = a; r < b; ++r) {
-        const uint32_t ev = inv_ev[r], i = r - r0;
+      const uint32_t n_ext = ext(n_run);
+      for (uint32_t j = 0; j < n_ext; ++j) {
+        const uint32_t i = i0 + j;
         if (i % 64 == 0) grp[i / 64] = uint16_t(n_runs);
-        const uint32_t rk = rank_of[ev]++;
-        resp[i] = uint16_t(uint32_t(slot[size_t(ev) * 16 + rk]) << 2);
-        bh->spl_src.push_back(inv_s[r]);
+        if (j < n_run) {
+          const uint32_t r = a + j, ev = inv_ev[r];
+          const uint32_t rk = rank_of[ev]++;
+          resp[i] = uint16_t(uint32_t(slot[size_t(ev) * 16 + rk]) << 2);
+          bh->spl_src.push_back(inv_s[r]);
+        } else {  // padding of the run's last line: its quad is loaded with the line, evaluated and dropped into the array's slack
+          resp[i] = uint16_t((uint32_t(M3_STAGE_CAP) + (i & 15u)) << 2);
+        }
       }
-      resp[b - 1 - r0] |= uint16_t(1u);  // last response of its run
+      resp[i0 + n_ext - 1] |= uint16_t(1u);  // last entry of its run
+      i0 += n_ext;
       spl_f4 += uint64_t(stride) * nseg;
       ++n_runs;
     }
@@ -425,13 +445,22 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
       } else {
         n_run = n_resp - start_r;
       }
+      // (with runs padded to whole lines in the list -- g_pad_runs -- the entries behind the run's last response are padding:
+      // their words point into the scatter array's slack)
+      auto word_at = [&](uint32_t i) -> uint32_t {
+        const uint32_t u = i / uint32_t(M3_GROUP), l = i % uint32_t(M3_GROUP);
+        const uint32_t d = words[h[3] + uint32_t(M3_GROUP) * (u / 2) + l];
+        return (u & 1u) ? d >> 16 : d & 0xFFFFu;
+      };
+      while (n_run > 0 && ((word_at(start_r + n_run - 1) & 0x7FFCu) >> 2) >= uint32_t(M3_STAGE_CAP)) --n_run;
+      const uint32_t n_ext = uint32_t((r + 1 < n_runs ? int64_t(coef_off) + int64_t(stride) * nseg - int64_t(int32_t(runs[2 * (r + 1)])) : int64_t(n_resp)) - int64_t(start_r));
       for (uint32_t k = 0; k < nseg; ++k)  // the padding of every plane is defined (never used in a product)
         std::memset(bs + (coef_off + uint64_t(k) * stride + n_run) * 4, 0, size_t(stride - n_run) * 16);
       for (uint32_t q = 0; q < n_run; ++q) {
         const float* src = in.coeff_many + 4ull * in.nknots_arr[bh.spl_src[src_i++]];
         for (uint32_t k = 0; k < nseg; ++k) std::memcpy(bs + (coef_off + uint64_t(k) * stride + q) * 4, src + 4 * k, 16);
       }
-      start_r += n_run;
+      start_r += n_ext;
     }
   }
   static const float kIdentityTf1[2] = {0.f, 1.f};
@@ -443,6 +472,7 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
 
 double g_pad_min_fill = kPadMinFillDefault;
 int g_tf1_sort = 2;
+int g_pad_runs = 2;
 
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
                 std::string* err, int brick_groups) {

@@ -48,8 +48,8 @@ for b in range(nb):
         for rn in range(n_runs):
             base, stride, p = int(np.int32(runs[rn][0])), int(runs[rn][1]) & 0xFFFF, int(runs[rn][1]) >> 16
             q0 = spl_off + base + seg[p] * stride + int(first_r[rn])
-            n = int(ends[rn] - first_r[rn])
-            tot["quads_used"] += 16 * n
+            n = int(ends[rn] - first_r[rn])  # entries of the run: its responses + (where the planner pads) the rest of its last line
+            tot["quads_used"] += 16 * int(((resp[first_r[rn]: ends[rn]] >> 2) < 5120).sum())
             for L in range((16 * q0) // 128, (16 * (q0 + n) - 1) // 128 + 1):
                 lines.add(L)
         tot["resp_words"] += 4 * ((n_resp + 1) // 2)

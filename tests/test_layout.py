@@ -141,6 +141,7 @@ def brick_event_lists(npts, ch, lay, b):
     assert G in (1, 2, 4) and nev <= 1024 * G
     n_blocks = 16 * G
     used = np.zeros(max(1, n_f4), bool)
+    pads_total, entries_total, aligned_runs = 0, 0, True
     for s in range(n_stages):
         h0, off_runs, off_pairs, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
         n_resp, n_runs, rows = h0 & 0xFFFF, (h0 >> 16) & 0x3FF, h0 >> 26
@@ -163,7 +164,7 @@ def brick_event_lists(npts, ch, lay, b):
             hw = cb.view(np.uint16)
             for h in range(4):
                 cnt[1024 * h: 1024 * (h + 1)] = (hw >> (4 * h)) & 15
-        assert cnt.sum() == n_resp and not cnt[nev:].any() and cnt.max() == rows <= STAGE_EVENT_MAX
+        assert not cnt[nev:].any() and cnt.max() == rows <= STAGE_EVENT_MAX
         resp = np.zeros(n_resp, np.uint16)                # two per dword, the way a lane fetches them
         for k in range((n_resp + 2047) // 2048):
             ln = min(1024, n_resp - 2048 * k)
@@ -174,12 +175,13 @@ def brick_event_lists(npts, ch, lay, b):
             assert not (blk[hi:] >> 16).any()
         ell = {}
         run = -1
+        n_pad = 0
         for r in range(n_resp):
             if r % 64 == 0:
                 run = int(grp[r // 64])                  # the kernel: run of the group's first response ...
             wd = int(resp[r])
             slot, last_run = (wd & 0x7FFC) >> 2, wd & 1
-            assert not wd & 0x8002 and slot < n_resp
+            assert not wd & 0x8002
             base = int(np.int32(runs[run][0]))
             stride, p = int(runs[run][1]) & 0xFFFF, int(runs[run][1]) >> 16
             assert stride % 8 == 0
@@ -187,10 +189,18 @@ def brick_event_lists(npts, ch, lay, b):
             idx = [base + k * stride + r for k in range(nseg)]
             assert all(0 <= i < n_f4 for i in idx) and not used[idx].any()
             used[idx] = True
+            if slot >= STAGE_CAP:                        # padding of a run's last line (runs padded to whole lines in the list):
+                assert slot < STAGE_CAP + 16 and (r + 1) % 8 != 1      # dropped into the array's slack; never first in a line
+                n_pad += 1
+                run += last_run
+                continue
+            assert slot < n_resp
             assert slot not in ell                       # one slot per response
             ell[slot] = (p, "spl", np.stack([spl[spl_off + i] for i in idx]))
             run += last_run                              # ... + the runs that ended before this response
         assert run == n_runs                             # the last response closes the last run
+        assert cnt.sum() == n_resp - n_pad
+        pads_total += n_pad
         # phase B: every lane reads its event's slots: first slot of the wave-block + exclusive prefix sum of the counts
         # over the block's lanes (a wave scan in the kernel) + j
         for blk_i in range(n_blocks):
@@ -208,6 +218,13 @@ def brick_event_lists(npts, ch, lay, b):
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
             assert (int(np.int32(runs[rn][0])) + int(first_r[rn])) % 8 == 0
+        entries_total += n_resp
+        aligned_runs = aligned_runs and not (first_r % 8).any()
+    # runs padded to whole lines in the lists (so that a group of 64 entries is eight whole lines): all of a brick's or none,
+    # and only where that costs at most 8 % more entries
+    if pads_total:
+        assert aligned_runs
+        assert os.environ.get("M3HIP_PAD_RUNS") == "1" or pads_total * 100 <= 8 * (entries_total - pads_total)
     # TF1: jagged rows per wave-block of 64 lane-slots; slot k = 1024 h + l works on event 1024 h + sigma[k] of the brick
     n_slots = 1024 * G
     hdr = w[off_tf1: off_tf1 + 32 * G + n_slots // 4 + n_slots // 2]
@@ -286,6 +303,26 @@ def test_ragged_brick_layout(n_events, cfg):
     assert rc == 0, err
     assert lay["n_bricks"] == (n_events + 1023) // 1024 and lay["n_tiles"] == 0
     check_bricks(npts, ch, lay)
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+def test_runs_padded_to_whole_lines_or_not(pad, monkeypatch):
+    """The planner pads a brick's runs to whole 128-byte lines in the stages' lists where that is cheap (M3HIP_PAD_RUNS: 0
+    never, 1 always, default by cost): both forms replay to the same event lists, and the padded one has every run start on
+    a multiple of eight entries."""
+    monkeypatch.setenv("M3HIP_PAD_RUNS", str(pad))
+    spec = synth.CONFIGS["c3"].scaled(1024 + 500)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, spec.n_events)
+    rc, err, lay = debug_layout(spec.n_params, spec.n_knots, npts, ch)
+    assert rc == 0, err
+    check_bricks(npts, ch, lay)
+    w = lay["words"]
+    w0 = int(lay["bdesc"][0][2])
+    entries = sum(int(w[w0 + HDR0 + 4 * s]) & 0xFFFF for s in range(int(w[w0])))
+    real = int(ch["npe"][:2 * 1024:2].sum())            # TSpline3 responses of the first brick's 1024 events
+    assert (entries > real) if pad else (entries == real)
+    assert entries <= 1.08 * real
 
 
 def test_more_runs_than_a_stage_holds():
