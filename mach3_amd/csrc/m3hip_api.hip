@@ -147,7 +147,7 @@ struct m3hip_ctx {
   uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
   bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
   bool evw_ok = false;            // the sample fits the packed word's fields
-  int64_t min_norm_idx = INT64_MAX;
+  int64_t min_norm_idx = INT64_MAX, max_norm_idx_evw = -1;  // over the slots the packed word holds (an event's first M3_EVW_NORM_SLOTS)
   uint32_t M = 0;
   // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
   // index with them unguarded)
@@ -418,6 +418,7 @@ void free_monolith(m3hip_handle h) {
   h->evw_dirty = true;
   h->evw_ok = false;
   h->min_norm_idx = INT64_MAX;
+  h->max_norm_idx_evw = -1;
   for (auto& x : h->extra) {
     dev_free(x.d_col); dev_free(x.d_idx); dev_free(x.d_tab);
     for (int i = 0; i < 2; ++i)
@@ -1170,7 +1171,10 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
           plane[i] = (m < c) ? norm_idx[norm_off[i] + m] : int16_t(-1);
           if (m < c && plane[i] < 0) return fail(h, M3HIP_EINVAL, "upload_events: negative norm parameter index");
           h->max_norm_idx = std::max<int64_t>(h->max_norm_idx, plane[i]);
-          if (m < c) h->min_norm_idx = std::min<int64_t>(h->min_norm_idx, plane[i]);
+          if (m < c && m < uint32_t(M3_EVW_NORM_SLOTS)) {
+            h->min_norm_idx = std::min<int64_t>(h->min_norm_idx, plane[i]);
+            h->max_norm_idx_evw = std::max<int64_t>(h->max_norm_idx_evw, plane[i]);
+          }
         }
         HIPCHK(h, hipMemcpy(h->d_nidx + size_t(m) * h->E_pad + event_offset, plane.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice));
       }
@@ -1978,12 +1982,12 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (!h->f64 && !h->h_bricks.empty()) {
     if (dyn_pass) h->evw_dirty = true;  // the re-binning pass has just rewritten d_bin
     if (h->evw_dirty) {
-      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->M <= 3 &&
-                  (h->max_norm_idx < 0 || h->max_norm_idx - h->min_norm_idx <= 62) && h->d_bin && h->d_osc;
+      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 &&
+                  (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) && h->d_bin && h->d_osc;
       if (const char* f = getenv("M3HIP_PACKED_EVENTS")) h->evw_ok = h->evw_ok && f[0] != '0';
       if (h->evw_ok) {
         if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
-        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, h->M, h->E_pad, int32_t(h->max_norm_idx < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, h->M, h->E_pad, int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
       }
       h->evw_dirty = false;
     }
@@ -1995,7 +1999,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   }
   if (!h->f64 && h->evw_ok && !h->evw_dirty) {
     a.evw = h->d_evw;
-    a.evw_norm_base = int32_t(h->max_norm_idx < 0 ? 0 : h->min_norm_idx);
+    a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);
   }
   if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;

@@ -117,6 +117,10 @@ struct ExtraSlot {
 };
 constexpr int M3_MAX_EXTRA = 8;
 
+// norm-parameter indices in the packed sample word (ReweightArgs::evw): an event's first three as 6-bit codes; events with
+// more read the rest from the index planes in the kernel's tail
+#define M3_EVW_NORM_SLOTS 3
+
 struct ReweightArgs {
   const TileDev* tiles;
   const BrickDev* bricks;

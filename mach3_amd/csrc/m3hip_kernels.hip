@@ -895,7 +895,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       t_osc = (int32_t)(((lo >> 20) | (hi << 12)) & 0xFFFFFFu) - 1;
 #pragma unroll
       for (int m = 0; m < kTailNorm; ++m) {
-        const uint32_t cd = m < 3 ? (hi >> (12 + 6 * m)) & 63u : 0u;
+        const uint32_t cd = m < M3_EVW_NORM_SLOTS ? (hi >> (12 + 6 * m)) & 63u : 0u;
         t_ni[m] = cd ? a.evw_norm_base + (int32_t)cd - 1 : -1;
       }
     }
@@ -1083,7 +1083,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if (valid) {
       if (MODE & kModeEval) a.spline_w[ev] = wh;
       if (MODE & (kModeFill | kModeEventW)) {
-        if (a.n_norm_slots > (uint32_t)kTailNorm) tw = mul_norm_weights(tw, a, ev, (uint32_t)kTailNorm);
+        // slots the look-ahead did not cover (the packed word holds an event's first M3_EVW_NORM_SLOTS): read here, in slot order
+        constexpr uint32_t kAhead = PACK ? (uint32_t)M3_EVW_NORM_SLOTS : (uint32_t)kTailNorm;
+        if (a.n_norm_slots > kAhead) tw = mul_norm_weights(tw, a, ev, kAhead);
         if (has_osc) tw *= oscw;
         tw = mul_binned_weights(tw, a, ev);
         tw *= wh;
@@ -1185,7 +1187,7 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
 }
 
 // ------------------------------------------------------------------------------------
-// k_pack_events: an event's bin, oscillation index and up to three norm-parameter indices as one 8-byte word
+// k_pack_events: an event's bin, oscillation index and its first three norm-parameter indices as one 8-byte word
 // (ReweightArgs::evw).  Set-up time: runs when one of the three arrays has changed.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots,
@@ -1193,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_pack_events(const int32_t* bin, const i
   const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (ev >= e_pad) return;
   uint64_t w = (uint64_t)(uint32_t)(bin[ev] + 1) | ((uint64_t)(uint32_t)(osc[ev] + 1) << 20);
-  for (uint32_t m = 0; m < n_norm_slots; ++m) {
+  for (uint32_t m = 0; m < n_norm_slots && m < (uint32_t)M3_EVW_NORM_SLOTS; ++m) {
     const int32_t i = nidx[(uint64_t)m * e_pad + ev];
     w |= (uint64_t)(i >= 0 ? (uint32_t)(i - norm_base + 1) : 0u) << (44 + 6 * m);
   }

@@ -453,6 +453,34 @@ def test_ragged_bricks_match_oracle(fresh_engine, monkeypatch, cfg, n_events, n_
     omono.close()
 
 
+@pytest.mark.parametrize("groups", [1, 4])
+def test_bricks_with_more_norm_parameters_than_the_packed_word_holds(fresh_engine, monkeypatch, groups):
+    """Up to six norm parameters per event (out of 40): the brick kernel takes an event's first three from its packed
+    sample word and the rest from the index planes, in slot order (SampleHandlerFD.cpp:568-594); event weights bit-exact."""
+    monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
+    n_events = 4096 + 900
+    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=96, n_norm=40, max_norm_per_event=6)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    assert eng.info().n_tiles_brick > 0 and eng.info().n_tiles_uniform == 0
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
+    assert int(np.diff(ev["norm_off"]).max()) == 6
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventWeights(0, n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    osamp.close()
+    omono.close()
+
+
 def test_oscillation_weights_change_every_step(fresh_engine):
     """OscillationHandler::Evaluate runs inside every Reweight (SampleHandlerFD.cpp:319-324): the weight table
     behind the events' oscillation pointers is re-uploaded per step (asynchronously, no sync in between) and
