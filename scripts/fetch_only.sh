@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: fetch_only.sh <tag> <bench args>
+# One FETCH_SIZE pass of a bench command; prints the reweight kernel's read traffic per launch (2 x FETCH_SIZE x 1024, the gfx950
+# correction of MI355X_MICROARCH.md).  Run on the GPU box from the repo root:  bash scripts/fetch_only.sh <tag> <bench args>
 TAG=$1; shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/fo_$TAG
