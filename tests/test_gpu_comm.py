@@ -57,7 +57,7 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import numpy as np
 from mach3_amd import synth, dist as m3dist
 from mach3_amd.engine import build_from_synth
-rank, world, tmp, mode, update_w2 = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3], sys.argv[4] == "1"
+rank, world, tmp, mode, update_w2 = int(sys.argv[1]), int(sys.argv[5]), sys.argv[2], sys.argv[3], sys.argv[4] == "1"
 spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
 e0, e1 = m3dist.shard_ranges(spec.n_events, world)[rank]
 eng, mono, sh, par = build_from_synth(spec, device_id=0, event_range=(e0, e1))
@@ -99,13 +99,13 @@ eng.close()
 """
 
 
-def _two_ranks(mode, update_w2):
+def _two_ranks(mode, update_w2, world=2):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         open(script, "w").write(_WORKER.format(root=ROOT))
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs = [subprocess.Popen([sys.executable, script, str(r), tmp, mode, "1" if update_w2 else "0"], env=env, stdout=subprocess.PIPE,
-                                  stderr=subprocess.STDOUT) for r in (0, 1)]
+        procs = [subprocess.Popen([sys.executable, script, str(r), tmp, mode, "1" if update_w2 else "0", str(world)], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
         outs = []
         for p in procs:
             try:
@@ -113,7 +113,7 @@ def _two_ranks(mode, update_w2):
             except subprocess.TimeoutExpired:
                 for q in procs:
                     q.kill()
-                pytest.fail(f"two-rank {mode} workers timed out")
+                pytest.fail(f"{world}-rank {mode} workers timed out")
         refused = [f for f in os.listdir(tmp) if f.startswith("refused")]
         if refused:
             why = open(os.path.join(tmp, refused[0])).read()[:300]
@@ -121,10 +121,12 @@ def _two_ranks(mode, update_w2):
                 pytest.skip("RCCL refuses two ranks on one device: " + why)
             pytest.fail("the one-shot exchange could not be set up: " + why)
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-        r0, r1 = (np.load(os.path.join(tmp, f"rank{r}.npz")) for r in (0, 1))
+        r0 = np.load(os.path.join(tmp, "rank0.npz"))
         # every rank holds the same exchanged vectors and the same likelihood (the one-shot sum is rank-ordered: bit-identical)
-        assert np.array_equal(r0["mc"], r1["mc"]) and np.array_equal(r0["w2"], r1["w2"]) and np.array_equal(r0["llh"], r1["llh"])
-        assert np.array_equal(r0["data"], r1["data"]) and np.array_equal(r0["w2_first"], r1["w2_first"])
+        for r in range(1, world):
+            r1 = np.load(os.path.join(tmp, f"rank{r}.npz"))
+            assert np.array_equal(r0["mc"], r1["mc"]) and np.array_equal(r0["w2"], r1["w2"]) and np.array_equal(r0["llh"], r1["llh"])
+            assert np.array_equal(r0["data"], r1["data"]) and np.array_equal(r0["w2_first"], r1["w2_first"])
         assert r0["rel"] <= 1e-15 and r0["n"] >= 4
         # ... equal to one engine over the whole sample
         spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
@@ -152,6 +154,12 @@ def test_two_ranks_one_shot_exchange_matches_unsharded(update_w2):
     """two processes on one card through m3hip_xch_*: w2 travels with mc while it accumulates (first Reweight, or every one
     with UpdateW2), then the message shrinks to mc alone"""
     _two_ranks("oneshot", update_w2)
+
+
+def test_four_ranks_one_shot_exchange_matches_unsharded():
+    """four processes on one card: slot [parity][rank] of every rank's buffer, four push blocks per step, a pull over four
+    slots -- the indexing two ranks cannot get wrong"""
+    _two_ranks("oneshot", False, world=4)
 
 
 _SILENT_PEER = r"""
