@@ -147,6 +147,7 @@ struct m3hip_ctx {
   uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
   bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
   bool evw_ok = false;            // the sample fits the packed word's fields
+  uint32_t evw_norm_slots = 0;    // norm slots the word carries: M3_EVW_NORM_SLOTS, or 0 when the sample's norm indices do not fit its codes
   int64_t min_norm_idx = INT64_MAX, max_norm_idx_evw = -1;  // over the slots the packed word holds (an event's first M3_EVW_NORM_SLOTS)
   uint32_t M = 0;
   // largest indices any uploaded event carries (checked against the table / vector sizes at reweight: the kernels
@@ -1982,12 +1983,18 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (!h->f64 && !h->h_bricks.empty()) {
     if (dyn_pass) h->evw_dirty = true;  // the re-binning pass has just rewritten d_bin
     if (h->evw_dirty) {
-      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 &&
-                  (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) && h->d_bin && h->d_osc;
-      if (const char* f = getenv("M3HIP_PACKED_EVENTS")) h->evw_ok = h->evw_ok && f[0] != '0';
+      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->d_bin && h->d_osc;
+      // norm parameters spread over more than 62 indices do not fit the word's 6-bit codes: the word then carries bin and
+      // oscillation index only, and the kernel's tail reads every norm slot from the index planes
+      h->evw_norm_slots = (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) ? uint32_t(M3_EVW_NORM_SLOTS) : 0u;
+      if (const char* f = getenv("M3HIP_PACKED_EVENTS")) {
+        h->evw_ok = h->evw_ok && f[0] != '0';
+        if (f[0] == 'b') h->evw_norm_slots = 0;  // "b": bin and oscillation index only (tests)
+      }
       if (h->evw_ok) {
         if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
-        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, h->M, h->E_pad, int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
+                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
       }
       h->evw_dirty = false;
     }
@@ -2000,6 +2007,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (!h->f64 && h->evw_ok && !h->evw_dirty) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);
+    a.evw_norm_slots = h->evw_norm_slots;
   }
   if (a.fill_w2) h->w2_spread = true;
   int mode = kModeFill;

@@ -138,6 +138,7 @@ struct ReweightArgs {
   // (0: none).  14 B -> 8 B per event; rebuilt on the device (k_pack_events) whenever one of the arrays changes.
   const uint64_t* evw;
   int32_t evw_norm_base;
+  uint32_t evw_norm_slots;  // norm slots held in the word (M3_EVW_NORM_SLOTS or 0); an event's further slots are read from nidx
   const double* params;      // [n_par + 1], last entry 1.0
   const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
   // ... or, when neighbouring events share their lists (MC ordered by spline bin), one list id per event into a

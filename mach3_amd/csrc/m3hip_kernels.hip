@@ -1083,9 +1083,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if (valid) {
       if (MODE & kModeEval) a.spline_w[ev] = wh;
       if (MODE & (kModeFill | kModeEventW)) {
-        // slots the look-ahead did not cover (the packed word holds an event's first M3_EVW_NORM_SLOTS): read here, in slot order
-        constexpr uint32_t kAhead = PACK ? (uint32_t)M3_EVW_NORM_SLOTS : (uint32_t)kTailNorm;
-        if (a.n_norm_slots > kAhead) tw = mul_norm_weights(tw, a, ev, kAhead);
+        // slots the look-ahead did not cover (the packed word holds an event's first M3_EVW_NORM_SLOTS, or none): read here, in slot order
+        const uint32_t ahead = PACK ? a.evw_norm_slots : (uint32_t)kTailNorm;
+        if (a.n_norm_slots > ahead) tw = mul_norm_weights(tw, a, ev, ahead);
         if (has_osc) tw *= oscw;
         tw = mul_binned_weights(tw, a, ev);
         tw *= wh;

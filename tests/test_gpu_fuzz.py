@@ -110,7 +110,7 @@ def _run_case(fresh_engine, c, seed):
     forced = os.environ.get("M3HIP_BRICK_GROUPS")
     os.environ["M3HIP_BRICK_GROUPS"] = forced or str((1, 2, 4)[seed % 3])
     # the events' {bin, osc, norm} indices as one packed word (the default when they fit) or as three arrays
-    os.environ["M3HIP_PACKED_EVENTS"] = "0" if seed % 4 == 3 else "1"
+    os.environ["M3HIP_PACKED_EVENTS"] = "0" if seed % 4 == 3 else "b" if seed % 4 == 1 else "1"  # arrays / word without norm codes / full word
     try:
         mono = SMonolith(fresh_engine, P, 7, cx, npts, chunks)
     finally:

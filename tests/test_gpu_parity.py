@@ -454,12 +454,15 @@ def test_ragged_bricks_match_oracle(fresh_engine, monkeypatch, cfg, n_events, n_
 
 
 @pytest.mark.parametrize("groups", [1, 4])
-def test_bricks_with_more_norm_parameters_than_the_packed_word_holds(fresh_engine, monkeypatch, groups):
-    """Up to six norm parameters per event (out of 40): the brick kernel takes an event's first three from its packed
-    sample word and the rest from the index planes, in slot order (SampleHandlerFD.cpp:568-594); event weights bit-exact."""
+@pytest.mark.parametrize("n_norm", [40, 300])
+def test_bricks_with_more_norm_parameters_than_the_packed_word_holds(fresh_engine, monkeypatch, groups, n_norm):
+    """Up to six norm parameters per event: out of 40, the brick kernel takes an event's first three from its packed sample
+    word and the rest from the index planes, in slot order (SampleHandlerFD.cpp:568-594); out of 300 (indices spread beyond
+    the word's 6-bit codes) the word carries bin and oscillation index only and every norm slot comes from the planes.
+    Event weights bit-exact either way."""
     monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
     n_events = 4096 + 900
-    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=96, n_norm=40, max_norm_per_event=6)
+    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=96, n_norm=n_norm, max_norm_per_event=6)
     eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
     assert eng.info().n_tiles_brick > 0 and eng.info().n_tiles_uniform == 0
     omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
