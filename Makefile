@@ -31,6 +31,12 @@ build/libm3hip_stamps.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_STAMPS -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
 
+# diagnostic build: the brick kernel without arithmetic and LDS traffic (loads, waits and barriers only) -- the memory side's share
+hollow: build/libm3hip_hollow.so
+build/libm3hip_hollow.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+
 isa: $(CSRC)/m3hip_kernels.hip
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage \
@@ -40,7 +46,7 @@ clean:
 	rm -rf $(LIBDIR)/*.so build/*
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean isa stamps
+.PHONY: all oracle clean isa stamps hollow
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
 examples: build/mr2t2_dragrace build/facade_check build/c5_step_loop build/libm3facade_test.so build/libm3seam2_test.so

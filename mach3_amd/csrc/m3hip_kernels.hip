@@ -574,6 +574,13 @@ extern "C" int m3hip_debug_read_stamps(unsigned long long* out, unsigned long lo
 #define M3_STAMP(k) do {} while (0)
 #define M3_STAMP_HWID() do {} while (0)
 #endif
+// Diagnostic build only (-DM3_BRICK_HOLLOW, `make hollow`): the brick kernel with its arithmetic and its LDS traffic taken
+// out -- every load, wait and barrier stays, a loaded register is "used" by an empty asm instead of being evaluated, scattered,
+// multiplied.  What such a launch takes is the memory side's share of the kernel's time (results are garbage).
+#ifdef M3_BRICK_HOLLOW
+#define M3_HOLLOW_USE4(v) asm volatile("" ::"v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
+#define M3_HOLLOW_USE1(v) asm volatile("" ::"v"(v))
+#endif
 
 // A wave-uniform address, pinned into an SGPR pair: the lane-dependent part of a load's address then stays a 32-bit
 // offset register (`global_load v, v_off, s[base]`).  Without the pin hipcc hoists base + lane offset out of loops
@@ -931,6 +938,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     return x;
   };
   auto column = [&](const uint32_t (&block0)[G], uint32_t counts) {
+#ifdef M3_BRICK_HOLLOW
+    M3_HOLLOW_USE1(counts);
+    return;
+#endif
     uint32_t cnt[G], excl[G];
 #pragma unroll
     for (int h = 0; h < G; ++h) cnt[h] = count_of(counts, h);
@@ -981,8 +992,16 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     for (int h = 0; h < G; ++h) block0[h] = __builtin_amdgcn_readfirstlane((uint32_t)lds_woff[(s & 1u) * 16 * G + 16 * h + wave]);
     auto scatter = [&](int u) {
       // bits 2..14 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
+#ifdef M3_BRICK_HOLLOW
+      const float4 cu = c[u];
+      const float du = dx[u];
+      M3_HOLLOW_USE4(cu);
+      M3_HOLLOW_USE1(du);
+      (void)n_resp;
+#else
       if (lane + u * kBrickThreads < n_resp)
         *(float*)((char*)ell + (word(m_cur, u) & 0x7FFCu)) = spline_poly(dx[u], c[u]);
+#endif
     };
     if (!LAST) {
       issue_quads(s + 1, m_nxt, scatter);
@@ -1043,6 +1062,14 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         for (int q = 0; q < N / 4; ++q) code[q] = tf1_on[q] ? code[q] : 0u;  // ... dropped here
 #pragma unroll
         for (int i = 0; i < N; ++i) {
+#ifdef M3_BRICK_HOLLOW
+          const float2 abi = ab[i];
+          const uint32_t cdw = code[i / 4];
+          M3_HOLLOW_USE1(abi.x);
+          M3_HOLLOW_USE1(abi.y);
+          M3_HOLLOW_USE1(cdw);
+          continue;
+#endif
           // code 0: no response in this row (the event's list has ended: the planner zero-fills); M3_TF1_SKIP: a step of 254
           // without a response
           const uint32_t cd = (code[i / 4] >> (8 * (i % 4))) & 0xFFu;
