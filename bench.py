@@ -262,7 +262,17 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         eng.comm_set_validate(True)
     t_spin = time.perf_counter()
     n_spin = 0
-    while time.perf_counter() - t_spin < args.spinup_seconds:
+
+    def keep_spinning():
+        # every step is a collective: the ranks must agree on how many there are, so rank 0's clock decides for all of them
+        go = time.perf_counter() - t_spin < args.spinup_seconds
+        if dist is not None and n_ranks > 1:
+            flag = torch.tensor([1.0 if go else 0.0], device="cuda")
+            dist.broadcast(flag, 0)
+            go = float(flag.item()) > 0
+        return go
+
+    while keep_spinning():
         step(n_spin)
         n_spin += 1
     for i in range(max(args.warmup, 2 if in_library else 0)):

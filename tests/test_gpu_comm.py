@@ -206,20 +206,25 @@ def test_one_shot_exchange_reports_a_missing_peer(fresh_engine):
     assert np.isfinite(sh.GetLikelihood())
 
 
-def test_bench_two_ranks_on_one_card_with_check():
-    """bench.py's N = 2 path end to end on the one card of the test box: two ranks (torch.distributed over gloo for the
-    rendez-vous, the engine's one-shot exchange for the bins -- RCCL refuses two ranks on one device), events sharded by
-    responses with the cuts counted on rank 0 and broadcast, `--check`: the sharded likelihood of three laps equals the
-    one-rank likelihood of the same sample (1e-9 relative).  Timing means nothing with two ranks on one GPU; the logic does."""
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_bench_ranks_on_one_card_with_check(n_ranks):
+    """bench.py's N > 1 path end to end on the one card of the test box, with the configuration it picks for that N
+    (configs[2] for two ranks, configs[3] -- four samples -- for four) at a reduced size: torch.distributed over gloo for the
+    rendez-vous, the engine's one-shot exchange for the bins (RCCL refuses several ranks on one device), events sharded by
+    responses with the cuts counted on rank 0 and broadcast, a time-bounded spin-up whose step count rank 0 decides for
+    everybody (every step is a collective), `--check`: the sharded likelihood of three laps equals the one-rank likelihood
+    of the same sample (1e-9 relative).  Timing means nothing with the ranks on one GPU; the logic does."""
     import json
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, M3_BENCH_BACKEND="gloo", M3_BENCH_EXCHANGE="oneshot", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3", "--events", "300000",
-                        "--steps", "10", "--warmup", "2", "--spinup-seconds", "0.2", "--check"], env=env, capture_output=True, text=True, timeout=500)
+    n_events = 150_000 * n_ranks
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--events", str(n_events),
+                        "--steps", "10", "--warmup", "2", "--spinup-seconds", "0.5", "--check"], env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and "one-shot" in line["config"]["comm"]
+    assert line["n_gpus"] == n_ranks and "one-shot" in line["config"]["comm"]
+    assert ("configs[2]" if n_ranks == 2 else "configs[3]") in line["config"]["workload"]
     assert line["check"]["ok"] and line["check"]["max_rel_diff"] <= 1e-9
-    assert line["config"]["events_per_gpu"] < 300000 and line["roofline"]["avg_kernel_ms_by_rank"]["min"] > 0
+    assert line["config"]["events_per_gpu"] < n_events and line["roofline"]["avg_kernel_ms_by_rank"]["min"] > 0
