@@ -31,9 +31,17 @@ import time
 
 # host thread pools sized to one GPU's CPU share (the reference recommends 8, allows 16 threads:
 # Manager/Monitor.cpp:122-138); must be set before any OpenMP runtime initialises
-os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+_local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+if _local_world > 1:
+    # one rank per GPU under torch.distributed.run: it exports OMP_NUM_THREADS=1 unless the caller chose a value, which would
+    # generate and lay out every rank's shard on one thread; take one GPU's share of the host instead and leave the threads
+    # unbound (bound "close", every rank's team would sit on the same first cores)
+    if os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 1) // _local_world)))
+else:
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
