@@ -369,7 +369,9 @@ def oneshot_leg(eng, step, rank, n_ranks, dist, torch, args):
 
     laps = [5000 + i for i in range(3)]
     ok, _ = attempt("peer access", peers_reachable)
-    ok, ref = attempt("RCCL reference laps", lambda: [step(i) for i in laps]) if ok else (False, None)
+    if not agree(ok, "the peer access check"):  # before the first collective step below: all ranks go on, or none
+        return res
+    ok, ref = attempt("RCCL reference laps", lambda: [step(i) for i in laps])
     ok, hdl = attempt("m3hip_xch_create", lambda: eng.xch_create(rank, n_ranks)) if ok else (False, None)
     handles = [hdl if hdl is not None else b""]
     if dist is not None and n_ranks > 1:
