@@ -87,6 +87,12 @@ int main() {
   rc |= run_case(11, 4096, 300, 0.9, false, false, 2.0, 4);  // heavy events: the planner cuts the bricks short of 4096 events
   rc |= run_case(8, 2048 + 300, 60, 0.85, true, false);    // nearly uniform lists: identity-padded uniform tiles
   rc |= run_case(7, 3000, 16, 0.0, true, false);      // no responses at all
+  g_pad_runs = 1;  // runs padded to whole lines in the response lists whatever that costs (default: where it is cheap)
+  rc |= run_case(12, 1024 + 700, 48, 0.03, true, false);   // short runs: mostly padding entries
+  rc |= run_case(13, 2 * 4096 + 99, 64, 0.1, true, false, kPadMinFillDefault, 4);
+  g_pad_runs = 0;
+  rc |= run_case(14, 2048 + 300, 48, 0.2, true, false);    // never padded
+  g_pad_runs = 2;
   std::printf("OK\n");
   return rc;
 }
