@@ -35,7 +35,7 @@ build/libm3hip_stamps.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC
 hollow: build/libm3hip_hollow.so
 build/libm3hip_hollow.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW=$(or $(HOLLOW),1) -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
 
 isa: $(CSRC)/m3hip_kernels.hip
 	@mkdir -p build

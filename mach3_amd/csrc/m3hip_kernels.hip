@@ -577,7 +577,7 @@ extern "C" int m3hip_debug_read_stamps(unsigned long long* out, unsigned long lo
 // Diagnostic build only (-DM3_BRICK_HOLLOW, `make hollow`): the brick kernel with its arithmetic and its LDS traffic taken
 // out -- every load, wait and barrier stays, a loaded register is "used" by an empty asm instead of being evaluated, scattered,
 // multiplied.  What such a launch takes is the memory side's share of the kernel's time (results are garbage).
-#ifdef M3_BRICK_HOLLOW
+#ifdef M3_BRICK_HOLLOW  // 1: as described; 2: also without the stage's second barrier; 3: also without the TF1 rows; 4: level 1 without the flush of the bin vector; 5: level 1 with the flush's barrier but without its atomics
 #define M3_HOLLOW_USE4(v) asm volatile("" ::"v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
 #define M3_HOLLOW_USE1(v) asm volatile("" ::"v"(v))
 #endif
@@ -922,7 +922,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     tf1_cbase = book_nxt.cbase;
     tf1_dbase = book_nxt.dbase;
   };
+#if defined(M3_BRICK_HOLLOW) && M3_BRICK_HOLLOW == 3  // (hollow level 3: without the TF1 rows)
+  const bool any_tf1 = false;
+#else
   const bool any_tf1 = bd.n_dict > 0;  // kernel-uniform
+#endif
 
   float w[G];  // SplineMonolith.cpp:798, one product per slab
 #pragma unroll
@@ -1012,7 +1016,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
       tail_issue_idx(0);
     }
+#if !defined(M3_BRICK_HOLLOW) || M3_BRICK_HOLLOW != 2  // (hollow level 2: without this barrier -- nothing is scattered there)
     __syncthreads();  // the stage's scatter is complete
+#endif
     // every event's responses: they lie next to each other in the scatter array, from the wave-block's first slot + the
     // exclusive prefix sum of the counts over the wave's lanes on (a DPP scan; two slabs' counts share a register)
     column(block0, counts);
@@ -1167,7 +1173,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     for (int i = lane; i < nb; i += kBrickThreads) row[i] = lds_hist[i];
     return;
   }
+#if defined(M3_BRICK_HOLLOW) && M3_BRICK_HOLLOW == 4  // (hollow level 4: without the flush of the bin vector)
+  if (false) {
+#else
   if ((MODE & kModeFill) && af.hist_lds) {
+#endif
     __syncthreads();
     M3_STAMP(10);
     const int nb = af.fill_w2 ? 2 * af.n_bins : af.n_bins;
@@ -1175,7 +1185,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     for (int i = lane; i < nb; i += kBrickThreads) {
       const double v = lds_hist[i];
       const int slot = i < af.n_bins ? rep * af.n_bins + i : (af.hist_rep + rep) * af.n_bins + (i - af.n_bins);
+#if defined(M3_BRICK_HOLLOW) && M3_BRICK_HOLLOW == 5  // (hollow level 5: the flush's barrier and LDS reads, not its atomics)
+      if (v == 123.456) atomicAdd(&af.hist[slot], v);
+#else
       if (v != 0.0) atomicAdd(&af.hist[slot], v);
+#endif
     }
   }
   M3_STAMP(11);

@@ -9,7 +9,12 @@ from mach3_amd.engine import build_from_synth
 cfg, ev = sys.argv[1], int(sys.argv[2])
 kw = {"mixed": False} if len(sys.argv) > 3 and sys.argv[3] == "spl" else {}
 spec = synth.CONFIGS[cfg].scaled(ev, **kw)
-eng, mono, sh, par = build_from_synth(spec)
+engine = None
+if os.environ.get("M3_GEXP_REPLICAS"):  # flush replicas of the bin vector (1 .. 64) instead of the engine's choice
+    from mach3_amd.engine import Engine
+    engine = Engine(0)
+    engine._chk(engine.lib.m3hip_debug_set_hist_replicas(engine.h, int(os.environ["M3_GEXP_REPLICAS"])))
+eng, mono, sh, par = build_from_synth(spec, engine=engine)
 sh.Reweight(); sh.AddData(sh.GetMCArray())
 laps = [synth.params(spec, i + 1) for i in range(16)]
 eng.timing_enable(True)

@@ -14,7 +14,9 @@ __global__ __launch_bounds__(1024, 8) void k_runs(const f32x4_t* __restrict__ p,
     f32x4_t v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t ri = r + (size_t)u * 1024, run = ri / quads_per_run, q = ri % quads_per_run;
+      // (a batch may reach past the workgroup's share when that is not a multiple of U x 1024: clamped to the share's end)
+      const size_t end = (size_t)(blockIdx.x + 1) * n_resp_per_block - 1;
+      const size_t rj = r + (size_t)u * 1024, ri = rj < end ? rj : end, run = ri / quads_per_run, q = ri % quads_per_run;
       v[u] = __builtin_nontemporal_load(p + (run * 6 + (size_t)((seg + run) % 3 + 2)) * quads_per_run + q);
     }
 #pragma unroll
@@ -41,5 +43,24 @@ int main() {
     const double read = (double)blocks * n_resp * 16 * iters;
     printf("run %5zu B, %5d blocks: %7.0f GB/s (%.1f us/launch)\n", run_bytes, blocks, read / (ms * 1e-3) / 1e9, ms * 1e3 / iters);
   }
+  // second table: the same stream at a run of 1 KiB, for workgroups that live as long as a brick (16 384 responses = 37 us)
+  // or shorter / longer, and with 5 loads in flight per lane (the brick kernel's depth) instead of 8
+  for (size_t n_resp : {10240, 15360, 30720, 61440})  // multiples of 5 x 1024 (and close to multiples of 8 x 1024: the last batch is clamped)
+    for (int U : {5, 8}) {
+      const size_t qpr = 64;
+      const int blocks = (int)(bytes / 16 / 6 / n_resp);
+      auto launch = [&](int it) {
+        if (U == 5) hipLaunchKernelGGL((k_runs<5>), dim3(blocks), dim3(1024), 0, 0, d, qpr, n_resp, it, out);
+        else hipLaunchKernelGGL((k_runs<8>), dim3(blocks), dim3(1024), 0, 0, d, qpr, n_resp, it, out);
+      };
+      for (int it = 0; it < 2; ++it) launch(it);
+      (void)hipEventRecord(e0, 0);
+      const int iters = 10;
+      for (int it = 0; it < iters; ++it) launch(it);
+      (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+      float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+      const double read = (double)blocks * n_resp * 16 * iters;
+      printf("run 1024 B, %6zu responses per workgroup, %d in flight, %5d blocks: %7.0f GB/s (%.1f us/launch)\n", n_resp, U, blocks, read / (ms * 1e-3) / 1e9, ms * 1e3 / iters);
+    }
   return 0;
 }
