@@ -245,8 +245,8 @@ struct m3hip_ctx {
   double* d_data = nullptr;
   double* d_hist = nullptr;  // [2][hist_rep][n_bins]
   double* d_llh_terms = nullptr;  // split form of k_llh (many bins): per-bin terms [n_bins]
-  int hist_rep = 32;      // flush replicas of the bin vector in use (chosen at set_binning)
-  int hist_rep_cfg = 32;  // ... upper limit
+  int hist_rep = 64;      // flush replicas of the bin vector in use (chosen at set_binning)
+  int hist_rep_cfg = 64;  // ... upper limit
   bool hist_rep_forced = false;  // m3hip_debug_set_hist_replicas: use exactly that many
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
@@ -1101,11 +1101,12 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   HIPCHK(h, hipStreamSynchronize(h->stream));
   dev_free(h->d_sample_off); dev_free(h->d_data); dev_free(h->d_hist); dev_free(h->d_llh_terms);
   h->d_sample_off = nullptr; h->d_data = nullptr; h->d_hist = nullptr; h->d_llh_terms = nullptr;
-  // The replicas spread the adds of thousands of workgroups over more addresses than one bin vector has: 32
-  // copies at 200 bins = 6 400 addresses measured as fast as no contention at all.  More bins spread the adds by
+  // The replicas spread the adds of thousands of workgroups over more addresses than one bin vector has: 64
+  // copies at 200 bins = 12 800 addresses (round 1 settled on 32; round 3's replica sweep on config 3: 1 / 8 / 32 / 64
+  // replicas 850 / 744 / 727.5 / 722 us; config 2 -1 % kernel and step at 64 with the bin likelihood's fold 32 loads deep).  More bins spread the adds by
   // themselves, while the per-step reset (k_prep) and the fold (k_llh) are linear in replicas x bins (118 us of a
   // 132 us step at 7 200 bins with 32 replicas): keep the number of addresses, not the number of replicas.
-  if (!h->hist_rep_forced) h->hist_rep = std::max(1, std::min(h->hist_rep_cfg, 6400 / nb));
+  if (!h->hist_rep_forced) h->hist_rep = std::max(1, std::min(h->hist_rep_cfg, 12800 / nb));
   int rc;
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;

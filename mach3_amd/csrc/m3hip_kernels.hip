@@ -1596,15 +1596,15 @@ void launch_fold_partials(const double* partial, int n_rows, int n_bins, int wit
   hipLaunchKernelGGL(k_fold_final, dim3(bx), dim3(256), 0, s, scratch, n_groups, row_len, hist, hist_rep, n_bins, with_w2);
 }
 
-// sum of one bin over the flush replicas, in replica order (fixed => reproducible), 16 loads in flight
+// sum of one bin over the flush replicas, in replica order (fixed => reproducible), 32 loads in flight
 __device__ __forceinline__ double fold_replicas(const double* base, int hist_rep, int n_bins) {
   double m = 0.0;
-  for (int r0 = 0; r0 < hist_rep; r0 += 16) {
-    double am[16];
+  for (int r0 = 0; r0 < hist_rep; r0 += 32) {
+    double am[32];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
+    for (int u = 0; u < 32; ++u) am[u] = (r0 + u < hist_rep) ? base[(size_t)(r0 + u) * n_bins] : 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) m += am[u];
+    for (int u = 0; u < 32; ++u) m += am[u];
   }
   return m;
 }
