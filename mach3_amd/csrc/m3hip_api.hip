@@ -245,8 +245,10 @@ struct m3hip_ctx {
   double* d_data = nullptr;
   double* d_hist = nullptr;  // [2][hist_rep][n_bins]
   double* d_llh_terms = nullptr;  // split form of k_llh (many bins): per-bin terms [n_bins]
-  int hist_rep = 64;      // flush replicas of the bin vector in use (chosen at set_binning)
+  int hist_rep = 32;      // flush replicas of the bin vector in use (chosen at set_binning, settled at the first reweight)
   int hist_rep_cfg = 64;  // ... upper limit
+  int hist_rep_big = 32;  // ... for samples of many workgroups (allocated for), see set_binning
+  bool hist_rep_locked = false;  // the first reweight has settled it: w2's replicas sit behind mc's, the layout must not move
   bool hist_rep_forced = false;  // m3hip_debug_set_hist_replicas: use exactly that many
   int teststat = M3HIP_kPoisson;
   bool update_w2 = false, first_w2 = true;
@@ -1106,15 +1108,23 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   // replicas 850 / 744 / 727.5 / 722 us; config 2 -1 % kernel and step at 64 with the bin likelihood's fold 32 loads deep).  More bins spread the adds by
   // themselves, while the per-step reset (k_prep) and the fold (k_llh) are linear in replicas x bins (118 us of a
   // 132 us step at 7 200 bins with 32 replicas): keep the number of addresses, not the number of replicas.
-  if (!h->hist_rep_forced) h->hist_rep = std::max(1, std::min(h->hist_rep_cfg, 12800 / nb));
+  // Twice the replicas pay for samples of thousands of workgroups only (config 2: -1 % kernel and step); a small sample's step
+  // is reset + fold (1e5 events: 28 -> 31 us with 64).  Allocated for the larger number, settled at the first reweight.
+  if (!h->hist_rep_forced) {
+    h->hist_rep = std::max(1, std::min(std::min(h->hist_rep_cfg, 32), 6400 / nb));
+    h->hist_rep_big = std::max(h->hist_rep, std::min(h->hist_rep_cfg, 12800 / nb));
+  } else {
+    h->hist_rep_big = h->hist_rep;
+  }
+  h->hist_rep_locked = false;
   int rc;
   if ((rc = dev_alloc(h, &h->d_sample_off, size_t(n_samples) + 1))) return rc;
   if ((rc = dev_alloc(h, &h->d_data, size_t(nb)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2 * h->hist_rep))) return rc;
+  if ((rc = dev_alloc(h, &h->d_hist, size_t(nb) * 2 * h->hist_rep_big))) return rc;
   if (nb > M3_LLH_SPLIT_BINS && (rc = dev_alloc(h, &h->d_llh_terms, size_t(nb)))) return rc;
   HIPCHK(h, hipMemcpy(h->d_sample_off, sample_bin_offset, sizeof(int32_t) * (n_samples + 1), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(h->d_data, 0, sizeof(double) * nb));
-  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep));
+  HIPCHK(h, hipMemset(h->d_hist, 0, sizeof(double) * nb * 2 * h->hist_rep_big));
   if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; }
   HIPCHK(h, hipHostMalloc((void**)&h->h_out, sizeof(double) * (2 + n_samples), hipHostMallocMapped));
   memset(h->h_out, 0, sizeof(double) * (2 + n_samples));
@@ -1829,6 +1839,10 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (!h->mono_done) return fail(h, M3HIP_ESTATE, "reweight before the monolith was uploaded");
   if (h->n_bins == 0) return fail(h, M3HIP_ESTATE, "reweight before set_binning");
   if (!params || n_par <= 0) return fail(h, M3HIP_EINVAL, "reweight: empty parameter vector");
+  if (!h->hist_rep_locked) {  // flush replicas: the larger number for samples of thousands of workgroups (set_binning)
+    if (!h->hist_rep_forced && h->h_tiles.size() + h->h_bricks.size() >= 2048) h->hist_rep = h->hist_rep_big;
+    h->hist_rep_locked = true;
+  }
   if (!h->parmap_set && n_par < h->P) return fail(h, M3HIP_EINVAL, "reweight: parameter vector shorter than the spline parameters");
   if (h->parmap_set && h->max_parmap >= n_par) return fail(h, M3HIP_EINVAL, "reweight: the spline parameter map points past the parameter vector");
   if (h->max_norm_idx >= n_par) return fail(h, M3HIP_EINVAL, "reweight: an event's norm parameter index points past the parameter vector");
