@@ -78,6 +78,19 @@ for c in np.unique(cu):
             (gaps.append((b - a) / 100.0))
             idle1 += (b - a) * (2 - lvl[i])
     idle2 += (2 * (last - last_start) - np.clip(t1[m] - last_start, 0, None).sum())
+# phase of a brick's start inside the lifetime of the brick that shares its CU at that moment (0 / 1: the two run in step,
+# 0.5: one streams while the other is in its prologue or its tail)
+ph = []
+for c in np.unique(cu):
+    m = np.where(cu == c)[0]
+    o = m[np.argsort(t0[m])]
+    for i, b in enumerate(o):
+        for b2 in o[max(0, i - 3):i]:
+            if t0[b2] < t0[b] < t1[b2]:
+                ph.append((t0[b] - t0[b2]) / (t1[b2] - t0[b2]))
+ph = np.array(ph)
+hist_ph, _ = np.histogram(ph, bins=10, range=(0, 1))
+print("  phase of a brick's start inside its CU neighbour's lifetime, tenths: " + " ".join(f"{100 * h / max(1, ph.size):.0f}%" for h in hist_ph))
 print(f"  {ncu} CUs seen; slot-time idle between a CU's workgroups {100 * idle1 / (2 * ncu * span):.1f} % of all slot time "
       f"(gap mean {np.mean(gaps) if gaps else 0:.2f} us, median {np.median(gaps) if gaps else 0:.2f} us, {len(gaps)} gaps); "
       f"idle behind a CU's last start (tail) {100 * idle2 / (2 * ncu * span):.1f} %; ramp (first start after launch start) "
