@@ -4,6 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms run N ranks: started WITHOUT a launcher (WORLD_SIZE unset) and N > 1, this process only starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a
+child -- decided before torch or anything else that could touch a GPU is imported -- and relays rank 0's JSON line and the
+exit code.  Under a launcher whose WORLD_SIZE differs from --gpus it exits with code 2: a line must never report another N
+than the one it was asked for.  `config.ranks_seen` is the sum of ones over the ranks that took part.
+
 A step = one pass of the hot path over one batch of synthetic MC:
     new parameter vector -> SampleHandlerFD::Reweight() -> GetLikelihood() -> LLH on the host
 (the pair MR2T2::ProposeStep runs per proposal, ref: Fitters/MR2T2.cpp:66-76), timed
@@ -28,6 +34,58 @@ import json
 import os
 import sys
 import time
+
+
+def _gpus_arg(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: run the N ranks as fresh children of THIS process
+    (which never imports torch, never touches a GPU and never execs), pass rank 0's line through and leave with the
+    children's exit code.  Under a launcher, refuse a WORLD_SIZE that is not --gpus."""
+    try:
+        want = _gpus_arg(sys.argv[1:])
+    except ValueError:
+        return  # argparse reports it
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != want and os.environ.get("M3_BENCH_FORCE_COMM") != "1":
+            print(f"bench.py: --gpus {want} but the launcher started WORLD_SIZE={world} ranks; refusing to report a line for another N", file=sys.stderr)
+            raise SystemExit(2)
+        return
+    if want <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(want), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {want} without a launcher: starting {want} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr is inherited: progress shows as it happens
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
+        raise SystemExit(5)
+    raise SystemExit(r.returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
 
 # host thread pools sized to one GPU's CPU share (the reference recommends 8, allows 16 threads:
 # Manager/Monitor.cpp:122-138); must be set before any OpenMP runtime initialises
@@ -78,13 +136,14 @@ def pmc_traffic(config_name, per_gpu):
 EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "2"))  # a 20-step driver run times 10 launches
 
 
-def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
+def cpu_baseline(spec, budget_s=15.0, sample_events=300_000):
     """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events` events of
     the same configuration; steps/s scaled to the full event count.  The big arrays are first touched
     inside OpenMP loops with the compute loops' static schedule (m3o_monolith_localise, HomedArray),
     threads bound to cores, so a multi-socket host is not handicapped by single-node page placement.
     Timed DragRace style at 8, 16 (the most the reference uses unless OMP_NUM_THREADS is exported,
-    Manager/Monitor.cpp:122-138) and, on bigger hosts, the physical cores; the best point is `value`."""
+    Manager/Monitor.cpp:122-138), 32, 64 and the physical cores as far as the host has them; the best point is `value`,
+    the 16-thread point is reported beside it (`at_16_threads`).  Everything in `sample` was measured by this run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from mach3_amd import synth
@@ -93,7 +152,7 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
     lib = ob.load("omp")
     cores = os.cpu_count() or 1
     physical = max(1, cores // 2) if cores >= 32 else cores  # SMT hosts of the pool: two hardware threads per core
-    sweep_threads = sorted({t for t in (8, 16, min(physical, 128)) if t <= cores} or {cores})
+    sweep_threads = sorted({t for t in (8, 16, 32, 64, min(physical, 128)) if t <= min(cores, physical)} or {cores})
     lib.m3o_set_num_threads(max(sweep_threads))  # first touch with the widest team: pages spread over all its nodes
     mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp", localise=True)
     samp.reweight()
@@ -126,9 +185,10 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
 
     runs = [run(t, budget_s / len(sweep_threads), 4000) for t in sweep_threads]
     best = max(runs, key=lambda r: r["steps_per_s"])
+    at16 = next((r for r in runs if r["threads"] == 16), None)
     samp.close()
     mono.close()
-    return {
+    out = {
         "value": best["steps_per_s"],
         "unit": "steps/s",
         "cores": best["threads"],
@@ -136,12 +196,18 @@ def cpu_baseline(spec, budget_s=12.0, sample_events=300_000):
         "sample": f"first {n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
                   f"{best['threads']} threads ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
                   f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; arrays first-touched in "
-                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}; one FULL-SIZE lap of "
-                  f"this build on record (all 1e7 events of configs[2], 16 threads, profiles/r03_cpu_full_c3.log): 161.6 ms = 0.970 of the "
-                  f"event-scaled 3e5-event sample measured in the same process",
+                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}; thread sweep "
+                  f"{', '.join(str(r['threads']) for r in runs)}, {budget_s / len(sweep_threads):.1f} s each",
         "steps_per_s_by_threads": {str(r["threads"]): r["steps_per_s"] for r in runs},
         "host_cores": cores,
     }
+    if at16 is not None:  # the reference's own thread cap (Manager/Monitor.cpp:122-138)
+        out["at_16_threads"] = {"value": at16["steps_per_s"], "unit": "steps/s", "ms_per_lap": at16["ms_per_lap"], "laps": at16["laps"]}
+    if spec.name == "c3" and spec.n_events == 10_000_000:
+        # NOT measured by this run: one full-size lap on record, which backs the scaling by events (another host, round 3)
+        out["full_lap_on_record"] = {"file": "profiles/r03_cpu_full_c3.log", "ms": 161.6, "threads": 16, "ratio_to_event_scaled_sample": 0.970,
+                                     "host": "the box of that log (round 3), not this run's"}
+    return out
 
 
 def shard_of(spec, rank, n_ranks, tdist=None):
@@ -486,8 +552,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if world != args.gpus and os.environ.get("M3_BENCH_FORCE_COMM") != "1":  # (_self_launch has seen to it; kept for imports of main())
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(2)
     n_gpus = world
     n_dev = torch.cuda.device_count()
     if local_rank >= n_dev:
@@ -513,6 +580,11 @@ def main():
     spec = base.scaled(args.events) if args.events else base
 
     m = measure(spec, rank, n_gpus, local_rank, args, dist, torch, args.allow_host_fallback)
+    ranks_seen = 1
+    if dist is not None:  # every rank that measured adds one
+        one = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
 
     check = None
     if args.check and n_gpus > 1:
@@ -544,6 +616,7 @@ def main():
             "config": {
                 "workload": workload_text(base, spec, n_gpus),
                 "total_events": spec.n_events,
+                "ranks_seen": ranks_seen,
                 # the job's work rate, comparable across the two workloads the N-series uses (N <= 2: configs[2], 1e7
                 # events; N = 4, 8: configs[3], 4e7 events): scaling efficiency across that switch is the ratio of THESE
                 "event_steps_per_s": spec.n_events * args.steps / m["el"],

@@ -353,12 +353,19 @@ int m3hip_comm_set_validate(m3hip_handle h, int on);
  *   m3hip_xch_create  after the bin space is defined; allocates this rank's buffer, returns its IPC handle
  *   m3hip_xch_open    handles of all ranks in rank order (this rank's own entry is ignored); from here on
  *                     m3hip_reweight / m3hip_step exchange through the buffers instead of RCCL
- * A peer that never pushes (a dead rank) is reported after 2 s as M3HIP_ECOMM by m3hip_get_likelihood / m3hip_step;
- * nothing on the device waits for ever.  The reference has no counterpart (one device: Manager/gpuUtils.cu:71). */
+ *   m3hip_xch_set_timeout  how long a rank waits for its peers' vectors of a step (default 2 s; also M3HIP_XCH_TIMEOUT_S
+ *                     in the environment of m3hip_xch_create).  Choose it above the largest host-side skew between two
+ *                     ranks of one step (chain output, checkpoints, a new throw matrix).
+ * A peer that does not push in time (a dead rank) is reported as M3HIP_ECOMM by whichever call reads the step's bins next
+ * (m3hip_get_likelihood / m3hip_step / m3hip_get_bins); nothing on the device waits for ever.  The rank then holds its own
+ * PARTIAL bins while its peers may have completed the step: M3HIP_ECOMM from the exchange is fatal for the whole group
+ * (stop every rank; there is no resynchronisation).  A slot that already carries a LATER step -- this rank fell a whole
+ * step behind -- is the same error.  The reference has no counterpart (one device: Manager/gpuUtils.cu:71). */
 #define M3HIP_XCH_HANDLE_BYTES 64
 int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out /* M3HIP_XCH_HANDLE_BYTES */);
 int m3hip_xch_open(m3hip_handle h, const void* handles /* n_ranks x M3HIP_XCH_HANDLE_BYTES */);
 int m3hip_xch_destroy(m3hip_handle h);
+int m3hip_xch_set_timeout(m3hip_handle h, double seconds);
 int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n_checked);
 
 /* ------------------------------------------------------------------------------------

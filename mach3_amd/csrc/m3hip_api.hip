@@ -212,7 +212,8 @@ struct m3hip_ctx {
   std::vector<std::pair<uint64_t, std::vector<uint32_t>>> grouped;  // (first event, order) of every grouped chunk
   bool perm_monolith = false;     // some chunk was grouped
   int brick_groups = 0;           // G of this monolith's bricks (m3hip_layout.h); 0 until the first chunk with ragged events fixes it
-  uint64_t expect_events = 0;     // m3hip_monolith_expect_events: the events this device will hold (0: unknown)
+  uint64_t expect_events = 0;     // m3hip_monolith_expect_events: the events this device will hold (0: unknown); taken by the next monolith_begin
+  uint64_t upload_expect = 0;     // ... the hint of the upload in progress
   uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
@@ -276,6 +277,7 @@ struct m3hip_ctx {
   int xch_ranks = 0, xch_rank = 0, xch_slot = 0;  // slot: doubles per slot (2 * n_bins + 2)
   bool xch_active = false;
   uint64_t xch_step = 0;
+  double xch_timeout_s = 2.0;     // every ticket spin of k_xch gives up after this long (m3hip_xch_set_timeout, M3HIP_XCH_TIMEOUT_S)
   uint64_t* h_xch_status = nullptr;  // mapped pinned host word (0: fine; else the step whose tickets did not arrive)
   uint64_t* d_xch_status = nullptr;
   unsigned long long* d_xch_pushed = nullptr;  // this rank's finished push blocks (n_ranks per step)
@@ -285,6 +287,7 @@ struct m3hip_ctx {
   uint64_t timing_ctr = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // reweight dispatch start / end; marker in front of k_llh (exchange gap)
   bool gap_pending = false;       // this step's reweight launch was timed and an exchange followed it
+  bool gap_recorded = false;      // ... and ev2 has been recorded for it (m3hip_get_likelihood)
   int pending = -1;
   double acc_ms[3] = {0, 0, 0};   // [0] fused reweight kernel, [1] seam-2 evaluation, [2] reweight end -> k_llh ready (fold + all-reduce + unpark)
   uint64_t cnt[3] = {0, 0, 0};
@@ -357,6 +360,21 @@ hipError_t wait_stream(hipStream_t s) {
   }
 }
 
+// The one-shot exchange's verdict on the last step (the stream is idle up to that step's k_xch).  The status word holds
+// step << 1 | kind: kind 0 = a ticket did not arrive within the time-out, 1 = a slot already carried a LATER step (this
+// rank fell more than a whole step behind its peers and their data of this step is gone).  Either way the bins on this
+// rank are its own partial sums and the GROUP has diverged: M3HIP_ECOMM from the exchange is fatal for every rank.
+int xch_check(m3hip_handle h) {
+  if (!h->xch_active || !h->h_xch_status || !*h->h_xch_status) return M3HIP_OK;
+  const uint64_t st = *h->h_xch_status;
+  *h->h_xch_status = 0;
+  if (st & 1u)
+    return fail(h, M3HIP_ECOMM, "one-shot exchange: a peer's slot already holds a later step than " + std::to_string(st >> 1) +
+                                    " (this rank fell a whole step behind; the group has diverged)");
+  return fail(h, M3HIP_ECOMM, "one-shot exchange: a peer's bin vector of step " + std::to_string(st >> 1) + " did not arrive within " +
+                                  std::to_string(h->xch_timeout_s) + " s (the group has diverged)");
+}
+
 void collect_timing(m3hip_handle h) {
   if (h->pending >= 0) {
     float ms = 0.f;
@@ -364,11 +382,11 @@ void collect_timing(m3hip_handle h) {
       h->acc_ms[h->pending] += ms;
       h->cnt[h->pending]++;
     }
-    if (h->gap_pending && hipEventElapsedTime(&ms, h->ev1, h->ev2) == hipSuccess) {
+    if (h->gap_pending && h->gap_recorded && hipEventElapsedTime(&ms, h->ev1, h->ev2) == hipSuccess && ms >= 0.f) {
       h->acc_ms[2] += ms;
       h->cnt[2]++;
     }
-    h->gap_pending = false;
+    h->gap_pending = h->gap_recorded = false;
     h->pending = -1;
   }
 }
@@ -698,6 +716,8 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_monolith(h);
+  h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
+  h->expect_events = 0;
   h->P = n_params;
   h->K = max_knots;
   h->h_npts.assign(npts, npts + n_params);
@@ -782,7 +802,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
   // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
-  if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->expect_events);
+  if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->upload_expect);
   const int G = h->brick_groups;
   if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err, G)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
@@ -973,7 +993,7 @@ int m3hip_monolith_end(m3hip_handle h) try {
   }
   for (uint64_t t = 0; t < n_tiles; ++t) h->h_tiles[t].res = h->d_resolved + h->tile_res_off[t];
   for (size_t b = 0; b < h->h_bricks.size(); ++b) h->h_bricks[b].tf1_x = h->d_resolved + h->brick_res_off[b];
-  h->expect_events = 0;  // the hint belongs to this upload
+  h->upload_expect = 0;
   h->list_index.clear();
   if ((rc = dev_alloc(h, &h->d_bricks, h->h_bricks.size()))) return rc;
   if (!h->h_bricks.empty())
@@ -1006,6 +1026,7 @@ int m3hip_upload_monolith(m3hip_handle h, uint64_t n_events, int n_params, int m
                           const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                           const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
                           const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) try {
+  if (h && h->expect_events == 0) h->expect_events = n_events;  // the one-call upload knows its size
   int rc = m3hip_monolith_begin(h, n_params, max_knots, coeff_x, npts);
   if (rc) return rc;
   rc = m3hip_monolith_append(h, n_events, coeff_many, total_nknots, nknots_arr, param_no, n_splines, coeff_tf1,
@@ -1154,7 +1175,11 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   h->evw_dirty = true;
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   if (osc_idx) {
-    for (uint64_t i = 0; i < n; ++i) h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
+    for (uint64_t i = 0; i < n; ++i) {
+      // -1 = no oscillation weight; anything below would run into the packed sample word's neighbouring fields (k_pack_events)
+      if (osc_idx[i] < -1) return fail(h, M3HIP_EINVAL, "upload_events: oscillation index below -1");
+      h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
+    }
     HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   }
   if (norm_off) {
@@ -1585,7 +1610,6 @@ int m3hip_compute_bins(m3hip_handle h) try {
   b.n_shifts = 0;
   launch_find_bins(b, h->stream);
   h->evw_dirty = true;  // d_bin is rewritten
-  h->max_bin_idx = std::max<int64_t>(h->max_bin_idx, int64_t(h->n_bins) - 1);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, wait_stream(h->stream));
   h->bins_computed = true;
@@ -2037,6 +2061,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     }
     mode |= kModeEventW | kModeEval;
   }
+  h->gap_pending = h->gap_recorded = false;  // a gap belongs to the step whose reweight set it
   // sampled launches carry two events that receive the dispatch's own start / end timestamps
   const bool timed = h->timing > 0 && (h->timing_ctr++ % uint64_t(h->timing)) == 0;
   const uint32_t n_tiles = uint32_t(h->h_tiles.size()), n_bricks = uint32_t(h->h_bricks.size());
@@ -2075,7 +2100,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     const int n_msg = h->n_bins * (with_w2 ? 2 : 1);
     const uint64_t step = ++h->xch_step;
     launch_xch(h->d_hist, h->d_hist, n_msg, h->d_xch_targets + size_t(step & 1) * h->xch_ranks, h->xch_ranks,
-               h->xch_own + size_t(step & 1) * h->xch_ranks * h->xch_slot, h->xch_slot, step, h->d_xch_status, h->d_xch_pushed, h->stream);
+               h->xch_own + size_t(step & 1) * h->xch_ranks * h->xch_slot, h->xch_slot, step, h->d_xch_status, h->d_xch_pushed,
+               uint64_t(h->xch_timeout_s * 1e8), h->stream);
     if (parked) launch_unpark_w2(h->d_hist, h->hist_rep, h->n_bins, h->stream);
     h->gap_pending = timed && (n_tiles || n_bricks);
   } else if (h->comm) {  // also with one rank: the communicator is exercised exactly as with N
@@ -2128,7 +2154,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   l.ticket = ++h->llh_ticket;
   l.dbg_clock = h->d_dbg_clock;
   const double t_a = now_s();
-  if (h->gap_pending) (void)hipEventRecord(h->ev2, h->stream);  // sampled steps with an exchange: reweight end -> here
+  if (h->gap_pending) h->gap_recorded = hipEventRecord(h->ev2, h->stream) == hipSuccess;  // sampled steps with an exchange: reweight end -> here
   launch_llh(l, h->stream);
   if (l.w2_mode == kW2FoldInPlace) h->w2_spread = false;
   HIPCHK(h, hipGetLastError());
@@ -2153,11 +2179,7 @@ int m3hip_get_likelihood(m3hip_handle h, double* llh_total, double* per_sample) 
   // HIP command list only grows and a later launch stalls for ~1 ms when it has to be trimmed.
   (void)hipStreamQuery(h->stream);
   h->ticket_done = h->ticket;  // everything submitted before k_llh has completed (stream order)
-  if (h->xch_active && h->h_xch_status && *h->h_xch_status) {
-    const uint64_t late = *h->h_xch_status;
-    *h->h_xch_status = 0;
-    return fail(h, M3HIP_ECOMM, "one-shot exchange: a peer's bin vector of step " + std::to_string(late) + " did not arrive within 2 s");
-  }
+  if (int rc_x = xch_check(h)) return rc_x;
   const double t_c = now_s();
   h->host_abs[1] = t_c;
   collect_timing(h);
@@ -2182,6 +2204,7 @@ int m3hip_get_bins(m3hip_handle h, double* mc, double* w2, int n_bins) try {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
+  if (int rc_x = xch_check(h)) return rc_x;  // a timed-out exchange leaves this rank's PARTIAL bins in d_hist
   // replicas are folded in replica order, exactly as k_llh does
   std::vector<double> tmp(size_t(n_bins) * 2 * h->hist_rep);
   HIPCHK(h, hipMemcpy(tmp.data(), h->d_hist, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
@@ -2333,6 +2356,12 @@ int m3hip_xch_destroy(m3hip_handle h) try {
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
+int m3hip_xch_set_timeout(m3hip_handle h, double seconds) try {
+  if (!h || !(seconds > 0.0) || seconds > 3600.0) return fail(h, M3HIP_EINVAL, "xch_set_timeout: between 0 and 3600 s");
+  h->xch_timeout_s = seconds;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
 int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) try {
   if (!h || !handle_out) return M3HIP_EINVAL;
   if (n_ranks < 1 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return fail(h, M3HIP_EINVAL, "xch_create: bad rank / n_ranks");
@@ -2342,6 +2371,10 @@ int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) tr
   m3hip_xch_destroy(h);
   h->xch_ranks = n_ranks;
   h->xch_rank = rank;
+  if (const char* f = getenv("M3HIP_XCH_TIMEOUT_S")) {
+    const double v = atof(f);
+    if (v > 0.0 && v <= 3600.0) h->xch_timeout_s = v;
+  }
   h->xch_slot = 2 * h->n_bins + 2;
   const size_t bytes = sizeof(double) * 2 * size_t(n_ranks) * size_t(h->xch_slot);
   // fine-grained: a peer's stores must become visible INSIDE a running kernel (coarse-grained memory only promises

@@ -282,7 +282,7 @@ void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t
 // tickets of the parity carry the step number.  `status` (mapped host word): set to the step number when a ticket did not
 // arrive within the time-out, so that the host can report it instead of waiting for ever.
 void launch_xch(const double* src, double* dst, int n_msg, double* const* targets, int n_ranks, const double* slots, int slot_doubles, uint64_t step,
-                uint64_t* status, unsigned long long* pushed, hipStream_t s);
+                uint64_t* status, unsigned long long* pushed, uint64_t timeout_ticks, hipStream_t s);
 void launch_fold_hist(double* hist, int hist_rep, int n_bins, int with_w2, int park_w2, hipStream_t s);
 void launch_unpark_w2(double* hist, int hist_rep, int n_bins, hipStream_t s);
 // deterministic mode: ordered sum of the workgroups' rows into replica 0, 32 rows at a time (scratch: ceil(n_rows / 32) rows)

@@ -1332,7 +1332,10 @@ void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
 // k_xch, block N (pull): acquire-loads the N tickets of the parity in this rank's OWN buffer until all carry the step number, then
 // adds the N vectors in rank order -- bit-identical bins on every rank by construction.
 // Two parities suffice: a rank pushes step t+2 only after its pull of t+1, which needed every peer's push of t+1, which
-// each peer issued behind its own pull of t on its stream.  Every spin has a time-out (2 s of the 100 MHz clock).
+// each peer issued behind its own pull of t on its stream.  Every spin has a time-out (`timeout_ticks` of the 100 MHz clock;
+// 2 s unless m3hip_xch_set_timeout says otherwise).  A ticket must EQUAL the step: a slot that already carries a later step
+// means this rank fell a whole step behind (host skew beyond the time-out on the peers' side) and the data is gone -- an error,
+// not a match.
 // ------------------------------------------------------------------------------------
 // A slot is [2 * n_bins data | ticket | pad]: the ticket has a fixed place whatever the length of the step's message.
 // push and pull as ONE launch: blocks 0 .. N-1 push, block N pulls (its own rank's push is one of the tickets it waits for;
@@ -1340,8 +1343,9 @@ void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
 // `pushed`: counts this rank's finished push blocks (monotonic: n_ranks per step); the pull block overwrites the vector the
 // push blocks read from, so it also waits for all of them.
 __global__ __launch_bounds__(256) void k_xch(const double* src, double* dst, int n_msg, double* const* targets, int n_ranks,
-                                             const double* slots, int slot_doubles, uint64_t step, uint64_t* status, unsigned long long* pushed) {
-  __shared__ int late;
+                                             const double* slots, int slot_doubles, uint64_t step, uint64_t* status, unsigned long long* pushed,
+                                             uint64_t timeout_ticks) {
+  __shared__ int late;  // 1: a ticket did not arrive in time; 2: a slot holds a later step
   if ((int)blockIdx.x < n_ranks) {
     double* t = targets[blockIdx.x];
     for (int i = threadIdx.x; i < n_msg; i += 256) __hip_atomic_store(&t[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1359,11 +1363,19 @@ __global__ __launch_bounds__(256) void k_xch(const double* src, double* dst, int
     const uint64_t t0 = wall_clock64();
     for (;;) {
       bool there;
-      if (r < n_ranks) there = __hip_atomic_load((const uint64_t*)(slots + (size_t)r * slot_doubles + (slot_doubles - 2)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= step;
-      else there = __hip_atomic_load(pushed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)n_ranks * step;
+      if (r < n_ranks) {
+        const uint64_t tk = __hip_atomic_load((const uint64_t*)(slots + (size_t)r * slot_doubles + (slot_doubles - 2)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tk > step) {
+          late = 2;
+          break;
+        }
+        there = tk == step;
+      } else {
+        there = __hip_atomic_load(pushed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)n_ranks * step;
+      }
       if (there) break;
-      if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer that never pushed must not hang the device
-        late = 1;
+      if (wall_clock64() - t0 > timeout_ticks) {  // a peer that never pushed must not hang the device
+        atomicMax(&late, 1);
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -1371,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_xch(const double* src, double* dst, int
   }
   __syncthreads();
   if (late) {
-    if (threadIdx.x == 0) __hip_atomic_store(status, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(status, (step << 1) | (late == 2 ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // src == dst: every push block of this rank has finished reading src (lane N above), so it may be overwritten
@@ -1382,8 +1394,8 @@ __global__ __launch_bounds__(256) void k_xch(const double* src, double* dst, int
   }
 }
 void launch_xch(const double* src, double* dst, int n_msg, double* const* targets, int n_ranks, const double* slots, int slot_doubles, uint64_t step,
-                uint64_t* status, unsigned long long* pushed, hipStream_t s) {
-  hipLaunchKernelGGL(k_xch, dim3(n_ranks + 1), dim3(256), 0, s, src, dst, n_msg, targets, n_ranks, slots, slot_doubles, step, status, pushed);
+                uint64_t* status, unsigned long long* pushed, uint64_t timeout_ticks, hipStream_t s) {
+  hipLaunchKernelGGL(k_xch, dim3(n_ranks + 1), dim3(256), 0, s, src, dst, n_msg, targets, n_ranks, slots, slot_doubles, step, status, pushed, timeout_ticks);
 }
 
 // ------------------------------------------------------------------------------------

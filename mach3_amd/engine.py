@@ -122,6 +122,9 @@ class Engine:
         assert len(blob) % capi.XCH_HANDLE_BYTES == 0
         self._chk(self.lib.m3hip_xch_open(self.h, C.c_char_p(blob)))
 
+    def xch_set_timeout(self, seconds: float):
+        self._chk(self.lib.m3hip_xch_set_timeout(self.h, C.c_double(seconds)))
+
     def xch_destroy(self):
         self._chk(self.lib.m3hip_xch_destroy(self.h))
 

@@ -132,3 +132,14 @@ def test_bench_shards_cover_the_sample_and_balance_the_responses():
         loads = [sum(synth.count(spec, a, b)) for a, b in r]
         assert max(loads) / min(loads) < 1.02, loads
     assert bench.shard_of(spec, 0, 1) == (0, spec.n_events)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """under a launcher, `--gpus N` with another WORLD_SIZE is an error (exit code 2), not a warning and a line for the wrong N;
+    decided before anything touches a GPU, so it runs here"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""

@@ -196,8 +196,15 @@ def test_one_shot_exchange_reports_a_missing_peer(fresh_engine):
                 time.sleep(0.05)
                 assert time.time() - t0 < 80 and peer.poll() is None, peer.stdout.read().decode() if peer.poll() is not None else "peer too slow"
             eng.xch_open([h0, open(os.path.join(tmp, "handle1"), "rb").read()])
-            with pytest.raises(capi.M3HipError, match="did not arrive"):
+            eng.xch_set_timeout(0.5)
+            t1 = time.time()
+            with pytest.raises(capi.M3HipError, match="did not arrive within 0.5"):
                 sh.Step()
+            assert time.time() - t1 < 1.9, "the configured time-out, not the 2 s default"
+            # the Reweight -> GetMCArray flow must not hand out this rank's partial bins either
+            sh.Reweight()
+            with pytest.raises(capi.M3HipError, match="did not arrive"):
+                sh.GetMCArray()
             eng.xch_destroy()
         finally:
             open(os.path.join(tmp, "done"), "w").write("x")
@@ -225,6 +232,24 @@ def test_bench_ranks_on_one_card_with_check(n_ranks):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == n_ranks and "one-shot" in line["config"]["comm"]
+    assert line["config"]["ranks_seen"] == n_ranks
     assert ("configs[2]" if n_ranks == 2 else "configs[3]") in line["config"]["workload"]
     assert line["check"]["ok"] and line["check"]["max_rel_diff"] <= 1e-9
     assert line["config"]["events_per_gpu"] < n_events and line["roofline"]["avg_kernel_ms_by_rank"]["min"] > 0
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the process starts the two ranks itself as
+    fresh children (it never touches the GPU), relays rank 0's line, and the line says two ranks took part -- the first
+    multi-GPU contact must not silently measure one GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(M3_BENCH_BACKEND="gloo", M3_BENCH_EXCHANGE="oneshot", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--events", "200000", "--steps", "6", "--warmup", "2",
+                        "--spinup-seconds", "0.3", "--check"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # ONE line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2
+    assert line["check"]["ok"]
