@@ -54,7 +54,7 @@ examples: build/mr2t2_dragrace build/facade_check build/c5_step_loop build/libm3
 # C shim over the header-only facade for the CPU tests (links libm3hip.so only for the symbols the headers reference)
 build/libm3facade_test.so: tests/cpp/facade_shim.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so
 	@mkdir -p build
-	g++ -std=c++17 -O2 -fPIC -shared -ffp-contract=off -Wall -Wextra -Iinclude -o $@ tests/cpp/facade_shim.cpp -L$(LIBDIR) -lm3hip \
+	g++ -std=c++17 -O2 -fPIC -shared -fopenmp -ffp-contract=off -Wall -Wextra -Iinclude -o $@ tests/cpp/facade_shim.cpp -L$(LIBDIR) -lm3hip \
 	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 # the reference's own SMonolithGPU call sites against the facade (tests/test_cpp_facade.py)

@@ -3,17 +3,20 @@
 // with every host phase of the step timed beside the GPU's: how much of a step is the O(nPar^2) host side?
 //   propose   ParameterHandlerBase::ProposeStep   (Cholesky-correlated throw, ParameterHandlerBase.cpp:652-745)
 //   launch    bounds (:844-856) + m3hip_reweight: the sample's step is only launched
-//   under     prior 0.5 d^T V^-1 d (:816-841), the Haario update left from the previous step (AdaptiveMCMCHandler.cpp:332-397) and the
-//             correlated throw of the NEXT proposal (:690-745; it does not depend on where the chain stands), while the device works
+//   under     while the device works: the Haario update left from the previous step (AdaptiveMCMCHandler.cpp:332-397; a team of
+//             at most 8 threads) and the random vector of the NEXT proposal.  The two O(nPar^2) sweeps -- the prior
+//             0.5 d^T V^-1 d (:816-841) and the next proposal's correlated throw L z (:726-745) -- run on the DEVICE beside the
+//             sample's kernels (ParameterHandlerBase::AttachDevice -> m3hip_par_*; `host` as 6th argument keeps them on the host)
 //   wait      m3hip_get_likelihood: the rest of the GPU step
 //   accept    acceptance test, AcceptStep; every `update_step` steps the Haario update runs here, with a new Cholesky factor
 // The sample goes up through the C ABI in generator-sized chunks (the MasterSpline object form of such a sample would
-// need 100 GB of pointers).  usage: c5_step_loop [events=12500000] [steps=300] [update_step=100]
+// need 100 GB of pointers).  usage: c5_step_loop [events=12500000] [steps=4000] [update_step=200] [start_throw=3000] [device|host]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../include/m3hip.h"
@@ -34,6 +37,7 @@ int main(int argc, char** argv) {
   // parameters: the throw matrix follows it from this step on (before, every update would be made decomposable by
   // diagonal shifts, as the reference does, and propose along the few directions visited so far)
   const int StartThrow = argc > 4 ? std::atoi(argv[4]) : 3000;
+  const bool on_device = !(argc > 5 && std::string(argv[5]) == "host");
   m3synth_config cfg{};  // mach3_amd/synth.py: CONFIGS["c5"]
   cfg.seed = 20260318; cfg.n_params = 1024; cfg.n_knots = 7; cfg.mixed = 1; cfg.n_norm = 16; cfg.max_norm_per_event = 3;
   cfg.n_samples = 1; cfg.n_bins = 200; cfg.osc_n = 4000 + 200000; cfg.occupancy = 1.0 / 64; cfg.bin_lo = 0.0; cfg.bin_hi = 5.0;
@@ -106,6 +110,7 @@ int main(int argc, char** argv) {
   ParameterHandlerBase par("c5_pars", prefit, cov, lo, up, {}, 12345);
   par.SetStepScale(0.3 * par.GetGlobalStepScale());
   par.InitialiseAdaption(0, 1 << 30, StartThrow, UpdateStep);
+  if (on_device) par.AttachDevice(h);
   std::printf("parameter handler for %d parameters (inverse + Cholesky of the prior covariance): %.2f s\n", nPar, now_s() - t_ph);
 
   // Asimov data at the prior centre (Fitters/MaCh3Factory.h:142-153)
@@ -135,9 +140,12 @@ int main(int argc, char** argv) {
     const bool out_of_bounds = par.CheckBounds() > 0;  // MR2T2.cpp:62: a proposal outside the bounds never reaches the samples
     if (!out_of_bounds) CK(m3hip_reweight(h, par.GetParPropVec().data(), nPar));
     const double c = now_s();
-    double logLProp = par.GetLikelihood();
+    const bool dev_step = on_device && !out_of_bounds;
+    double logLProp = 0.0;
+    if (dev_step) par.LaunchDeviceStep();  // prior of this proposal + the next proposal's throw, enqueued beside the sample's kernels
+    else logLProp = par.GetLikelihood();
     par.FinishPendingAdaption();
-    par.PrepareNextThrow();
+    if (!dev_step) par.PrepareNextThrow();
     const double d = now_s();
     if (!out_of_bounds) {
       CK(m3hip_get_likelihood(h, &llh, nullptr));
@@ -145,6 +153,7 @@ int main(int argc, char** argv) {
     } else {
       ++oob;
     }
+    if (dev_step) logLProp += par.CollectDeviceStep();
     const double e = now_s();
     const double accProb = out_of_bounds ? 0.0 : std::min(1.0, std::exp(logLCurr - logLProp));
     if (!(unif(rng) > accProb)) {
@@ -160,9 +169,10 @@ int main(int argc, char** argv) {
   const double el = now_s() - t0;
   const double us = 1e6 / NSteps;
   std::printf("%d steps in %.3f s = %.0f steps/s (%.1f us/step); acceptance %.2f, out of bounds %d\n", NSteps, el, NSteps / el, el * us, double(accepted) / NSteps, oob);
-  std::printf("per step: propose %.1f us | bounds + launch %.1f us | prior + Haario update + next step's correlated throw UNDER the GPU step %.1f us | rest of the wait for the "
+  std::printf("prior and correlated throw on the %s\n", on_device ? "DEVICE (m3hip_par_*)" : "host");
+  std::printf("per step: propose %.1f us | bounds + launch %.1f us | host work UNDER the GPU step (Haario update, next random vector%s) %.1f us | rest of the wait for the "
               "likelihood %.1f us | accept (+ a new Cholesky factor every %d steps from step %d on) %.1f us, worst %.1f us\n",
-              t_prop * us, t_launch * us, t_under * us, t_wait * us, UpdateStep, StartThrow, t_acc * us, t_acc_max * 1e6);
+              t_prop * us, t_launch * us, on_device ? "; launch of the prior + throw kernels" : ", prior, correlated throw", t_under * us, t_wait * us, UpdateStep, StartThrow, t_acc * us, t_acc_max * 1e6);
   const double exposed = t_prop + t_acc, gpu = t_launch + t_under + t_wait;
   std::printf("host work on the step's critical path %.1f us = %.1f %% of the step; the GPU step spans %.1f us, of which the host computed during %.1f us\n",
               exposed * us, 100.0 * exposed / (exposed + gpu), gpu * us, t_under * us);

@@ -369,6 +369,24 @@ int m3hip_xch_set_timeout(m3hip_handle h, double seconds);
 int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n_checked);
 
 /* ------------------------------------------------------------------------------------
+ * The parameter handler's O(nPar^2) work of a Metropolis step, on the device (the callers of the hot
+ * path; at the 1 040 parameters of BASELINE configs[4] these sweeps take longer on one host core than the GPU's step).
+ *   m3hip_par_upload(which = 0)  InvCovMatrix, nPar x nPar row-major (lower triangle read)
+ *   m3hip_par_upload(which = 1)  the lower Cholesky factor of the throw matrix (ParameterHandlerBase::SetThrowMatrix,
+ *                                Parameters/ParameterHandlerBase.cpp:1140-1200); again whenever the adaptive proposal replaces it
+ *   m3hip_par_launch             enqueue, without waiting: the prior term 0.5 d^T V^-1 d of ParameterHandlerBase::CalcLikelihood
+ *                                (Parameters/ParameterHandlerBase.cpp:816-841; d = proposed - prior value, 0 where the prior is
+ *                                flat) and the correlated throw L z of CorrelateSteps (:726-745, M3::MatrixVectorMulti,
+ *                                Parameters/ParameterHandlerUtils.h:118-135; z = the random vector of Randomize, :690-707, drawn
+ *                                on the host).  Runs on a stream of its own beside the step's reweight kernel.
+ *   m3hip_par_result             waits for the last launch; prior and corr_throw[nPar].  Fixed summation order: reproducible,
+ *                                equal to the host loops up to fp64 rounding.
+ * include/mach3_amd/Fitters.h: ParameterHandlerBase::AttachDevice uses these. */
+int m3hip_par_upload(m3hip_handle h, int which, const double* matrix, int n);
+int m3hip_par_launch(m3hip_handle h, const double* d, const double* z, int n);
+int m3hip_par_result(m3hip_handle h, double* prior, double* corr_throw, int n);
+
+/* ------------------------------------------------------------------------------------
  * Introspection / measurement
  * ---------------------------------------------------------------------------------- */
 typedef struct {

@@ -25,8 +25,10 @@
 #include "Core.h"
 #include "SampleHandlerFD.h"
 
-// OpenMP is optional for the host driver: with -fopenmp the quadratic loops are vectorised and the Haario update threaded
+// OpenMP is optional for the host driver: with -fopenmp the quadratic loops are vectorised and the Haario update runs on a
+// small team (SetAdaptionThreads; at most 8 -- a team of all of a 256-thread host costs more in its fork than the loop saves)
 #if defined(_OPENMP)
+#include <omp.h>
 #define M3_OMP_STR(x) #x
 #define M3_OMP(x) _Pragma(M3_OMP_STR(x))
 #else
@@ -75,6 +77,7 @@ class ParameterHandlerBase {
   bool IsParameterFixed(const int i) const { return fixed[size_t(i)]; }
   void ToggleFixParameter(const int i) {
     throw_ready = throw_drawn = false;
+    ++throw_epoch;
     if (i < 0 || i >= _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "ToggleFixParameter: parameter index out of range");
     fixed[size_t(i)] = !fixed[size_t(i)];
   }
@@ -130,6 +133,50 @@ class ParameterHandlerBase {
     }
     SpecialStepProposal();
   }
+
+  /// The two O(nPar^2) sweeps of a step -- the prior term (CalcLikelihood, ref: :816-841) and the next proposal's correlated
+  /// throw (CorrelateSteps, ref: :726-745) -- on the engine's device (m3hip_par_*), beside the sample's reweight kernel.
+  /// The host keeps the random numbers (Randomize, :690-707), the bounds, the special proposals and the Haario update.
+  /// At the 1 040 parameters of BASELINE configs[4] the sweeps take 0.4 ms on one host core and a few microseconds there.
+  /// Same numbers up to fp64 rounding (fixed summation order on the device; tests/test_cpp_facade.py).
+  void AttachDevice(m3hip_handle h) {
+    if (!h) throw MaCh3Exception(__FILE__, __LINE__, "AttachDevice: null engine handle");
+    if (m3hip_par_upload(h, 0, InvertCovMatrix.data(), _fNumPar) != M3HIP_OK || m3hip_par_upload(h, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
+      throw MaCh3Exception(__FILE__, __LINE__, std::string("AttachDevice: ") + m3hip_last_error(h));
+    dev = h;
+  }
+  bool OnDevice() const { return dev != nullptr; }
+  /// enqueue (nothing waits): the prior of the CURRENT proposal and the correlated throw of the NEXT one
+  void LaunchDeviceStep() {
+    std::vector<double>& d = diff_scratch;
+    d.resize(size_t(_fNumPar));
+    for (int i = 0; i < _fNumPar; ++i) d[size_t(i)] = _fFlatPrior[size_t(i)] ? 0.0 : _fPropVal[size_t(i)] - _fPreFitValue[size_t(i)];
+    if (!throw_drawn) {
+      for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
+      throw_drawn = true;
+    }
+    if (m3hip_par_launch(dev, d.data(), randParams.data(), _fNumPar) != M3HIP_OK)
+      throw MaCh3Exception(__FILE__, __LINE__, std::string("LaunchDeviceStep: ") + m3hip_last_error(dev));
+    launched_epoch = throw_epoch;
+  }
+  /// the prior term of the proposal LaunchDeviceStep was called for; the next proposal's throw is in place, unless the
+  /// throw matrix or the set of fixed parameters changed since (ProposeStep then recomputes it on the host, same random vector)
+  double CollectDeviceStep() {
+    double prior = 0.0;
+    std::vector<double>& t = throw_scratch;
+    t.resize(size_t(_fNumPar));
+    if (m3hip_par_result(dev, &prior, t.data(), _fNumPar) != M3HIP_OK)
+      throw MaCh3Exception(__FILE__, __LINE__, std::string("CollectDeviceStep: ") + m3hip_last_error(dev));
+    if (launched_epoch == throw_epoch && throw_drawn) {
+      corr_throw.swap(t);
+      throw_ready = true;
+    }
+    return prior;
+  }
+  /// the lower Cholesky factor of the throw matrix, row-major (what CorrelateSteps multiplies with)
+  const std::vector<double>& GetThrowMatrixCholesky() const { return throwMatrixCholDecomp; }
+  /// threads of the Haario update's team (with -fopenmp; 1 = serial)
+  void SetAdaptionThreads(int n) { adaption_threads = std::max(1, std::min(n, 8)); }
 
   /// ref: ParameterHandlerBase.cpp:652-664 (ProposeStep), 690-707 (Randomize), 726-745 (CorrelateSteps)
   void ProposeStep() {
@@ -241,6 +288,8 @@ M3_OMP(omp simd reduction(+ : s))
     const double* x = _fCurrVal.data();
     if (steps_post_burn > 0) {
       const double keep = double(steps_post_burn - 1) / steps_post_burn, nb = double(steps_post_burn), nb1 = double(steps_post_burn + 1);
+      // rows are independent; chunks of 8 rows dealt round-robin balance the triangle over the team
+M3_OMP(omp parallel for schedule(static, 8) num_threads(adaption_threads) if (n >= 256 && adaption_threads > 1))
       for (int i = 0; i < n; ++i) {
         double* row = cov + size_t(i) * n;
         const double pi = nb * mp[i], ci = nb1 * mc[i], xi = x[i];
@@ -282,30 +331,72 @@ M3_OMP(omp simd)
         if (!std::isfinite(cov[size_t(i) * _fNumPar + j])) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix has a non-finite entry");
     constexpr double MaxShift = 1e-4;
     double shift = 0.0;
+    const int n = _fNumPar;
+    // L_ij = (A_ij - sum_{k<j} L_ik L_jk) / L_jj in panels of 32 columns.  One factorisation of 1 040 parameters is 0.37 GFLOP
+    // -- 35 ms as a plain row sweep on one core -- and it sits on the step's critical path whenever the adaptive proposal
+    // refreshes its matrix, so the team of the Haario update shares it: (1) every row's sums over the columns left of the
+    // panel, the bulk of the work, rows independent; (2a) the panel's diagonal block, one thread; (2b) the rows below it,
+    // independent again.  Three barriers per panel.  Every entry is the same sum in the same order whoever computes it: the
+    // factor does not depend on the number of threads.
+    constexpr int kPanel = 32;
     for (int attempt = 0;; ++attempt, shift = attempt <= 64 ? shift + 1e-9 : 2 * shift) {
       bool ok = true;
-      for (int i = 0; i < _fNumPar && ok; ++i)
-        for (int j = 0; j <= i; ++j) {
-          const double *li = L.data() + size_t(i) * _fNumPar, *lj = L.data() + size_t(j) * _fNumPar;
-          double dot = 0.0;
+M3_OMP(omp parallel num_threads(adaption_threads) if (n >= 256 && adaption_threads > 1))
+      for (int j0 = 0; j0 < n; j0 += kPanel) {
+        if (!ok) continue;  // (every thread sees the same `ok`: it only changes between two barriers)
+        const int j1 = std::min(n, j0 + kPanel);
+M3_OMP(omp for schedule(static, 4))
+        for (int i = j0; i < n; ++i) {  // (1)
+          double* li = L.data() + size_t(i) * n;
+          const int jmax = std::min(i, j1 - 1);
+          for (int j = j0; j <= jmax; ++j) {
+            const double* lj = L.data() + size_t(j) * n;
+            double dot = 0.0;
 M3_OMP(omp simd reduction(+ : dot))
-          for (int k = 0; k < j; ++k) dot += li[k] * lj[k];
-          const double s = cov[size_t(i) * _fNumPar + j] + (i == j ? shift : 0.0) - dot;
-          if (i == j) {
-            if (!(s > 0.0)) {
-              ok = false;
-              break;
-            }
-            L[size_t(i) * _fNumPar + i] = std::sqrt(s);
-          } else {
-            L[size_t(i) * _fNumPar + j] = s / L[size_t(j) * _fNumPar + j];
+            for (int k = 0; k < j0; ++k) dot += li[k] * lj[k];
+            li[j] = cov[size_t(i) * n + j] + (i == j ? shift : 0.0) - dot;
           }
         }
+M3_OMP(omp single)
+        for (int i = j0; i < j1 && ok; ++i) {  // (2a)
+          double* li = L.data() + size_t(i) * n;
+          for (int j = j0; j <= i; ++j) {
+            const double* lj = L.data() + size_t(j) * n;
+            double s = li[j];
+            for (int k = j0; k < j; ++k) s -= li[k] * lj[k];
+            if (i == j) {
+              if (!(s > 0.0)) {
+                ok = false;
+                break;
+              }
+              li[i] = std::sqrt(s);
+            } else {
+              li[j] = s / lj[j];
+            }
+          }
+        }
+        if (ok) {
+M3_OMP(omp for schedule(static, 4))
+          for (int i = j1; i < n; ++i) {  // (2b)
+            double* li = L.data() + size_t(i) * n;
+            for (int j = j0; j < j1; ++j) {
+              const double* lj = L.data() + size_t(j) * n;
+              double s = li[j];
+              for (int k = j0; k < j; ++k) s -= li[k] * lj[k];
+              li[j] = s / lj[j];
+            }
+          }
+        }
+      }
       if (ok) break;
       if (shift >= MaxShift) throw MaCh3Exception(__FILE__, __LINE__, "throw matrix is not positive definite");
+      for (int i = 0; i < n; ++i) std::fill(L.begin() + size_t(i) * n, L.begin() + size_t(i) * n + i + 1, 0.0);
     }
     throwMatrixCholDecomp = L;
     throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)
+    ++throw_epoch;
+    if (dev && m3hip_par_upload(dev, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
+      throw MaCh3Exception(__FILE__, __LINE__, std::string("SetThrowMatrix: ") + m3hip_last_error(dev));
   }
 
  private:
@@ -357,7 +448,16 @@ M3_OMP(omp simd reduction(+ : dot))
   int start_adaptive_update = 0, end_adaptive_update = 0, start_adaptive_throw = 0, adaptive_update_step = 1, total_steps = 0;
   std::vector<double> par_means, par_means_prev, adaptive_covariance;
   mutable std::vector<double> diff_scratch;
+  std::vector<double> throw_scratch;
   bool adaption_pending = false, throw_ready = false, throw_drawn = false;
+  // device side (AttachDevice)
+  m3hip_handle dev = nullptr;
+  uint64_t throw_epoch = 0, launched_epoch = 0;  // bumped whenever a throw in flight would be stale
+#if defined(_OPENMP)
+  int adaption_threads = std::max(1, std::min(8, omp_get_max_threads()));
+#else
+  int adaption_threads = 1;
+#endif
 };
 
 /// ref: Fitters/FitterBase.h:36-61 + Fitters/MCMCBase.cpp:32-216 (chain bookkeeping kept in memory)
@@ -446,14 +546,16 @@ class MCMCBase {
       if (s->CheckBounds() > 0) out_of_bounds = true;
     if (!out_of_bounds)
       for (auto* s : samples) s->Reweight();
+    // handlers attached to the device (ParameterHandlerBase::AttachDevice) enqueue their prior and their next throw beside
+    // the samples' kernels; the others compute both here, under the GPU's work
+    for (auto* s : systematics)
+      if (s->OnDevice() && !out_of_bounds) s->LaunchDeviceStep();
     double llh = 0.0;
-    for (size_t s = 0; s < systematics.size(); ++s) {
-      syst_llh[s] = systematics[s]->GetLikelihood();
-      llh += syst_llh[s];
-    }
+    for (size_t s = 0; s < systematics.size(); ++s)
+      if (!systematics[s]->OnDevice() || out_of_bounds) syst_llh[s] = systematics[s]->GetLikelihood();
     for (auto* s : systematics) {
       s->FinishPendingAdaption();
-      s->PrepareNextThrow();
+      if (!s->OnDevice() || out_of_bounds) s->PrepareNextThrow();
     }
     if (!out_of_bounds) {
       for (size_t i = 0; i < samples.size(); ++i) {
@@ -463,6 +565,10 @@ class MCMCBase {
     } else {
       ++oobCount;
       for (size_t i = 0; i < samples.size(); ++i) sample_llh[i] = M3::_LARGE_LOGL_;
+    }
+    for (size_t s = 0; s < systematics.size(); ++s) {
+      if (systematics[s]->OnDevice() && !out_of_bounds) syst_llh[s] = systematics[s]->CollectDeviceStep();
+      llh += syst_llh[s];
     }
     logLProp = llh;
   }

@@ -277,6 +277,22 @@ struct m3hip_ctx {
   int xch_ranks = 0, xch_rank = 0, xch_slot = 0;  // slot: doubles per slot (2 * n_bins + 2)
   bool xch_active = false;
   uint64_t xch_step = 0;
+  // parameter-handler side of a step on the device (m3hip_par_*): prior and correlated throw
+  struct ParDev {
+    int n = 0;
+    double* d_inv = nullptr;    // [n][n] inverse prior covariance (lower triangle read)
+    double* d_chol = nullptr;   // [n][n] Cholesky factor of the throw matrix (lower triangular)
+    double* d_rows = nullptr;   // [2n] per-row results
+    double* d_in = nullptr;     // [2n] the step's [d | z] on board
+    double* h_in[2] = {nullptr, nullptr};  // pinned, device-mapped: [d | z] of two steps in flight at most
+    double* d_in_host[2] = {nullptr, nullptr};
+    double* h_out = nullptr;    // pinned, device-mapped: [prior | corr_throw[n] | ticket]
+    double* d_out = nullptr;
+    uint64_t ticket = 0;        // launches so far
+    uint64_t collected = 0;     // ... whose results have been waited for
+    bool have_inv = false, have_chol = false;
+  } par;
+  hipStream_t par_stream = nullptr;  // its own stream: two latency-bound launches that need not queue behind the reweight kernel
   double xch_timeout_s = 2.0;     // every ticket spin of k_xch gives up after this long (m3hip_xch_set_timeout, M3HIP_XCH_TIMEOUT_S)
   uint64_t* h_xch_status = nullptr;  // mapped pinned host word (0: fine; else the step whose tickets did not arrive)
   uint64_t* d_xch_status = nullptr;
@@ -358,6 +374,16 @@ hipError_t wait_stream(hipStream_t s) {
     if (e != hipErrorNotReady) return e;
     if (now_s() - t0 > 5.0) return hipStreamSynchronize(s);
   }
+}
+
+void par_free(m3hip_handle h) {
+  auto& p = h->par;
+  if (h->par_stream) (void)hipStreamSynchronize(h->par_stream);
+  dev_free(p.d_inv); dev_free(p.d_chol); dev_free(p.d_rows); dev_free(p.d_in);
+  for (int i = 0; i < 2; ++i)
+    if (p.h_in[i]) (void)hipHostFree(p.h_in[i]);
+  if (p.h_out) (void)hipHostFree(p.h_out);
+  p = m3hip_ctx::ParDev();
 }
 
 // The one-shot exchange's verdict on the last step (the stream is idle up to that step's k_xch).  The status word holds
@@ -660,6 +686,8 @@ int m3hip_destroy(m3hip_handle h) try {
   dev_free(h->d_hist);
   dev_free(h->d_llh_terms);
   dev_free(h->d_dbg_clock);
+  par_free(h);
+  if (h->par_stream) (void)hipStreamDestroy(h->par_stream);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -2428,6 +2456,89 @@ int m3hip_xch_open(m3hip_handle h, const void* handles) try {
   HIPCHK(h, hipMemset(h->d_xch_pushed, 0, sizeof(unsigned long long)));
   h->xch_step = 0;
   h->xch_active = true;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+/* ---------------------------------------------------------------- parameter handler on the device */
+
+static int par_wait(m3hip_handle h) {  // every launched par step has published its results
+  auto& p = h->par;
+  if (p.collected == p.ticket) return M3HIP_OK;
+  volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(p.h_out + 1 + p.n);
+  hipStream_t st = h->par_stream ? h->par_stream : h->stream;
+  const double t0 = now_s();
+  uint64_t spins = 0;
+  (void)hipStreamQuery(st);
+  while (*flag != p.ticket) {
+    if ((++spins & 0xFFu) == 0) {
+      hipError_t e = hipStreamQuery(st);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(h, M3HIP_EHIP, std::string("par_result: ") + hipGetErrorString(e));
+      if (now_s() - t0 > 60.0) return fail(h, M3HIP_EHIP, "par_result: timed out waiting for the device");
+    }
+  }
+  (void)hipStreamQuery(st);
+  p.collected = p.ticket;
+  return M3HIP_OK;
+}
+
+int m3hip_par_upload(m3hip_handle h, int which, const double* m, int n) try {
+  if (!h) return M3HIP_EINVAL;
+  if ((which != 0 && which != 1) || !m || n < 1 || n > 16384) return fail(h, M3HIP_EINVAL, "par_upload: which is 0 (inverse covariance) or 1 (Cholesky factor), 1 <= n <= 16384");
+  HIPCHK(h, hipSetDevice(h->device));
+  auto& p = h->par;
+  int rc;
+  if (p.n != n) {  // (re)size everything
+    par_free(h);
+    if (!h->par_stream) {
+      const char* f = getenv("M3HIP_PAR_STREAM");
+      if (!(f && f[0] == '0')) HIPCHK(h, hipStreamCreateWithFlags(&h->par_stream, hipStreamNonBlocking));
+    }
+    if ((rc = dev_alloc(h, &p.d_inv, size_t(n) * n))) return rc;
+    if ((rc = dev_alloc(h, &p.d_chol, size_t(n) * n))) return rc;
+    if ((rc = dev_alloc(h, &p.d_rows, size_t(2) * n))) return rc;
+    if ((rc = dev_alloc(h, &p.d_in, size_t(2) * n))) return rc;
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipHostMalloc((void**)&p.h_in[i], sizeof(double) * 2 * n, hipHostMallocMapped));
+      HIPCHK(h, hipHostGetDevicePointer((void**)&p.d_in_host[i], p.h_in[i], 0));
+    }
+    HIPCHK(h, hipHostMalloc((void**)&p.h_out, sizeof(double) * (n + 2), hipHostMallocMapped));
+    memset(p.h_out, 0, sizeof(double) * (n + 2));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&p.d_out, p.h_out, 0));
+    p.n = n;
+  }
+  if ((rc = par_wait(h))) return rc;  // a step in flight still reads the old matrix
+  HIPCHK(h, hipMemcpy(which == 0 ? p.d_inv : p.d_chol, m, sizeof(double) * size_t(n) * n, hipMemcpyHostToDevice));
+  (which == 0 ? p.have_inv : p.have_chol) = true;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_par_launch(m3hip_handle h, const double* d, const double* z, int n) try {
+  if (!h) return M3HIP_EINVAL;
+  auto& p = h->par;
+  if (!p.have_inv || !p.have_chol) return fail(h, M3HIP_ESTATE, "par_launch before both matrices were uploaded (m3hip_par_upload)");
+  if (!d || !z || n != p.n) return fail(h, M3HIP_EINVAL, "par_launch: NULL vectors or n differs from the uploaded matrices");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if (p.ticket > p.collected && (rc = par_wait(h))) return rc;  // results nobody collected: the output block is about to be rewritten
+  const int slot = int(p.ticket & 1);
+  memcpy(p.h_in[slot], d, sizeof(double) * n);
+  memcpy(p.h_in[slot] + n, z, sizeof(double) * n);
+  ++p.ticket;
+  launch_par_step(p.d_inv, p.d_chol, p.d_in_host[slot], p.d_in, n, p.d_rows, p.d_out, reinterpret_cast<volatile uint64_t*>(p.d_out + 1 + n), p.ticket,
+                  h->par_stream ? h->par_stream : h->stream);
+  HIPCHK(h, hipGetLastError());
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_par_result(m3hip_handle h, double* prior, double* corr_throw, int n) try {
+  if (!h) return M3HIP_EINVAL;
+  auto& p = h->par;
+  if (p.ticket == 0) return fail(h, M3HIP_ESTATE, "par_result before par_launch");
+  if (n != p.n) return fail(h, M3HIP_EINVAL, "par_result: n differs from the uploaded matrices");
+  int rc = par_wait(h);
+  if (rc) return rc;
+  if (prior) *prior = p.h_out[0];
+  if (corr_throw) memcpy(corr_throw, p.h_out + 1, sizeof(double) * n);
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

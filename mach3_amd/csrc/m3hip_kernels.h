@@ -276,6 +276,10 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
 // dynamic LDS of a fill launch and whether the bin vector is privatised there (see ReweightArgs::hist_lds)
 constexpr int M3_HIST_LDS_MAX_BYTES = 20 * 1024;
 void launch_llh(const LlhArgs& a, hipStream_t s);
+// prior (rows 0..n-1 of `inv`, lower triangle) and correlated throw (L z) of one Metropolis step: in = [d | z] (2n doubles),
+// out = [prior | corr_throw[n]] in mapped host memory, then `ticket` into *done_flag
+void launch_par_step(const double* inv, const double* chol, const double* in_host, double* in_dev, int n, double* rows, double* out,
+                     volatile uint64_t* done_flag, uint64_t ticket, hipStream_t s);
 void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t n, bool widen, hipStream_t s);
 // One-shot exchange of the folded bin vector (m3hip_xch_*): every rank stores its vector and then a ticket into slot
 // [parity][rank] of every rank's buffer; a rank's bins are the rank-ordered sum of the N slots of its own buffer once all N

@@ -1727,6 +1727,73 @@ void launch_osc_convert(const float* f32, const double* f64, void* dst, uint64_t
   else hipLaunchKernelGGL(k_osc_narrow, dim3(g), dim3(256), 0, s, f64, reinterpret_cast<float*>(dst), n);
 }
 
+// ------------------------------------------------------------------------------------
+// The parameter handler's two O(nPar^2) sweeps of a Metropolis step, on the device (BASELINE configs[4] has
+// 1 040 parameters: 2 x 8.65 MB of fp64 matrix per step, 0.6 ms on one host core -- longer than the GPU's step):
+//   rows 0 .. n-1   the prior, Parameters/ParameterHandlerBase.cpp:816-841: sum over i, j <= i of (i == j ? 0.5 : 1) d_i d_j V^-1_ij
+//                   (d = proposed - prior value, 0 where the prior is flat); row i contributes d_i (sum_{j<i} V^-1_ij d_j + 0.5 V^-1_ii d_i)
+//   rows n .. 2n-1  the correlated throw, :726-745 with Parameters/ParameterHandlerUtils.h:118-135: corr_throw = L z, L the lower
+//                   Cholesky factor of the throw matrix
+// One wave per row, lanes stride over the row's lower-triangle part (512-byte coalesced reads), a fixed shuffle tree; the
+// finishing kernel adds the prior's rows in index order groups and hands prior + throw to mapped host memory, then the ticket.
+// Every sum has a fixed order: results are reproducible run to run (they differ from the host loops' by fp64 rounding only).
+// ------------------------------------------------------------------------------------
+// (the step's [d | z] arrives in mapped host memory; one block brings it on board first -- 2 080 waves reading it across PCIe
+// would each pay that round trip)
+__global__ __launch_bounds__(1024) void k_par_stage(const double* __restrict__ in_host, int n2, double* __restrict__ in_dev) {
+  for (int i = threadIdx.x; i < n2; i += 1024) in_dev[i] = in_host[i];
+}
+__global__ __launch_bounds__(256) void k_par_rows(const double* __restrict__ inv, const double* __restrict__ chol, const double* __restrict__ in, int n,
+                                                  double* __restrict__ rows) {
+  const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  if (r >= 2 * n) return;
+  const bool prior = r < n;
+  const int i = prior ? r : r - n;
+  const double* __restrict__ row = (prior ? inv : chol) + (size_t)i * n;
+  const double* __restrict__ v = in + (prior ? 0 : n);  // d, then z
+  const int last = prior ? i - 1 : i;                    // the prior's diagonal term carries its own factor
+  // eight loads of the row in flight per lane (a row of 1 040 is 17 per lane: two round trips, not seventeen), summed in a
+  // fixed order
+  double s = 0.0;
+  for (int j0 = lane; j0 <= last; j0 += 8 * 64) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + 64 * u;
+      const int jc = j <= last ? j : last;
+      a[u] = row[jc];
+      b[u] = j <= last ? v[jc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += a[u] * b[u];
+  }
+  s = wave_sum(s);
+  if (lane == 0) rows[r] = prior ? v[i] * (s + 0.5 * v[i] * row[i]) : s;
+}
+__global__ __launch_bounds__(1024) void k_par_finish(const double* __restrict__ rows, int n, double* __restrict__ out, volatile uint64_t* done_flag, uint64_t ticket) {
+  __shared__ double part[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += rows[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  for (int i = threadIdx.x; i < n; i += 1024) out[1 + i] = rows[n + i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    out[0] = t;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *done_flag = ticket;
+}
+void launch_par_step(const double* inv, const double* chol, const double* in_host, double* in_dev, int n, double* rows, double* out,
+                     volatile uint64_t* done_flag, uint64_t ticket, hipStream_t s) {
+  hipLaunchKernelGGL(k_par_stage, dim3(1), dim3(1024), 0, s, in_host, 2 * n, in_dev);
+  hipLaunchKernelGGL(k_par_rows, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, s, inv, chol, in_dev, n, rows);
+  hipLaunchKernelGGL(k_par_finish, dim3(1), dim3(1024), 0, s, rows, n, out, done_flag, ticket);
+}
+
 void launch_llh(const LlhArgs& a, hipStream_t s) {
   if (a.n_bins > M3_LLH_SPLIT_BINS) {
     const int n_groups = (a.n_bins + M3_LLH_SPLIT_LANES - 1) / M3_LLH_SPLIT_LANES;

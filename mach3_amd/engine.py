@@ -122,6 +122,23 @@ class Engine:
         assert len(blob) % capi.XCH_HANDLE_BYTES == 0
         self._chk(self.lib.m3hip_xch_open(self.h, C.c_char_p(blob)))
 
+    # ---- the parameter handler's prior and correlated throw on the device (m3hip_par_*)
+    def par_upload(self, which: int, matrix):
+        m = np.ascontiguousarray(matrix, np.float64)
+        assert m.ndim == 2 and m.shape[0] == m.shape[1]
+        self._chk(self.lib.m3hip_par_upload(self.h, which, m.ctypes.data, m.shape[0]))
+
+    def par_launch(self, d, z):
+        d = np.ascontiguousarray(d, np.float64)
+        z = np.ascontiguousarray(z, np.float64)
+        self._chk(self.lib.m3hip_par_launch(self.h, d.ctypes.data, z.ctypes.data, len(d)))
+
+    def par_result(self, n: int):
+        prior = C.c_double()
+        throw = np.empty(n, np.float64)
+        self._chk(self.lib.m3hip_par_result(self.h, C.byref(prior), throw.ctypes.data, n))
+        return prior.value, throw
+
     def xch_set_timeout(self, seconds: float):
         self._chk(self.lib.m3hip_xch_set_timeout(self.h, C.c_double(seconds)))
 

@@ -176,6 +176,126 @@ int facade_parameter_handler_checks(unsigned long long seed) {
 }
 
 // 1 when registering the same sub-sample title twice is refused (Fitters/FitterBase.cpp:262-279), else 0
+// The parameter handler's prior and correlated throw on the device (ParameterHandlerBase::AttachDevice -> m3hip_par_*)
+// against the host loops of the same class, on a random SPD covariance of n parameters: two handlers with the same seed
+// walk the same chain, one on the host, one attached to device 0.  out[0] = worst relative difference of the prior term,
+// out[1] = worst difference of a proposed value in units of the step's largest move, out[2] = steps compared.
+// Half way a new throw matrix arrives while a device throw is in flight: it must be dropped and recomputed.  Needs a GPU.
+int facade_par_device_check(int n, unsigned long long seed, int n_steps, double* out) {
+  m3hip_handle h = nullptr;
+  try {
+    if (m3hip_create(0, &h) != M3HIP_OK) return 100;
+    std::mt19937_64 g(seed);
+    std::normal_distribution<double> N(0.0, 1.0);
+    auto spd = [&](double ridge) {
+      std::vector<double> a(size_t(n) * n), c(size_t(n) * n, 0.0);
+      for (auto& v : a) v = N(g);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double s = 0.0;
+          for (int k = 0; k < n; ++k) s += a[size_t(i) * n + k] * a[size_t(j) * n + k];
+          c[size_t(i) * n + j] = c[size_t(j) * n + i] = s / n + (i == j ? ridge : 0.0);
+        }
+      return c;
+    };
+    const std::vector<double> cov = spd(0.5), cov2 = spd(0.25);
+    std::vector<double> prefit(static_cast<size_t>(n), 0.0), lo(static_cast<size_t>(n), -1e3), up(static_cast<size_t>(n), 1e3);
+    for (auto& v : prefit) v = N(g);
+    std::vector<bool> flat(static_cast<size_t>(n), false);
+    for (int i = 0; i < n; i += 37) flat[size_t(i)] = true;  // some flat priors: they drop out of the prior term
+    ParameterHandlerBase host("host", prefit, cov, lo, up, flat, seed), dev("dev", prefit, cov, lo, up, flat, seed);
+    host.SetFixParameter(3 % n);
+    dev.SetFixParameter(3 % n);
+    dev.AttachDevice(h);
+    if (!dev.OnDevice() || host.OnDevice()) return 1;
+    double worst_prior = 0.0, worst_prop = 0.0;
+    for (int s = 0; s < n_steps; ++s) {
+      host.ProposeStep();
+      dev.ProposeStep();  // from the second step on with the throw the device computed
+      double move = 0.0, diff = 0.0;
+      for (int i = 0; i < n; ++i) {
+        move = std::max(move, std::fabs(host.GetParProp(i) - host.GetParCurr(i)));
+        diff = std::max(diff, std::fabs(host.GetParProp(i) - dev.GetParProp(i)));
+      }
+      if (!(move > 0.0)) return 2;
+      worst_prop = std::max(worst_prop, diff / move);
+      if (dev.GetParProp(3 % n) != dev.GetParCurr(3 % n)) return 3;  // fixed parameters stay
+      const double p_host = host.GetLikelihood();
+      dev.LaunchDeviceStep();
+      if (s == n_steps / 2) {  // a new throw matrix while a throw is in flight
+        host.SetThrowMatrix(cov2);
+        dev.SetThrowMatrix(cov2);
+      }
+      const double p_dev = dev.CollectDeviceStep();
+      worst_prior = std::max(worst_prior, std::fabs(p_dev - p_host) / std::max(std::fabs(p_host), 1e-300));
+      host.AcceptStep();
+      dev.AcceptStep();
+    }
+    out[0] = worst_prior;
+    out[1] = worst_prop;
+    out[2] = n_steps;
+    m3hip_destroy(h);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "facade_par_device_check: %s\n", e.what());
+    if (h) m3hip_destroy(h);
+    return 99;
+  }
+}
+
+// SetThrowMatrix's panel Cholesky on a random SPD matrix of n parameters: out[0] = max |L L^T - A| / max |A|, out[1] = 1 if the
+// factor is bit-identical with one thread and with `threads` (the build has OpenMP), out[2] = 1 if a singular matrix was made
+// decomposable by a diagonal shift (M3::MakeMatrixPosDef's behaviour)
+int facade_cholesky_check(int n, unsigned long long seed, int threads, double* out) {
+  try {
+    std::mt19937_64 g(seed);
+    std::normal_distribution<double> N(0.0, 1.0);
+    std::vector<double> a(size_t(n) * n), c(size_t(n) * n, 0.0);
+    for (auto& v : a) v = N(g);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) s += a[size_t(i) * n + k] * a[size_t(j) * n + k];
+        c[size_t(i) * n + j] = c[size_t(j) * n + i] = s / n + (i == j ? 0.1 : 0.0);
+      }
+    std::vector<double> prefit(static_cast<size_t>(n), 0.0), lo(static_cast<size_t>(n), -1e3), up(static_cast<size_t>(n), 1e3);
+    ParameterHandlerBase p1("one", prefit, c, lo, up, {}, 1), pt("team", prefit, c, lo, up, {}, 1);
+    p1.SetAdaptionThreads(1);
+    pt.SetAdaptionThreads(threads);
+    p1.SetThrowMatrix(c);
+    pt.SetThrowMatrix(c);
+    const std::vector<double>&L1 = p1.GetThrowMatrixCholesky(), &Lt = pt.GetThrowMatrixCholesky();
+    out[1] = std::memcmp(L1.data(), Lt.data(), sizeof(double) * L1.size()) == 0 ? 1.0 : 0.0;
+    double worst = 0.0, amax = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j) {
+        double s = 0.0;
+        for (int k = 0; k <= j; ++k) s += Lt[size_t(i) * n + k] * Lt[size_t(j) * n + k];
+        worst = std::max(worst, std::fabs(s - c[size_t(i) * n + j]));
+        amax = std::max(amax, std::fabs(c[size_t(i) * n + j]));
+      }
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j)
+        if (Lt[size_t(i) * n + j] != 0.0) return 2;  // upper triangle stays empty
+    out[0] = worst / amax;
+    // rank-deficient: two identical rows/columns
+    std::vector<double> sing(c);
+    for (int k = 0; k < n; ++k) sing[size_t(1) * n + k] = sing[size_t(k) * n + 1] = c[size_t(0) * n + k];
+    sing[size_t(1) * n + 1] = c[0];
+    sing[size_t(0) * n + 1] = sing[size_t(1) * n + 0] = c[0];
+    out[2] = 0.0;
+    try {
+      pt.SetThrowMatrix(sing);
+      out[2] = 1.0;
+    } catch (const MaCh3Exception&) {
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "facade_cholesky_check: %s\n", e.what());
+    return 99;
+  }
+}
+
 int facade_duplicate_title_refused() {
   const std::vector<double> prefit = {0.0, 0.0, 0.0};
   const std::vector<double> cov = {1, 0, 0, 0, 1, 0, 0, 0, 1};

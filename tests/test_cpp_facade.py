@@ -136,3 +136,22 @@ def test_configs4_step_loop_example_runs():
     acc = float(out.split("acceptance ")[1].split(",")[0])
     assert 0.05 < acc < 0.99
     assert "out of bounds 0" in out and "host work on the step's critical path" in out
+
+
+@pytest.mark.gpu
+def test_device_prior_and_throw_equal_the_host_loops():
+    """SURVEY 8f row 2 at BASELINE configs[4]'s size: the prior term (ParameterHandlerBase::CalcLikelihood, ref
+    Parameters/ParameterHandlerBase.cpp:816-841) and the correlated throw (CorrelateSteps, :726-745) computed on the device
+    (AttachDevice -> m3hip_par_*) against the host loops of the same class, 1 040 parameters with a random SPD covariance, some
+    flat priors and a fixed parameter, 40 steps of one chain walked twice; a throw matrix replaced while a device throw is in
+    flight must be dropped.  Bar: 1e-12 relative (fp64 sums in another order)."""
+    import ctypes as C
+    import numpy as np
+    subprocess.run(["make", "-C", ROOT, "build/libm3facade_test.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(ROOT, "build", "libm3facade_test.so"))
+    lib.facade_par_device_check.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+    for n, steps in ((1040, 40), (7, 12), (257, 20)):
+        out = np.zeros(3)
+        rc = lib.facade_par_device_check(n, 20260318 + n, steps, out.ctypes.data)
+        assert rc == 0, (n, rc)
+        assert out[2] == steps and out[0] <= 1e-12 and out[1] <= 1e-12, (n, out)

@@ -88,3 +88,14 @@ def test_annealing_follows_the_reference_formula(shim):
     assert shim.facade_toy_chain(3, 40000, 11, ann.ctypes.data) == 0
     assert ann[0] < 0.6 * plain[0]                 # acceptance
     assert (ann[6:9] < 0.5 * plain[6:9]).all()     # variances of the kept part of the chain
+
+
+@pytest.mark.parametrize("n", [5, 100, 300, 1040])
+def test_throw_matrix_cholesky(shim, n):
+    """SetThrowMatrix (ref: Parameters/ParameterHandlerBase.cpp:1140-1200): the panel factorisation reproduces the matrix, does
+    not depend on the size of its thread team (bit for bit), leaves the upper triangle empty, and a singular matrix is made
+    decomposable by a diagonal shift as M3::MakeMatrixPosDef does (Parameters/ParameterHandlerUtils.h:512-545)"""
+    shim.facade_cholesky_check.argtypes = [C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+    out = np.zeros(3)
+    assert shim.facade_cholesky_check(n, 99 + n, 4, out.ctypes.data) == 0
+    assert out[0] < 1e-13 and out[1] == 1.0 and out[2] == 1.0, out
