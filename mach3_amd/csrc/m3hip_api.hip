@@ -147,6 +147,7 @@ struct m3hip_ctx {
   uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
   bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
   bool evw_ok = false;            // the sample fits the packed word's fields
+  bool bins_in_word = false;      // the last re-binning pass wrote the words' bin field only: d_bin is stale (bins_from_word)
   uint32_t evw_norm_slots = 0;    // norm slots the word carries: M3_EVW_NORM_SLOTS, or 0 when the sample's norm indices do not fit its codes
   int64_t min_norm_idx = INT64_MAX, max_norm_idx_evw = -1;  // over the slots the packed word holds (an event's first M3_EVW_NORM_SLOTS)
   uint32_t M = 0;
@@ -464,6 +465,7 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_evw); h->d_evw = nullptr;
   h->evw_dirty = true;
   h->evw_ok = false;
+  h->bins_in_word = false;
   h->min_norm_idx = INT64_MAX;
   h->max_norm_idx_evw = -1;
   for (auto& x : h->extra) {
@@ -543,6 +545,23 @@ BinArgs make_bin_args(m3hip_handle h) {
   b.kin_stride = h->kin_stride;
   b.n_events = h->E;
   return b;
+}
+
+// d_bin up to date again after re-binning passes that wrote the packed words only
+int bins_from_word(m3hip_handle h) {
+  if (!h->bins_in_word) return M3HIP_OK;
+  h->bins_in_word = false;
+  if (!h->d_evw || !h->d_bin) return M3HIP_OK;
+  launch_unpack_bins(h->d_evw, h->d_bin, h->E, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return M3HIP_OK;
+}
+
+// whether the events' sample side fits the brick kernel's packed 8-byte word (ReweightArgs::evw)
+bool evw_fits(m3hip_handle h) {
+  bool ok = !h->f64 && !h->h_bricks.empty() && h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->d_bin && h->d_osc;
+  if (const char* f = getenv("M3HIP_PACKED_EVENTS")) ok = ok && f[0] != '0';
+  return ok;
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
@@ -1193,6 +1212,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   if (n == 0) return M3HIP_OK;
   if (!bin_idx) return fail(h, M3HIP_EINVAL, "upload_events: bin_idx is NULL");
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc_b = bins_from_word(h)) return rc_b;  // the other events' bins must be in d_bin before a slice of it is replaced
   HIPCHK(h, hipStreamSynchronize(h->stream));
   int64_t mx = -1;
   for (uint64_t i = 0; i < n; ++i) {
@@ -1638,6 +1658,7 @@ int m3hip_compute_bins(m3hip_handle h) try {
   b.n_shifts = 0;
   launch_find_bins(b, h->stream);
   h->evw_dirty = true;  // d_bin is rewritten
+  h->bins_in_word = false;
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, wait_stream(h->stream));
   h->bins_computed = true;
@@ -1702,6 +1723,7 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
   if (!h || !out) return M3HIP_EINVAL;
   if (!h->mono_done || event_offset + n > h->E) return fail(h, M3HIP_EINVAL, "get_event_bins: bad range");
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc_b = bins_from_word(h)) return rc_b;
   HIPCHK(h, wait_stream(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_bin + event_offset, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   return M3HIP_OK;
@@ -2008,17 +2030,60 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     ba.par_map = h->d_parmap;
     launch_binned_weights(ba, h->stream);
   }
-  // functional shifts: every event is re-binned from its shifted kinematics -- inside the uniform reweight kernel's epilogue
-  // when the sample has uniform tiles only; as a pass of its own (k_find_bins, then the events' packed words are rebuilt)
-  // when it has bricks or is the float_t = double variant: the brick kernel has no register to spare for the binning cascade
-  // (its fused form spilled 56-90 registers, and a kernel that uses scratch at all is slow out of proportion)
+  // The brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields:
+  // (re)built here when one of the three arrays changed (set-up time).
+  const bool packed_fit = evw_fits(h);
+  if (!h->f64 && !h->h_bricks.empty() && h->evw_dirty) {
+    h->evw_ok = packed_fit;
+    // norm parameters spread over more than 62 indices do not fit the word's 6-bit codes: the word then carries bin and
+    // oscillation index only, and the kernel's tail reads every norm slot from the index planes
+    h->evw_norm_slots = (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) ? uint32_t(M3_EVW_NORM_SLOTS) : 0u;
+    if (const char* f = getenv("M3HIP_PACKED_EVENTS")) {
+      if (f[0] == 'b') h->evw_norm_slots = 0;  // "b": bin and oscillation index only (tests)
+    }
+    if (h->evw_ok) {
+      if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
+      launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
+                         int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+    }
+    h->evw_dirty = false;
+  }
+  const bool word_valid = !h->f64 && !h->h_bricks.empty() && h->evw_ok && packed_fit && h->d_evw;
+  // Functional shifts: every event is re-binned from its shifted kinematics (ApplyShifts + FindBin).  Uniform tiles do it in
+  // their kernel's epilogue.  Samples with bricks (and the float_t = double variant) by a pass of its own in front of the
+  // reweight kernel: with the binning tables in LDS when they fit (uniform samples, <= 2048 edges) and, when the packed words
+  // exist, straight into their bin field -- 8 B of kinematics + the word, read and written, per event; k_rebin_pack /
+  // k_find_bins from global tables otherwise.  Bricks of 1024 events with the packed word can also re-bin in the brick
+  // kernel's own tail (no scratch since round 3's register work): measured slower than the LDS pass (the cascade's look-ups
+  // come from L2 there), so only M3HIP_REBIN=tail selects it.
   const bool dyn_any = !h->h_shifts.empty();
-  const bool dyn_pass = dyn_any && (h->f64 || !h->h_bricks.empty());
+  bool nonuniform = false;
+  for (const BinSample& bs : h->bb_samples) nonuniform = nonuniform || !bs.uniform;
+  const bool lds_ok = rebin_tables_fit_lds(int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), int(h->h_shifts.size()),
+                                           int(h->h_cuts.size()), nonuniform);
+  const char* rebin_env = getenv("M3HIP_REBIN");  // experiments / tests: tail | pass | global
+  const bool want_tail = rebin_env && rebin_env[0] == 't';
+  const bool use_lds = lds_ok && !(rebin_env && rebin_env[0] == 'g');
+  const bool brick_tail = want_tail && brick_can_rebin(uint32_t(h->brick_groups), word_valid);
+  const bool dyn_pass = dyn_any && (h->f64 || (!h->h_bricks.empty() && !brick_tail));
   const bool dyn_bins = dyn_any && !dyn_pass;  // fused
   if (dyn_pass) {
     BinArgs b = make_bin_args(h);
     b.compute_nominal = 0;
-    launch_find_bins(b, h->stream);
+    if (word_valid && h->h_tiles.empty()) {  // bricks only: nothing but the words needs the bins
+      if (use_lds) {
+        launch_rebin_lds(b, h->d_evw, int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), h->stream);
+        h->bins_in_word = true;  // d_bin is stale until somebody asks for it (bins_from_word)
+      } else {
+        launch_rebin_pack(b, h->d_evw, h->stream);
+      }
+    } else {
+      if (use_lds) launch_rebin_lds(b, nullptr, int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), h->stream);
+      else launch_find_bins(b, h->stream);
+      if (word_valid)  // (mixed tiles and bricks: the words follow the bins; rare)
+        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
+                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+    }
   }
   const double t_c = now_s();
 
@@ -2046,32 +2111,12 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       HIPCHK(h, hipMemcpy(h->d_perm, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice));
     }
   }
-  // the brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields
-  if (!h->f64 && !h->h_bricks.empty()) {
-    if (dyn_pass) h->evw_dirty = true;  // the re-binning pass has just rewritten d_bin
-    if (h->evw_dirty) {
-      h->evw_ok = h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->d_bin && h->d_osc;
-      // norm parameters spread over more than 62 indices do not fit the word's 6-bit codes: the word then carries bin and
-      // oscillation index only, and the kernel's tail reads every norm slot from the index planes
-      h->evw_norm_slots = (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) ? uint32_t(M3_EVW_NORM_SLOTS) : 0u;
-      if (const char* f = getenv("M3HIP_PACKED_EVENTS")) {
-        h->evw_ok = h->evw_ok && f[0] != '0';
-        if (f[0] == 'b') h->evw_norm_slots = 0;  // "b": bin and oscillation index only (tests)
-      }
-      if (h->evw_ok) {
-        if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
-        launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
-                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
-      }
-      h->evw_dirty = false;
-    }
-  }
   ReweightArgs a = make_rw_args(h);
   if (dyn_bins && !h->f64) {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;
   }
-  if (!h->f64 && h->evw_ok && !h->evw_dirty) {
+  if (word_valid) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);
     a.evw_norm_slots = h->evw_norm_slots;

@@ -105,6 +105,14 @@ struct BinArgs {
   uint64_t n_events;
 };
 void launch_find_bins(const BinArgs& a, hipStream_t s);
+// per-step re-binning straight into the bin field of the events' packed sample words (ReweightArgs::evw)
+void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s);
+// ... with the binning tables in LDS (uniform samples whose tables fit: rebin_tables_fit_lds); evw null: into a.bin instead
+bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform);
+void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s);
+void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream_t s);
+// whether the brick kernel re-bins in its own tail (launch_reweight_brick with dyn_bins) for this shape of sample
+bool brick_can_rebin(uint32_t brick_groups, bool packed_word);
 
 // One experiment weight beyond oscillation and splines (SampleHandlerFD::AddAdditionalWeightPointers appends such pointers to
 // total_weight_pointers, Samples/SampleHandlerFD.cpp:196; CalcWeightFunc refreshes what they point at, SampleHandlerFD.h:289):

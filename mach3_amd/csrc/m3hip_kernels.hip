@@ -171,7 +171,7 @@ __device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin
 // :281-294), then nominal bin -> +-1 neighbour -> binary search per axis and, for non-uniform samples, the
 // candidate scan of the mega-bin (BinningHandler.cpp:257-291).  Shared by k_find_bins and the fused epilogue.
 __device__ int d_event_bin(const BinArgs& a, uint64_t ev) {
-  const int sid = a.sample_id[ev];
+  const int sid = a.sample_id ? a.sample_id[ev] : 0;  // (null: one sample)
   const BinSample sm = a.samples[sid];
   double x[M3_MAX_DIM];
   for (int c = 0; c < a.kin_stride; ++c) x[c] = a.kin[ev * a.kin_stride + c];
@@ -195,7 +195,8 @@ __device__ int d_event_bin(const BinArgs& a, uint64_t ev) {
   int global = 0;
   for (int d = 0; d < sm.n_dim; ++d) {
     const BinAxis ax = a.axes[sm.axis_off + d];
-    const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], a.nom_bin[ev * a.kin_stride + d]);
+    // (no cached nominal bins: the cascade's last route, the binary search -- every route gives the same index)
+    const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], a.nom_bin ? a.nom_bin[ev * a.kin_stride + d] : -1);
     if (b < 0) out = true;  // BinningHandler.cpp:269: one axis out of range -> UnderOverFlowBin
     global += b * ax.stride;
   }
@@ -1198,15 +1199,23 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 template <int MODE, bool DYN, int G>
 static void launch_brick_g(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
   const dim3 b(kBrickThreads);
-  constexpr bool kSampleSide = (MODE & (kModeFill | kModeEventW)) != 0 && !DYN;  // only these read the packed word
-  if (kSampleSide && a.evw) {
-    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true, G, kSampleSide>), g, b, lds, s, k, a);
-    else M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false, G, kSampleSide>), g, b, lds, s, k, a);
-    return;
+  constexpr bool kSampleSide = (MODE & (kModeFill | kModeEventW)) != 0;  // only these read the packed word
+  if constexpr (DYN) {
+    // the events' bins from their shifted kinematics in the slab's tail (d_event_bin): only G = 1 with the packed word fits the
+    // registers (no scratch; G = 4: 53 spilled); every other shape is re-binned by a pass of its own (m3hip_api.hip)
+    static_assert(G == 1 && kSampleSide, "the fused re-binning exists for bricks of 1024 events with the packed sample word");
+    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, true, 1, true>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true>), g, b, lds, s, k, a);
+  } else {
+    if (kSampleSide && a.evw) {
+      if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, false, true, G, kSampleSide>), g, b, lds, s, k, a);
+      else M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G, kSampleSide>), g, b, lds, s, k, a);
+      return;
+    }
+    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, false, true, G>), g, b, lds, s, k, a);
+    else if (k.nt || G != 1) M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<MODE, false, false, false, 1>), g, b, lds, s, k, a);
   }
-  if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, true, G>), g, b, lds, s, k, a);
-  else if (k.nt || DYN || G != 1) M3_LAUNCH((k_reweight_brick<MODE, true, DYN, false, G>), g, b, lds, s, k, a);
-  else M3_LAUNCH((k_reweight_brick<MODE, false, false, false, 1>), g, b, lds, s, k, a);
 }
 
 template <int MODE, bool DYN>
@@ -1221,10 +1230,188 @@ void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, c
   size_t lds = ((mode & kModeFill) && a.hist_lds) ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
-  (void)dyn_bins;  // ragged samples are re-binned by a pass of their own (m3hip_api.hip): no fused form of the brick kernel
+  if (dyn_bins && (mode & kModeFill)) {  // brick_can_rebin() held: the caller ran no pass of its own
+    if (mode == kModeFill) launch_brick_g<kModeFill, true, 1>(a, g, lds, k, s);
+    else launch_brick_g<kModeFill | kModeEval | kModeEventW, true, 1>(a, g, lds, k, s);
+    return;
+  }
   if (mode == kModeEval) launch_brick_mode<kModeEval, false>(a, g, lds, k, s);
   else if (mode == kModeFill) launch_brick_mode<kModeFill, false>(a, g, lds, k, s);
   else launch_brick_mode<kModeFill | kModeEval | kModeEventW, false>(a, g, lds, k, s);
+}
+bool brick_can_rebin(uint32_t brick_groups, bool packed_word) { return brick_groups <= 1 && packed_word; }
+
+// k_rebin_pack: the per-step re-binning of samples whose brick kernel cannot do it in its tail (G > 1): the event's bin from
+// its shifted kinematics (d_event_bin) straight into the bin field of its packed sample word -- one pass, 8 B read + 8 B
+// written per event beside the kinematics, instead of k_find_bins followed by a full k_pack_events (which re-read the
+// oscillation and norm indices of every event every step: +27 % on a config-3 step)
+__global__ __launch_bounds__(256) void k_rebin_pack(BinArgs a, uint64_t* evw) {
+  const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ev >= a.n_events) return;
+  const uint64_t w = evw[ev];  // requested before the binning cascade's dependent look-ups
+  const int b = d_event_bin(a, ev);
+  a.bin[ev] = b;
+  evw[ev] = (w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+}
+// The same with the binning tables in LDS (samples, axes, edges, shifts with their parameter values, cuts): the cascade of an
+// event is a chain of dependent look-ups into tables of a few KB, and from L2 that chain -- not the 24-36 B of HBM traffic per
+// event -- set the pass's time (160 us per 1e7 events, as a pass or in the brick kernel's tail).  A block brings the tables in
+// once for 4096 events; the cached nominal bins are not read at all (the binary search over LDS edges gives the same index, and
+// 4 B per event and axis stay in HBM).  WORD: the bin goes into the packed sample word's bin field only (m3hip_get_event_bins
+// reads it from there); else into `bin`.
+struct RebinLimits { static constexpr int kSamples = 32, kAxes = 64, kEdges = 2048, kShifts = 16, kCuts = 16; };
+// d_event_bin on kinematics that are already in registers (xn: the event's nominal columns)
+template <int STRIDE>
+__device__ __forceinline__ int d_event_bin_x(const BinArgs& a, int sid, const double (&xn)[STRIDE]) {
+  const BinSample sm = a.samples[sid];
+  double x[STRIDE];
+#pragma unroll
+  for (int c = 0; c < STRIDE; ++c) x[c] = xn[c];
+  for (int s = 0; s < a.n_shifts; ++s) {
+    const KinShift sh = a.shifts[s];
+    if (sh.dim < STRIDE && (sh.sample < 0 || sh.sample == sid)) {
+      const double th = a.params[sh.param];
+      const int kind = sh.kind & 0xFF, aux = sh.kind >> 8;
+#pragma unroll
+      for (int c = 0; c < STRIDE; ++c) {  // (no dynamic index into the register arrays)
+        if (c != sh.dim) continue;
+        double xa = xn[0];
+#pragma unroll
+        for (int q = 1; q < STRIDE; ++q) xa = aux == q ? xn[q] : xa;
+        x[c] = kind == 1 ? x[c] * (1.0 + th) : (kind == 2 ? x[c] + th : x[c] + th * xa);
+      }
+    }
+  }
+  bool out = false;
+  for (int ci = 0; ci < a.n_cuts; ++ci) {
+    const KinCut ct = a.cuts[ci];
+    if (ct.column < STRIDE && (ct.sample < 0 || ct.sample == sid)) {
+      double v = x[0];
+#pragma unroll
+      for (int q = 1; q < STRIDE; ++q) v = ct.column == q ? x[q] : v;
+      if ((v < ct.lo) || (v >= ct.hi)) out = true;
+    }
+  }
+  int global = 0;
+#pragma unroll
+  for (int d = 0; d < STRIDE; ++d) {
+    if (d < sm.n_dim) {
+      const BinAxis ax = a.axes[sm.axis_off + d];
+      const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], -1);
+      if (b < 0) out = true;
+      global += b * ax.stride;
+    }
+  }
+  return out ? -1 : global + sm.global_offset;  // (uniform samples only: rebin_tables_fit_lds)
+}
+// STRIDE = kin_stride when it is 1 or 2: the workgroups are persistent (the tables come in once), a lane's next event is
+// requested while its current one walks the tables; 0: any stride, one event after the other
+template <bool WORD, int STRIDE>
+__global__ __launch_bounds__(1024) void k_rebin_lds(BinArgs a, uint64_t* __restrict__ evw, int n_samples, int n_axes, int n_edges) {
+  __shared__ BinSample s_samples[RebinLimits::kSamples];
+  __shared__ BinAxis s_axes[RebinLimits::kAxes];
+  __shared__ double s_edges[RebinLimits::kEdges];
+  __shared__ KinShift s_shifts[RebinLimits::kShifts];
+  __shared__ double s_theta[RebinLimits::kShifts];
+  __shared__ KinCut s_cuts[RebinLimits::kCuts];
+  __shared__ int s_moves[RebinLimits::kSamples];  // whether a registered shift touches the sample: the others keep their nominal bins
+  const int t = threadIdx.x;
+  if (t < n_samples) {
+    s_samples[t] = a.samples[t];
+    int moves = 0;
+    for (int q = 0; q < a.n_shifts; ++q) moves |= (a.shifts[q].sample < 0 || a.shifts[q].sample == t) ? 1 : 0;
+    s_moves[t] = moves;
+  }
+  if (t < n_axes) s_axes[t] = a.axes[t];
+  for (int i = t; i < n_edges; i += 1024) s_edges[i] = a.edges[i];
+  if (t < a.n_shifts) {
+    KinShift sh = a.shifts[t];
+    s_theta[t] = a.params[sh.param];
+    sh.param = t;  // index into s_theta
+    s_shifts[t] = sh;
+  }
+  if (t < a.n_cuts) s_cuts[t] = a.cuts[t];
+  __syncthreads();
+  BinArgs al = a;
+  al.samples = s_samples;
+  al.axes = s_axes;
+  al.edges = s_edges;
+  al.shifts = s_shifts;
+  al.params = s_theta;
+  al.cuts = s_cuts;
+  al.nom_bin = nullptr;
+  if (n_samples == 1) al.sample_id = nullptr;
+  const uint64_t step = (uint64_t)gridDim.x * 1024u;
+  if constexpr (STRIDE == 0) {
+    for (uint64_t ev = (uint64_t)blockIdx.x * 1024u + t; ev < a.n_events; ev += step) {
+      if (!s_moves[al.sample_id ? al.sample_id[ev] : 0]) continue;
+      uint64_t w = 0;
+      if (WORD) w = evw[ev];
+      const int b = d_event_bin(al, ev);
+      if (WORD) evw[ev] = (w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+      else a.bin[ev] = b;
+    }
+  } else {
+    const double* __restrict__ kin = a.kin;
+    const int32_t* __restrict__ sidp = al.sample_id;
+    struct In { double x[STRIDE]; uint64_t w; int sid; };
+    auto fetch = [&](uint64_t ev, In& in) {
+      const uint64_t e = ev < a.n_events ? ev : a.n_events - 1;  // (past the end: a valid event, dropped)
+      in.sid = sidp ? sidp[e] : 0;
+      // events of samples no shift touches are neither read nor written (one sample: no test, one round trip)
+      const bool moves = sidp ? s_moves[in.sid] != 0 : true;
+#pragma unroll
+      for (int c = 0; c < STRIDE; ++c) in.x[c] = moves ? kin[e * STRIDE + c] : 0.0;
+      in.w = WORD && moves ? evw[e] : 0;
+      if (!moves) in.sid = -1;
+    };
+    uint64_t ev = (uint64_t)blockIdx.x * 1024u + t;
+    In cur, nxt;
+    fetch(ev, cur);
+    for (; ev < a.n_events; ev += step) {
+      fetch(ev + step, nxt);
+      if (cur.sid >= 0) {
+        const int b = d_event_bin_x<STRIDE>(al, cur.sid, cur.x);
+        if (WORD) evw[ev] = (cur.w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+        else a.bin[ev] = b;
+      }
+      cur = nxt;
+    }
+  }
+}
+bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform) {
+  return !nonuniform && n_samples <= RebinLimits::kSamples && n_axes <= RebinLimits::kAxes && n_edges <= RebinLimits::kEdges && n_shifts <= RebinLimits::kShifts &&
+         n_cuts <= RebinLimits::kCuts;
+}
+void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s) {
+  if (a.n_events == 0) return;
+  const uint64_t chunks = (a.n_events + 1023) / 1024;
+  const dim3 g((unsigned)(chunks < 512 ? chunks : 512));  // two workgroups of 1024 lanes per CU; each strides over the events
+  const dim3 b(1024);
+#define M3_REBIN(WORD, STRIDE) hipLaunchKernelGGL((k_rebin_lds<WORD, STRIDE>), g, b, 0, s, a, evw, n_samples, n_axes, n_edges)
+  if (evw) {
+    if (a.kin_stride == 1) M3_REBIN(true, 1);
+    else if (a.kin_stride == 2) M3_REBIN(true, 2);
+    else M3_REBIN(true, 0);
+  } else {
+    if (a.kin_stride == 1) M3_REBIN(false, 1);
+    else if (a.kin_stride == 2) M3_REBIN(false, 2);
+    else M3_REBIN(false, 0);
+  }
+#undef M3_REBIN
+}
+void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s) {
+  if (a.n_events == 0) return;
+  hipLaunchKernelGGL(k_rebin_pack, dim3((unsigned)((a.n_events + 255) / 256)), dim3(256), 0, s, a, evw);
+}
+// the bin field of the packed words back into `bin` (m3hip_get_event_bins after steps that re-binned into the words only)
+__global__ __launch_bounds__(256) void k_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n) {
+  const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ev < n) bin[ev] = (int32_t)((uint32_t)evw[ev] & 0xFFFFFu) - 1;
+}
+void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_unpack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, evw, bin, n);
 }
 
 // ------------------------------------------------------------------------------------

@@ -1439,3 +1439,85 @@ def test_deterministic_fill_needs_the_private_bin_vector(fresh_engine):
         sh.Reweight()
     eng.set_deterministic(False)
     sh.Reweight()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_into_word_g2", "lds_pass_into_word_g4", "brick_tail", "global_pass_into_word_g4",
+                                  "lds_pass_no_word", "global_pass_no_word"])
+def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
+    """SURVEY 8f row 4 on a brick sample of a size where the launch has rounds of workgroups (120 000 events of configs[2]'s
+    shape): an energy-scale functional parameter re-bins every event every step (ApplyShifts, Samples/SampleHandlerFD.cpp:545-564;
+    FindBin with the cached nominal bin, Samples/SampleStructs.h:577-613).  Every device form against the oracle: the pass with
+    the binning tables in LDS that rewrites the packed words' bin field (the default; bricks of 1024, 2048 and 4096 events), the
+    brick kernel's own tail (M3HIP_REBIN=tail), the passes over global tables (k_rebin_pack, k_find_bins), samples without the
+    packed word.  Bins integer-exact, event weights bit-exact, bin contents 1e-12, LLH 1e-9."""
+    from mach3_amd.engine import Engine
+    if path.endswith("_g2"):
+        monkeypatch.setenv("M3HIP_BRICK_GROUPS", "2")
+    if path.endswith("_g4"):
+        monkeypatch.setenv("M3HIP_BRICK_GROUPS", "4")
+    if "no_word" in path:
+        monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
+    if path == "brick_tail":
+        monkeypatch.setenv("M3HIP_REBIN", "tail")
+    if path.startswith("global"):
+        monkeypatch.setenv("M3HIP_REBIN", "global")
+    spec = synth.CONFIGS["c3"].scaled(120_000)
+    E, NP = spec.n_events, spec.n_par
+    lib = ob.load("serial")
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, E)
+    ev = synth.events_chunk(spec, 0, E)
+    opar = np.concatenate([synth.params(spec, 0), [0.0]])
+    omono = ob.OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    edges = synth.bin_edges(spec)
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, ev["sample_id"], ev["erec"], ev["norm_off"], ev["norm_idx"], opar, ev["osc_idx"], synth.osc_table(spec), omono)
+    osamp.set_test_statistic(spec.test_statistic, False)
+    osamp.add_shift(-1, 0, 1, opar, NP)
+
+    eng = Engine(0)
+    try:
+        par = opar.copy()
+        mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, [ch], expect_events=E)
+        mono.setSplinePointers(par)
+        sh = SampleHandlerFD(eng, 1, None, par, spec.test_statistic, bin_edges=[[edges]])
+        sh.SetupKinematics(0, ev["sample_id"], ev["erec"])
+        sh.ComputeBins()
+        sh.SetupEvents(0, sh.GetEventBins(0, E), ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+        sh.SetOscillationWeights(synth.osc_table(spec))
+        sh.AddKinShift(-1, 0, 1, NP)
+        info = eng.info()
+        assert info.n_tiles_brick > 0 and info.n_tiles_uniform == 0
+        assert int(info.brick_groups) == (2 if path.endswith("_g2") else 4 if path.endswith("_g4") else 1)
+        sh.RecordEventWeights(True)
+        sh.Reweight()
+        osamp.reweight()
+        sh.AddData(osamp.mc)
+        osamp.add_data(osamp.mc)
+        nominal = osamp.event_bins().copy()
+        moved = 0
+        for lap, scale in enumerate([0.0, 0.013, -0.02, 0.2, -0.35, 0.0]):
+            par[:NP] = synth.params(spec, 1 + lap)
+            par[NP] = scale
+            opar[:] = par
+            sh.Reweight()
+            llh = sh.GetLikelihood()
+            osamp.reweight()
+            got, exp = sh.GetEventBins(0, E), osamp.event_bins()
+            assert np.array_equal(got, exp), (path, scale)
+            moved += int((exp != nominal).sum())
+            assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32)), (path, scale)
+            assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), (path, scale)
+            _llh_close(llh, osamp.get_likelihood())
+        assert moved > E // 4
+        sh.ClearKinShifts()           # back to the nominal bins; the packed words follow
+        par[NP] = opar[NP] = 0.3       # ... and the parameter no longer moves anything
+        sh.Reweight()
+        assert np.array_equal(sh.GetEventBins(0, E), nominal)
+    finally:
+        eng.close()
+        osamp.close()
+        omono.close()
