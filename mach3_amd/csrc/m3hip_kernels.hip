@@ -1261,8 +1261,11 @@ __global__ __launch_bounds__(256) void k_rebin_pack(BinArgs a, uint64_t* evw) {
 // reads it from there); else into `bin`.
 struct RebinLimits { static constexpr int kSamples = 32, kAxes = 64, kEdges = 2048, kShifts = 16, kCuts = 16; };
 // d_event_bin on kinematics that are already in registers (xn: the event's nominal columns)
+// `last_global`: the event's global bin of the previous step (-1: none) -- for 1-D samples the cascade's "nominal" bin: parameters
+// move little from step to step, so the +-1 neighbour test (five independent LDS reads) nearly always replaces the binary search
+// (eight dependent ones); every route gives the same index
 template <int STRIDE>
-__device__ __forceinline__ int d_event_bin_x(const BinArgs& a, int sid, const double (&xn)[STRIDE]) {
+__device__ __forceinline__ int d_event_bin_x(const BinArgs& a, int sid, const double (&xn)[STRIDE], int last_global) {
   const BinSample sm = a.samples[sid];
   double x[STRIDE];
 #pragma unroll
@@ -1297,7 +1300,9 @@ __device__ __forceinline__ int d_event_bin_x(const BinArgs& a, int sid, const do
   for (int d = 0; d < STRIDE; ++d) {
     if (d < sm.n_dim) {
       const BinAxis ax = a.axes[sm.axis_off + d];
-      const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], -1);
+      int hint = -1;
+      if (d == 0 && sm.n_dim == 1 && last_global >= sm.global_offset && last_global - sm.global_offset < ax.n_bins) hint = last_global - sm.global_offset;
+      const int b = d_find_bin(a.edges + ax.edge_off, ax.n_bins, x[d], hint);
       if (b < 0) out = true;
       global += b * ax.stride;
     }
@@ -1371,9 +1376,13 @@ __global__ __launch_bounds__(1024) void k_rebin_lds(BinArgs a, uint64_t* __restr
     for (; ev < a.n_events; ev += step) {
       fetch(ev + step, nxt);
       if (cur.sid >= 0) {
-        const int b = d_event_bin_x<STRIDE>(al, cur.sid, cur.x);
-        if (WORD) evw[ev] = (cur.w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
-        else a.bin[ev] = b;
+        const int b = d_event_bin_x<STRIDE>(al, cur.sid, cur.x, WORD ? (int)((uint32_t)cur.w & 0xFFFFFu) - 1 : -1);
+        if (WORD) {  // only events that changed bin are written back
+          const uint64_t w = (cur.w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+          if (w != cur.w) evw[ev] = w;
+        } else {
+          a.bin[ev] = b;
+        }
       }
       cur = nxt;
     }
