@@ -118,19 +118,26 @@ def log(*a):
 def pmc_traffic(config_name, per_gpu):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_<config>_pmc_*.json: FETCH_SIZE and WRITE_SIZE collected in separate runs and
-    corrected as MI355X_MICROARCH.md prescribes).  The newest profile of this workload wins; None when
-    no profile matches."""
+    corrected as MI355X_MICROARCH.md prescribes).  The newest profile of this configuration at this number of events per
+    GPU wins; failing that, the newest profile of the configuration at another size, scaled by events (the store and its
+    traffic are linear in the events of one configuration; the line says so: `traffic_scaled_from_events`).  None when no
+    profile of the configuration exists."""
     import glob
-    best = None
+    exact, other = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config_name}_pmc_*.json"))):
         try:
             d = json.load(open(f))
             for k, v in d["kernels"].items():
-                if "k_reweight" in k and "hbm_bytes_per_launch" in v and d.get("events_per_gpu", 1_000_000) == per_gpu:
-                    best = {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "round": d.get("round")}
+                if "k_reweight" in k and "hbm_bytes_per_launch" in v:
+                    ev = d.get("events_per_gpu", 1_000_000)
+                    rec = {"bytes": v["hbm_bytes_per_launch"], "source": os.path.relpath(f, ROOT), "round": d.get("round")}
+                    if ev == per_gpu:
+                        exact = rec
+                    elif ev > 0:
+                        other = dict(rec, bytes=v["hbm_bytes_per_launch"] * per_gpu / ev, scaled_from_events=ev)
         except Exception:
             pass
-    return best
+    return exact or other
 
 
 EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "2"))  # a 20-step driver run times 10 launches
@@ -514,6 +521,7 @@ def roofline(base_name, m, per_gpu):
         "traffic_source": tr["source"] if tr else None,
         "traffic_measured_in_run": False,  # a constant from the committed rocprofv3 --pmc passes of this workload (counters cannot be read in-process)
         "traffic_profile_round": tr.get("round") if tr else None,
+        "traffic_scaled_from_events": tr.get("scaled_from_events") if tr else None,  # not None: the profile is of this configuration at another size
         "alg_bytes_per_launch": int(info.alg_bytes_fused),
         "avg_kernel_ms": k_ms,
         "launches_timed": m["k_n"],
