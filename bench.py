@@ -393,17 +393,20 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         t[rank] = k_ms
         dist.all_reduce(t)
         k_all = [float(x) for x in t.cpu()]
-    oneshot = None
-    if in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
-        oneshot = oneshot_leg(eng, step, rank, n_ranks, dist, torch, args)
     check = None
     if args.check:  # LLH of a few laps, for the comparison with a one-rank run of the same sample
         check = []
         for i in range(3):
             check.append(step(1000 + i))
-    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=oneshot,
-               comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all)
-    eng.close()
+    # the one-shot leg runs AFTER the caller has the line's numbers in hand (main() guards it with a watchdog: nothing that
+    # happens in an `extra` may cost the run its line)
+    after = None
+    if in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
+        after = lambda: oneshot_leg(eng, step, rank, n_ranks, dist, torch, args)  # noqa: E731
+    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=None,
+               comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all, after=after, close=eng.close)
+    if after is None:
+        eng.close()
     return out
 
 
@@ -606,6 +609,7 @@ def main():
             check = {"llh_sharded": m["check"], "llh_one_rank": one["check"], "max_rel_diff": rel, "ok": bool(rel <= 1e-9)}
         dist.barrier()
 
+    out = None
     if rank == 0:
         per_gpu = m["e1"] - m["e0"]
         out = {
@@ -636,6 +640,8 @@ def main():
             },
             "roofline": roofline(base.name, m, per_gpu),
         }
+        if m.get("after") is not None:
+            out.setdefault("extra", {})["oneshot_exchange"] = None  # filled in below
         if m["comm_val"] is not None:
             # self-validation of the exchange on the untimed steps (every rank; the worst bin of the worst rank), the time the
             # exchange adds between the reweight kernel's end and the bin likelihood's start, and every rank's kernel time
@@ -643,8 +649,6 @@ def main():
             out["config"]["comm_validated_steps"] = m["comm_val"]["validated_steps"]
             out["config"]["comm_max_rel"] = m["comm_val"]["max_rel"]
             out["config"]["comm_us"] = m["comm_us"]
-        if m.get("oneshot") is not None:
-            out.setdefault("extra", {})["oneshot_exchange"] = m["oneshot"]
         if len(m["k_all"]) > 1:
             out["roofline"]["avg_kernel_ms_by_rank"] = {"min": min(m["k_all"]), "max": max(m["k_all"])}
         if check is not None:
@@ -666,6 +670,33 @@ def main():
                                                "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}
             except Exception as e:
                 out.setdefault("extra", {})["configs[1]"] = {"failed": str(e)}
+    if m.get("after") is not None:
+        # every rank runs the leg (its steps are collectives); a rank whose leg does not return within the limit prints the
+        # line without it (rank 0) and leaves -- a hung `extra` must not cost the run its line
+        import threading
+        limit = float(os.environ.get("M3_BENCH_ONESHOT_LIMIT_S", "180"))
+
+        def give_up():
+            if rank == 0:
+                out["extra"]["oneshot_exchange"] = {"error": f"did not finish within {limit:.0f} s; abandoned (the line above it stands)"}
+                print(json.dumps(out), file=json_out, flush=True)
+            log(f"[bench] rank {rank}: the one-shot leg did not return within {limit:.0f} s; leaving without it")
+            os._exit(0 if check is None or check["ok"] else 4)
+        wd = threading.Timer(limit, give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            res = m["after"]()
+        except Exception as e:  # (the leg reports its own failures as text; this is the belt to those braces)
+            res = {"error": f"rank {rank}: {e}"}
+        wd.cancel()
+        if rank == 0:
+            out["extra"]["oneshot_exchange"] = res
+        try:
+            m["close"]()
+        except Exception:
+            pass
+    if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
         if check is not None and not check["ok"]:
             raise SystemExit(4)

@@ -147,6 +147,7 @@ struct m3hip_ctx {
   uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
   bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
   bool evw_ok = false;            // the sample fits the packed word's fields
+  char sw_packed = '1', sw_rebin = 'p';  // M3HIP_PACKED_EVENTS / M3HIP_REBIN as they stood at monolith_begin (experiments, tests): the step path reads no environment
   bool bins_in_word = false;      // the last re-binning pass wrote the words' bin field only: d_bin is stale (bins_from_word)
   uint32_t evw_norm_slots = 0;    // norm slots the word carries: M3_EVW_NORM_SLOTS, or 0 when the sample's norm indices do not fit its codes
   int64_t min_norm_idx = INT64_MAX, max_norm_idx_evw = -1;  // over the slots the packed word holds (an event's first M3_EVW_NORM_SLOTS)
@@ -560,8 +561,7 @@ int bins_from_word(m3hip_handle h) {
 // whether the events' sample side fits the brick kernel's packed 8-byte word (ReweightArgs::evw)
 bool evw_fits(m3hip_handle h) {
   bool ok = !h->f64 && !h->h_bricks.empty() && h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->d_bin && h->d_osc;
-  if (const char* f = getenv("M3HIP_PACKED_EVENTS")) ok = ok && f[0] != '0';
-  return ok;
+  return ok && h->sw_packed != '0';
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
@@ -763,6 +763,8 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_monolith(h);
+  { const char* f = getenv("M3HIP_PACKED_EVENTS"); h->sw_packed = f && f[0] ? f[0] : '1'; }
+  { const char* f = getenv("M3HIP_REBIN"); h->sw_rebin = f && f[0] ? f[0] : 'p'; }
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
   h->expect_events = 0;
   h->P = n_params;
@@ -2038,9 +2040,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     // norm parameters spread over more than 62 indices do not fit the word's 6-bit codes: the word then carries bin and
     // oscillation index only, and the kernel's tail reads every norm slot from the index planes
     h->evw_norm_slots = (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) ? uint32_t(M3_EVW_NORM_SLOTS) : 0u;
-    if (const char* f = getenv("M3HIP_PACKED_EVENTS")) {
-      if (f[0] == 'b') h->evw_norm_slots = 0;  // "b": bin and oscillation index only (tests)
-    }
+    if (h->sw_packed == 'b') h->evw_norm_slots = 0;  // M3HIP_PACKED_EVENTS=b: bin and oscillation index only (tests)
     if (h->evw_ok) {
       if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
       launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
@@ -2061,9 +2061,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   for (const BinSample& bs : h->bb_samples) nonuniform = nonuniform || !bs.uniform;
   const bool lds_ok = rebin_tables_fit_lds(int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), int(h->h_shifts.size()),
                                            int(h->h_cuts.size()), nonuniform);
-  const char* rebin_env = getenv("M3HIP_REBIN");  // experiments / tests: tail | pass | global
-  const bool want_tail = rebin_env && rebin_env[0] == 't';
-  const bool use_lds = lds_ok && !(rebin_env && rebin_env[0] == 'g');
+  const bool want_tail = h->sw_rebin == 't';  // M3HIP_REBIN = tail | pass | global (experiments / tests)
+  const bool use_lds = lds_ok && h->sw_rebin != 'g';
   const bool brick_tail = want_tail && brick_can_rebin(uint32_t(h->brick_groups), word_valid);
   const bool dyn_pass = dyn_any && (h->f64 || (!h->h_bricks.empty() && !brick_tail));
   const bool dyn_bins = dyn_any && !dyn_pass;  // fused
