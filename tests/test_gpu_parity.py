@@ -1521,3 +1521,82 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         eng.close()
         osamp.close()
         omono.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_no_word", "brick_tail", "global_pass_into_word"])
+def test_functional_shifts_on_a_ragged_two_sample_2d_space(path, monkeypatch):
+    """The re-binning forms on bricks with TWO kinematic columns and two samples (60 000 ragged events): a 2-D sample moved by an
+    energy scale and by `y += theta * E` (the aux form), with a selection cut on the shifted y, beside a 1-D sample that no
+    shift touches (its events keep their nominal bins and are neither read nor written by the LDS pass).  Bins integer-exact
+    against the oracle, event weights bit-exact, bin contents 1e-12, LLH 1e-9."""
+    from mach3_amd.engine import Engine
+    if "no_word" in path:
+        monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
+    if path == "brick_tail":
+        monkeypatch.setenv("M3HIP_REBIN", "tail")
+    if path.startswith("global"):
+        monkeypatch.setenv("M3HIP_REBIN", "global")
+    spec = synth.CONFIGS["c3"].scaled(60_000)
+    E, NP = spec.n_events, spec.n_par
+    rng = np.random.default_rng(77)
+    lib = ob.load("serial")
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, E)
+    ev = synth.events_chunk(spec, 0, E)
+    sample_id = (rng.random(E) < 0.4).astype(np.int32)          # sample 0: 2-D, moved; sample 1: 1-D, untouched
+    kin = np.stack([ev["erec"], rng.uniform(-1.05, 1.05, E)], axis=1)
+    ex, ey = synth.bin_edges(spec), np.linspace(-1.0, 1.0, 7)
+    opar = np.concatenate([synth.params(spec, 0), [0.0, 0.0]])
+    omono = ob.OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([ex, ey])
+    b.add_uniform([ex])
+    osamp = ob.OracleSample(lib, b, sample_id, kin, ev["norm_off"], ev["norm_idx"], opar, ev["osc_idx"], synth.osc_table(spec), omono)
+    osamp.set_test_statistic(spec.test_statistic, False)
+    osamp.add_shift(0, 0, 1, opar, NP)                 # E *= 1 + theta_0, sample 0
+    osamp.add_shift(0, 1, 3 | (0 << 8), opar, NP + 1)  # y += theta_1 * E (nominal), sample 0
+    osamp.add_cut(0, 1, -0.9, 0.95)
+
+    eng = Engine(0)
+    try:
+        par = opar.copy()
+        mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, [ch], expect_events=E)
+        mono.setSplinePointers(par)
+        sh = SampleHandlerFD(eng, 2, None, par, spec.test_statistic, bin_edges=[[ex, ey], [ex]])
+        sh.SetupKinematics(0, sample_id, kin)
+        sh.AddKinCut(0, 1, -0.9, 0.95)
+        sh.ComputeBins()
+        nominal = sh.GetEventBins(0, E)
+        osamp.reweight()  # (the oracle bins at reweight; at theta = 0 that is the nominal binning)
+        assert np.array_equal(nominal, osamp.event_bins())
+        sh.SetupEvents(0, nominal, ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+        sh.SetOscillationWeights(synth.osc_table(spec))
+        sh.AddKinShift(0, 0, 1, NP)
+        sh.AddKinShiftAux(0, 1, 0, NP + 1)
+        assert eng.info().n_tiles_brick > 0 and eng.info().n_tiles_uniform == 0
+        sh.RecordEventWeights(True)
+        sh.Reweight()
+        sh.AddData(osamp.mc)
+        osamp.add_data(osamp.mc)
+        moved = 0
+        for lap, (s0, s1) in enumerate([(0.0, 0.0), (0.02, 0.0), (-0.03, 0.05), (0.25, -0.1), (0.0, 0.3), (0.0, 0.0)]):
+            par[:NP] = synth.params(spec, 1 + lap)
+            par[NP], par[NP + 1] = s0, s1
+            opar[:] = par
+            sh.Reweight()
+            llh = sh.GetLikelihood()
+            osamp.reweight()
+            got, exp = sh.GetEventBins(0, E), osamp.event_bins()
+            assert np.array_equal(got, exp), (path, s0, s1)
+            assert np.array_equal(got[sample_id == 1], nominal[sample_id == 1])   # the untouched sample stays put
+            moved += int((exp != nominal).sum())
+            assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32)), (path, s0, s1)
+            assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), (path, s0, s1)
+            _llh_close(llh, osamp.get_likelihood())
+        assert moved > E // 10
+    finally:
+        eng.close()
+        osamp.close()
+        omono.close()
