@@ -82,7 +82,7 @@ build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/
 .PHONY: examples
 
 # calibration programs behind the ceilings quoted in DESIGN.md / profiles/README.md (run on an MI355X)
-TOOLS = build/sector_fetch build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths build/hbm_width_bw
+TOOLS = build/sector_fetch build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths build/hbm_width_bw build/mall_probe
 tools: $(TOOLS)
 build/%: tools/%.hip
 	@mkdir -p build
