@@ -1,6 +1,7 @@
 """Soak: many fused steps in one process; reports latency percentiles per block of steps and the process RSS, to catch
 leaks (host command lists, events) and drifts.  usage: soak.py [events] [steps] [config] [samples nx ny]
-(with the last three: 2-D samples, device-side binning, Barlow-Beeston -- the many-bins form of the fill and of k_llh)"""
+(with the last three: 2-D samples, device-side binning, Barlow-Beeston -- the many-bins form of the fill and of k_llh;
+SOAK_SHIFT=1 additionally registers an energy-scale functional parameter: the per-step re-binning pass)"""
 import sys, os, time, resource
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT)
@@ -24,8 +25,15 @@ if len(sys.argv) > 6:
     sh.ComputeBins()
     sh.SetupEvents(0, sh.GetEventBins(0, ev), evs["osc_idx"], evs["norm_off"], evs["norm_idx"])
     sh.SetOscillationWeights(synth.osc_table(spec))
+shift = os.environ.get("SOAK_SHIFT") == "1" and len(sys.argv) > 6   # a functional parameter: every event re-binned every step
+if shift:
+    par = np.concatenate([par, [0.0]])
+    sh.par = par
+    sh.AddKinShift(-1, 0, 1, len(par) - 1)
 sh.Reweight(); sh.AddData(sh.GetMCArray())
 laps=[synth.params(spec,i+1) for i in range(64)]
+if shift:
+    laps = [np.concatenate([l, [0.01 * ((i % 7) - 3)]]) for i, l in enumerate(laps)]
 def rss_mb():
     with open("/proc/self/statm") as f: return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
 blk = steps // 10
