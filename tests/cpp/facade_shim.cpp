@@ -311,11 +311,19 @@ int facade_duplicate_title_refused() {
   return 0;
 }
 
+// kind + 10: the same chain with the parameter handler attached to device 0 (ParameterHandlerBase::AttachDevice): the prior and
+// the correlated throw of every step come from the m3hip_par_* kernels through MCMCBase::EvaluateProposal (needs a GPU)
 int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out) {
+  m3hip_handle dev = nullptr;
   try {
     const std::vector<double> prefit = {0.0, 0.0, 0.0};
     const std::vector<double> cov = {1.0, 0.6, 0.0, 0.6, 1.0, 0.0, 0.0, 0.0, 0.25};
     ParameterHandlerBase ph("toy", prefit, cov, {-5, -5, -5}, {5, 5, 0.6}, {}, seed + 1);
+    if (kind >= 10) {
+      kind -= 10;
+      if (m3hip_create(0, &dev) != M3HIP_OK) return -2;
+      ph.AttachDevice(dev);
+    }
     ToySample sample(ph.RetPointer(0));
     MR2T2 plain(seed);
     DelayedMR2T2 delayed(seed, 1.0, 0.3, 2, 0.1);
@@ -344,8 +352,11 @@ int facade_toy_chain(int kind, int n_steps, unsigned long long seed, double* out
     for (int i = 0; i < 3; ++i) { out[3 + i] = m[i]; out[6 + i] = v[i] / n; }
     out[9] = c01 / n;
     out[10] = double(sample.n_reweight);
+    if (dev) m3hip_destroy(dev);
     return 0;
-  } catch (const std::exception&) {
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "facade_toy_chain: %s\n", e.what());
+    if (dev) m3hip_destroy(dev);
     return -1;
   }
 }

@@ -99,3 +99,22 @@ def test_throw_matrix_cholesky(shim, n):
     out = np.zeros(3)
     assert shim.facade_cholesky_check(n, 99 + n, 4, out.ctypes.data) == 0
     assert out[0] < 1e-13 and out[1] == 1.0 and out[2] == 1.0, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,name", [(10, "MR2T2"), (12, "MR2T2+adaptive"), (11, "DelayedMR2T2")])
+def test_chain_with_the_parameter_handler_on_the_device(shim, kind, name):
+    """the same toy chains with `ParameterHandlerBase::AttachDevice`: every step's prior term and correlated throw come from the
+    device (m3hip_par_*) through MCMCBase::EvaluateProposal -- launch beside the sample's Reweight, collect behind its
+    GetLikelihood, host fallback for out-of-bounds proposals, throw matrix re-uploaded by the adaptive proposal"""
+    n = 40000
+    r = run(shim, kind, n, 777 + kind)
+    sd = np.sqrt(np.diag(POST_COV))
+    assert np.all(np.abs(r["mean"] - POST_MEAN) < 5 * sd / np.sqrt(n * 0.8 / 30)), (name, r["mean"], POST_MEAN)
+    assert np.allclose(r["var"], np.diag(POST_COV), rtol=0.30 if kind == 11 else 0.15), (name, r["var"], np.diag(POST_COV))
+    assert 0.02 < r["acc"] < 0.75, (name, r["acc"])
+    if kind == 10:
+        assert r["oob"] > 0 and r["n_reweight"] == n + 1 - r["oob"]
+        # ... and the device chain walks the host chain's path: same seeds, same decisions (the sums differ by rounding only)
+        h = run(shim, 0, n, 777 + kind)
+        assert abs(r["acc"] - h["acc"]) < 0.02 and np.allclose(r["mean"], h["mean"], atol=0.02)
