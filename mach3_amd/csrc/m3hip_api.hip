@@ -179,6 +179,11 @@ struct m3hip_ctx {
   float* d_osc_table = nullptr;
   uint64_t n_osc = 0;
   bool osc_valid_f32 = false, osc_valid_f64 = false;  // which precision of the table is current on the device
+  // per-event oscillation weights for the brick kernel, expanded from a large table once it has stopped changing
+  float* d_oscw = nullptr;
+  bool oscw_valid = false;
+  int osc_static_steps = 0;       // reweights since the table or the events' oscillation indices last changed
+  int oscw_mode = -1;             // M3HIP_OSC_COLUMN: 0 never, 1 as soon as possible whatever the table's size, -1 the rule
   void* h_osc_stage[2] = {nullptr, nullptr};           // pinned staging of the per-step table upload
   uint64_t osc_stage_ticket[2] = {0, 0};
   int osc_stage_pos = 0;
@@ -463,6 +468,9 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bin); h->d_bin = nullptr;
   dev_free(h->d_osc); h->d_osc = nullptr;
   dev_free(h->d_nidx); h->d_nidx = nullptr;
+  dev_free(h->d_oscw); h->d_oscw = nullptr;
+  h->oscw_valid = false;
+  h->osc_static_steps = 0;
   dev_free(h->d_evw); h->d_evw = nullptr;
   h->evw_dirty = true;
   h->evw_ok = false;
@@ -765,6 +773,7 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   free_monolith(h);
   { const char* f = getenv("M3HIP_PACKED_EVENTS"); h->sw_packed = f && f[0] ? f[0] : '1'; }
   { const char* f = getenv("M3HIP_REBIN"); h->sw_rebin = f && f[0] ? f[0] : 'p'; }
+  { const char* f = getenv("M3HIP_OSC_COLUMN"); h->oscw_mode = f && f[0] ? atoi(f) : -1; }
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
   h->expect_events = 0;
   h->P = n_params;
@@ -1225,6 +1234,8 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   h->evw_dirty = true;
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   if (osc_idx) {
+    h->oscw_valid = false;
+    h->osc_static_steps = 0;
     for (uint64_t i = 0; i < n; ++i) {
       // -1 = no oscillation weight; anything below would run into the packed sample word's neighbouring fields (k_pack_events)
       if (osc_idx[i] < -1) return fail(h, M3HIP_EINVAL, "upload_events: oscillation index below -1");
@@ -1779,6 +1790,8 @@ int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) try {
   if ((rc = osc_upload(h, table, n, sizeof(float), h->d_osc_table))) return rc;
   h->osc_valid_f32 = true;
   h->osc_valid_f64 = false;
+  h->oscw_valid = false;
+  h->osc_static_steps = 0;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -1791,6 +1804,8 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) try
   if ((rc = osc_upload(h, table, n, sizeof(double), h->d_osc_table_d))) return rc;
   h->osc_valid_f64 = true;
   h->osc_valid_f32 = false;
+  h->oscw_valid = false;
+  h->osc_static_steps = 0;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -2095,6 +2110,19 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       h->osc_valid_f32 = true;
     }
   }
+  // A large oscillation table does not stay in L2 beside the brick kernel's streams, and every event's gather from it then
+  // goes to memory (one GPU's share of config 5, 204 000 entries: 5.5 % of the kernel).  Once table and indices have been
+  // left alone for two steps -- a pre-staged table; a fit that moves oscillation parameters re-uploads it every step and never
+  // gets here -- the weights are gathered ONCE into a per-event column the kernel streams (4 B per event).
+  if (!h->f64 && !h->h_bricks.empty() && h->n_osc && h->d_osc && h->oscw_mode != 0) {
+    ++h->osc_static_steps;
+    const bool large = sizeof(float) * h->n_osc > 64 * 1024;
+    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && h->osc_static_steps > 2))) {
+      if (!h->d_oscw && (rc = dev_alloc(h, &h->d_oscw, size_t(h->E_pad)))) return rc;
+      launch_osc_expand(h->d_osc, h->d_osc_table, h->d_oscw, h->E_pad, h->stream);
+      h->oscw_valid = true;
+    }
+  }
   if (h->perm_dirty) {  // processing order of a binned-only event space: stable sort of the events by pointer list
     h->perm_dirty = false;
     if (h->bl_mode == 1 && h->S + h->T == 0) {
@@ -2115,6 +2143,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;
   }
+  if (h->oscw_valid && !h->f64) a.oscw = h->d_oscw;
   if (word_valid) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);

@@ -110,6 +110,7 @@ void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s);
 // ... with the binning tables in LDS (uniform samples whose tables fit: rebin_tables_fit_lds); evw null: into a.bin instead
 bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform);
 void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s);
+void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint64_t n, hipStream_t s);
 void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream_t s);
 // whether the brick kernel re-bins in its own tail (launch_reweight_brick with dyn_bins) for this shape of sample
 bool brick_can_rebin(uint32_t brick_groups, bool packed_word);
@@ -160,6 +161,8 @@ struct ReweightArgs {
   const float* bw;           // weightvec_Monolith of the binned spline handler
   uint32_t n_bw_slots;
   const float* osc_table;
+  const float* oscw;         // [E_pad] or null: the events' oscillation weights themselves (brick kernel; the engine expands a large
+                             // table that has stopped changing: k_osc_expand), 1.0 where an event has no oscillation pointer
   const ExtraSlot* extras;   // [n_extra] device array, multiplied after the spline weight in slot order
   uint32_t n_extra;
   // M3::float_t = double build of the sample side (Manager/Core.h:27-51: the default, non-low-memory

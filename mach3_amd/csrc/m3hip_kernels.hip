@@ -879,6 +879,13 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     ev_valid = le < bd.n_events;
     ev_own = bd.first_event + (ev_valid ? le : 0u);  // idle lanes shadow the brick's first event
     if (a.perm) ev_own = a.perm[ev_own];  // processing order -> event; kernel-uniform branch: only grouped uploads pay this dependent load
+    if (MODE & (kModeFill | kModeEventW)) {
+      // the event's oscillation weight itself when the engine has expanded a large, static table into a per-event column
+      // (ReweightArgs::oscw): requested with the indices, not behind them.  No branch around the load: without the column
+      // every lane reads the same word of the brick descriptors and drops it.
+      const float* ow = a.oscw ? a.oscw + ev_own : (const float*)a.bricks;
+      t_oscw = *ow;
+    }
     if ((MODE & (kModeFill | kModeEventW)) && PACK) {  // the event's indices in one 8-byte word
       t_pack = a.evw[ev_own];
       return;
@@ -912,7 +919,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
       const float* ot = a.osc_table ? a.osc_table : (const float*)a.bricks;
       const double* pp = a.params ? a.params : (const double*)a.bricks;
-      t_oscw = ot[t_osc >= 0 ? t_osc : 0];
+      const float from_table = ot[(t_osc >= 0 && !a.oscw) ? t_osc : 0];  // (with the column: everybody reads entry 0 and drops it)
+      t_oscw = a.oscw ? t_oscw : from_table;
 #pragma unroll
       for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
     }
@@ -1412,6 +1420,19 @@ void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes
 void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s) {
   if (a.n_events == 0) return;
   hipLaunchKernelGGL(k_rebin_pack, dim3((unsigned)((a.n_events + 255) / 256)), dim3(256), 0, s, a, evw);
+}
+// k_osc_expand: the events' oscillation weights as a column (1.0 for events without an oscillation pointer).  A table of
+// hundreds of KB does not stay in L2 beside the streams, and the per-event gather from it cost 5.5 % of the brick kernel on one
+// GPU's share of config 5 (204 000 entries): when the table has not changed for a few steps the engine gathers ONCE.
+__global__ __launch_bounds__(256) void k_osc_expand(const int32_t* __restrict__ osc, const float* __restrict__ table, float* __restrict__ out, uint64_t n) {
+  const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ev >= n) return;
+  const int32_t i = osc[ev];
+  out[ev] = i >= 0 ? table[i] : 1.0f;
+}
+void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint64_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_osc_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, osc, table, out, n);
 }
 // the bin field of the packed words back into `bin` (m3hip_get_event_bins after steps that re-binned into the words only)
 __global__ __launch_bounds__(256) void k_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n) {

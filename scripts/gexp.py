@@ -8,6 +8,8 @@ from mach3_amd import synth
 from mach3_amd.engine import build_from_synth
 cfg, ev = sys.argv[1], int(sys.argv[2])
 kw = {"mixed": False} if len(sys.argv) > 3 and sys.argv[3] == "spl" else {}
+if os.environ.get("M3_GEXP_OSC_N"):  # size of the pre-staged oscillation table (config 5: 204 000 entries; the others 4 000)
+    kw["osc_n"] = int(os.environ["M3_GEXP_OSC_N"])
 spec = synth.CONFIGS[cfg].scaled(ev, **kw)
 engine = None
 if os.environ.get("M3_GEXP_REPLICAS"):  # flush replicas of the bin vector (1 .. 64) instead of the engine's choice

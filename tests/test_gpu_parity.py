@@ -1645,3 +1645,63 @@ def test_parameter_handler_kernels_through_the_c_abi(fresh_engine):
         eng.par_launch(np.zeros(3), np.zeros(3))
     with pytest.raises(capi.M3HipError, match="which is 0"):
         eng.par_upload(2, np.eye(3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rule", "always", "never"])
+def test_large_static_oscillation_table_becomes_a_per_event_column(mode, monkeypatch):
+    """A pre-staged oscillation table of hundreds of KB (BASELINE configs[4]: 204 000 entries) does not stay in L2 beside the
+    brick kernel's streams; once table and indices have been left alone for two steps the engine gathers the weights ONCE into a
+    per-event column the kernel streams.  Same numbers either way: event weights bit-exact against the oracle through the
+    transitions gather -> column -> (table re-uploaded) gather -> column, with events that have no oscillation pointer, zero
+    weights, and a slice of indices re-uploaded.  `M3HIP_OSC_COLUMN` = 1 / 0 forces / forbids the column."""
+    from mach3_amd.engine import Engine
+    if mode != "rule":
+        monkeypatch.setenv("M3HIP_OSC_COLUMN", "1" if mode == "always" else "0")
+    # 200 KB of weights: "large" by the engine's rule.  Poisson: the oracle sample is re-created half way (new indices), and a
+    # Barlow-Beeston sample would freeze another W2 there than the engine's
+    spec = synth.CONFIGS["c3"].scaled(40_000, n_params=64, osc_n=50_000, test_statistic=capi.kPoisson)
+    eng = Engine(0)
+    try:
+        eng2, mono, sh, par = build_from_synth(spec, engine=eng)
+        omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, spec.n_events)
+        otbl = osamp.keep[7]
+        osc_idx = osamp.keep[6]
+        assert (osc_idx >= 0).sum() > 20_000 and (osc_idx < 0).sum() > 0 and eng.info().n_tiles_brick > 0
+        sh.RecordEventWeights(True)
+        sh.Reweight()
+        osamp.reweight()
+        data = osamp.mc.copy()
+        sh.AddData(data)
+        osamp.add_data(data)
+        rng = np.random.default_rng(4)
+        for lap in range(1, 16):
+            if lap in (6, 7):       # the table moves for two steps: back to the gather
+                otbl[:] = rng.random(len(otbl)).astype(np.float32)
+                if lap == 7:
+                    otbl[::5] = 0.0
+                sh.SetOscillationWeights(otbl)
+            if lap == 12:           # a slice of the events' oscillation indices changes (and with it their bins' contents)
+                sl = slice(1024, 9000)
+                osc_idx = osc_idx.copy()
+                osc_idx[sl] = rng.integers(-1, spec.osc_n, sl.stop - sl.start).astype(np.int32)
+                sh.SetupEvents(0, ev["bin_idx"], osc_idx, ev["norm_off"], ev["norm_idx"])
+                # (the oracle resolves its events' pointers when the sample is created: a new sample over the new indices)
+                osamp.close()
+                b2 = ob.OracleBinning(ob.load("serial"))
+                b2.add_uniform([synth.bin_edges(spec)])
+                osamp = ob.OracleSample(ob.load("serial"), b2, ev["sample_id"], ev["erec"], ev["norm_off"], ev["norm_idx"], opar, osc_idx, otbl, omono)
+                osamp.set_test_statistic(spec.test_statistic, False)
+                osamp.reweight()
+                osamp.add_data(data)
+            par[:] = synth.params(spec, lap)
+            opar[:] = par
+            llh = sh.Step()
+            osamp.reweight()
+            assert np.array_equal(sh.GetEventWeights(0, spec.n_events).view(np.uint32), osamp.event_weights().view(np.uint32)), (mode, lap)
+            assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0), (mode, lap)
+            _llh_close(llh, osamp.get_likelihood())
+        osamp.close()
+        omono.close()
+    finally:
+        eng.close()
