@@ -135,6 +135,7 @@ struct m3hip_ctx {
   double dbg_dev_us = 0;            // device-side k_prep start -> k_llh end of the last step
   int par_cap = 0;
   double* d_params = nullptr;  // [par_cap + 1]
+  float* d_params_f32 = nullptr;  // [par_cap + 1]: float(value), the cast CalcWeightTotal makes per event (k_prep writes both)
   float* h_vals = nullptr;     // pinned staging for the vals/segments path
   int16_t* h_segs = nullptr;
   float* d_vals_in = nullptr;
@@ -434,8 +435,11 @@ int ensure_param_capacity(m3hip_handle h, int n_par) {
     h->ring_ticket[i] = 0;
   }
   dev_free(h->d_params);
+  dev_free(h->d_params_f32);
+  h->d_params_f32 = nullptr;
   int rc = dev_alloc(h, &h->d_params, size_t(n_par) + 1);
   if (rc) return rc;
+  if ((rc = dev_alloc(h, &h->d_params_f32, size_t(n_par) + 1))) return rc;
   h->par_cap = n_par;
   return M3HIP_OK;
 }
@@ -696,6 +700,7 @@ int m3hip_destroy(m3hip_handle h) try {
     if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
   }
   dev_free(h->d_params);
+  dev_free(h->d_params_f32);
   dev_free(h->d_osc_table);
   dev_free(h->d_osc_table_d);
   for (int i = 0; i < 2; ++i)
@@ -2004,6 +2009,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   memset(&p, 0, sizeof(p));
   p.params_src = h->d_params_src[slot];
   p.params_dev = h->d_params;
+  p.params_f32 = h->d_params_f32;
   p.n_par = n_par;
   p.par_map = h->d_parmap;
   p.coeff_x = h->d_coeff_x;
@@ -2139,6 +2145,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     }
   }
   ReweightArgs a = make_rw_args(h);
+  a.n_par_total = n_par;
+  a.params_f32 = h->d_params_f32;
   if (dyn_bins && !h->f64) {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;

@@ -149,6 +149,8 @@ struct ReweightArgs {
   int32_t evw_norm_base;
   uint32_t evw_norm_slots;  // norm slots held in the word (M3_EVW_NORM_SLOTS or 0); an event's further slots are read from nidx
   const double* params;      // [n_par + 1], last entry 1.0
+  int32_t n_par_total;       // n_par of this step's parameter vector (the brick kernel bounds its window of norm values by it)
+  const float* params_f32;   // [n_par + 1] float(params): what the window is read from
   const int32_t* bwidx;      // [n_bw_slots][E_pad] ELL of indices into the binned-spline weights, -1 = empty
   // ... or, when neighbouring events share their lists (MC ordered by spline bin), one list id per event into a
   // store of the distinct lists: the index traffic drops from 4 B per weight to 4 B per event
@@ -193,6 +195,7 @@ struct PrepArgs {
   // FindSplineSegment inputs
   const double* params_src;   // pinned host (device-mapped) or device: proposed values [n_par]
   double* params_dev;         // [n_par + 1] device copy, [n_par] = 1.0
+  float* params_f32;          // [n_par + 1] or null: float(value) of the same (the brick kernel's window of norm parameters)
   int32_t n_par;
   const int32_t* par_map;     // [P] spline parameter -> global index
   const float* coeff_x;       // [P*K]

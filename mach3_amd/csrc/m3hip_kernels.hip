@@ -39,8 +39,15 @@ __global__ __launch_bounds__(1024) void k_prep(PrepArgs a) {
     }
   }
   if (a.params_src) {
-    for (int i = tid; i < a.n_par; i += nt) a.params_dev[i] = a.params_src[i];
-    if (tid == 0) a.params_dev[a.n_par] = 1.0;
+    for (int i = tid; i < a.n_par; i += nt) {
+      const double v = a.params_src[i];
+      a.params_dev[i] = v;
+      if (a.params_f32) a.params_f32[i] = static_cast<float>(v);
+    }
+    if (tid == 0) {
+      a.params_dev[a.n_par] = 1.0;
+      if (a.params_f32) a.params_f32[a.n_par] = 1.0f;
+    }
     __syncthreads();  // from here on read the device copy, not host memory over PCIe
   }
   const int K = a.max_knots;
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   __shared__ __attribute__((aligned(16))) uint32_t lds_hdr[kBrickHdrWords];
   __shared__ PTab lds_ptab[kBrickLdsParams];
   __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
+  __shared__ float lds_nv[64];  // PACK: the norm parameters the packed words' 6-bit codes can name, float(params[evw_norm_base + k]) (SampleHandlerFD.cpp:575: the cast the reference makes per event)
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(lane >> 6);
@@ -749,6 +757,14 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
   if (x_in_lds && lane < bd.n_dict) x_own = tf1x[lane].f;
+  // The packed word's norm codes index a window of 63 parameters.  Their values (k_prep wrote float(value) beside the doubles:
+  // the cast of SampleHandlerFD.cpp:575) come in with the prologue's round trip and sit in LDS: the slabs' tails take them from
+  // there -- no global look-up behind the word (the tail's dependent chain is word -> weight, not word -> index -> value).
+  float nv_own = 1.0f;
+  if (PACK && (MODE & (kModeFill | kModeEventW)) && lane < 64 && a.params_f32) {
+    const int32_t k = a.evw_norm_base + (int32_t)lane;
+    nv_own = a.params_f32[k < a.n_par_total ? k : a.n_par_total];  // ([n_par_total] = 1.0)
+  }
   PTab t_own;
   t_own.dx = 0.f;
   t_own.seg = 0;
@@ -766,7 +782,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     constexpr bool FROM_LDS = decltype(from_lds_tag)::value;
     const uint32_t n_runs = (h0 >> 16) & 0x3FFu;
     uint32_t lane = threadIdx.x;
-    if (G == 4) asm volatile("" : "+v"(lane));  // G = 4 has no register to spare for LDS addresses hoisted out of the stage loop
+    if (G != 1) asm volatile("" : "+v"(lane));  // G = 2 / 4 have no register to spare for LDS addresses hoisted out of the stage loop
     if (lane < n_runs + 65u) {
       const uint32_t p = m.run.y >> 16;
       PTab t;
@@ -791,6 +807,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
   if (x_in_lds && lane < bd.n_dict) lds_tf1x[1 + lane] = x_own;
   if (lane == 0) lds_tf1x[0] = 0.f;
+  if (PACK && lane < 64) lds_nv[lane] = nv_own;
   if (tab_in_lds && lane < (uint32_t)a.n_params) lds_ptab[lane] = t_own;
   __syncthreads();  // stage 0's tables, the headers and the parameter table visible
   M3_STAMP(1);
@@ -868,6 +885,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t ev_own = 0;  // this lane's event of the slab (an engine holds fewer than 2^32)
   bool ev_valid = false;
   int32_t t_bin = -1, t_osc = -1, t_ni[kTailNorm];
+  uint32_t t_codes = 0;
   uint64_t t_pack = 0;
   float t_oscw = 1.f;
   double t_nv[kTailNorm];
@@ -908,11 +926,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const uint32_t lo = (uint32_t)t_pack, hi = (uint32_t)(t_pack >> 32);
       t_bin = (int32_t)(lo & 0xFFFFFu) - 1;
       t_osc = (int32_t)(((lo >> 20) | (hi << 12)) & 0xFFFFFFu) - 1;
-#pragma unroll
-      for (int m = 0; m < kTailNorm; ++m) {
-        const uint32_t cd = m < M3_EVW_NORM_SLOTS ? (hi >> (12 + 6 * m)) & 63u : 0u;
-        t_ni[m] = cd ? a.evw_norm_base + (int32_t)cd - 1 : -1;
-      }
+      t_codes = hi >> 12;  // three 6-bit norm codes: resolved against lds_nv in the tail
     }
     if (MODE & (kModeFill | kModeEventW)) {
       // a sample without oscillated events has no table, one without norm parameters no index array: absent entries
@@ -921,8 +935,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const double* pp = a.params ? a.params : (const double*)a.bricks;
       const float from_table = ot[(t_osc >= 0 && !a.oscw) ? t_osc : 0];  // (with the column: everybody reads entry 0 and drops it)
       t_oscw = a.oscw ? t_oscw : from_table;
+      if (!PACK) {
 #pragma unroll
-      for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
+        for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
+      }
     }
   };
   auto slab_begin = [&]() {  // the slab whose bookkeeping was requested last becomes the current one
@@ -1043,7 +1059,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     }
     stage(n_stages - 1, std::true_type{});
     M3_STAMP(8);
-  } else {
+  } else {  // (a brick without TSpline3 stages)
     slab_begin();
     if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
     tail_issue_idx(0);
@@ -1109,7 +1125,14 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     const bool valid = ev_valid;
     const int32_t bin_h = t_bin;
     float tw = 1.0f;
-    if (MODE & (kModeFill | kModeEventW)) {
+    if ((MODE & (kModeFill | kModeEventW)) && PACK) {
+#pragma unroll
+      for (int m = 0; m < M3_EVW_NORM_SLOTS; ++m) {
+        const uint32_t cd = (t_codes >> (6 * m)) & 63u;
+        const float nv = lds_nv[cd ? cd - 1u : 0u];
+        if (cd) tw *= nv;
+      }
+    } else if (MODE & (kModeFill | kModeEventW)) {
 #pragma unroll
       for (int m = 0; m < kTailNorm; ++m)
         if (t_ni[m] >= 0) tw *= static_cast<float>(t_nv[m]);
