@@ -37,16 +37,21 @@ build/libm3hip_hollow.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW=$(or $(HOLLOW),1) -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
 
+# experiment build: make variant NAME=foo XDEF="-DM3X_FOO" -> build/libm3hip_foo.so (load with M3HIP_LIB; scripts/gexp.py)
+variant:
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(XDEF) -shared -o build/libm3hip_$(NAME).so $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+
 isa: $(CSRC)/m3hip_kernels.hip
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage \
+	$(HIPCC) $(HIPFLAGS) $(XDEF) -c --cuda-device-only -save-temps=obj -Rpass-analysis=kernel-resource-usage \
 	    -o build/m3hip_kernels.o $(CSRC)/m3hip_kernels.hip
 
 clean:
 	rm -rf $(LIBDIR)/*.so build/*
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean isa stamps hollow
+.PHONY: all oracle clean isa stamps hollow variant
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
 examples: build/mr2t2_dragrace build/facade_check build/c5_step_loop build/libm3facade_test.so build/libm3seam2_test.so

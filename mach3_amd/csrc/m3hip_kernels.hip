@@ -552,7 +552,8 @@ static_assert(4 * (M3_STAGE_CAP + kBrickEllSlack) <= 0x8000, "bits 2..14 of a re
 // gfx950's 160 KB.  The static arrays below take 46 KB at any G; the dynamic bin vector of a fill launch is capped at
 // M3_HIST_LDS_MAX_BYTES, so the sum fits whatever the bin space (round 2's [rank][event] scatter array did not leave that room).
 constexpr size_t kBrickStaticLds = sizeof(float) * (M3_STAGE_CAP + kBrickEllSlack) + 8 * 2 * (size_t)kBrickRunSlots + 2 * 2 * 16 * kBrickGrpPerWave +
-                                   2 * 2 * 16 * M3_BRICK_MAX_GROUPS + 4 * (size_t)kBrickHdrWords + 8 * (size_t)kBrickLdsParams + 4 * ((size_t)kBrickLdsParams + 1);
+                                   2 * 2 * 16 * M3_BRICK_MAX_GROUPS + 4 * (size_t)kBrickHdrWords + 8 * (size_t)kBrickLdsParams + 4 * ((size_t)kBrickLdsParams + 1) +
+                                   4 * 64 + 4 * ((size_t)kBrickThreads + 32) + 2 * 512 * (size_t)M3_BRICK_MAX_GROUPS;
 static_assert(kBrickStaticLds + M3_HIST_LDS_MAX_BYTES <= 80 * 1024, "two brick workgroups per CU: static LDS + the largest LDS bin vector must fit 80 KB");
 // Idle lanes do not branch around their loads (see the note in the kernel): they read a few KB past the list they index.
 // m3hip_api.hip allocates every chunk's stores with this much room behind them.
@@ -640,13 +641,18 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // arrays; a template parameter, because both forms in one kernel cost the slabs' tails more registers than there are
 template <int MODE, bool NT, bool DYN = false, bool BIGP = false, int G = 1, bool PACK = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
-  __shared__ float ell[M3_STAGE_CAP + kBrickEllSlack];  // compact scatter array: one slot per response of the stage
+  __shared__ __attribute__((aligned(16))) float ell[M3_STAGE_CAP + kBrickEllSlack];  // compact scatter array: one slot per response of the stage
   __shared__ RRun lds_runs[2 * kBrickRunSlots];   // resolved run tables of two stages
   __shared__ __attribute__((aligned(16))) uint16_t lds_grp[2 * 16 * kBrickGrpPerWave];  // [stage & 1][wave][u]: run of the group's first response
-  __shared__ uint16_t lds_woff[2 * 16 * G];       // [stage & 1][slab][wave]: first slot of the wave-block's rows
+  __shared__ __attribute__((aligned(4))) uint16_t lds_woff[2 * 16 * G];       // [stage & 1][slab][wave]: first slot of the wave-block's rows
   __shared__ __attribute__((aligned(16))) uint32_t lds_hdr[kBrickHdrWords];
   __shared__ PTab lds_ptab[kBrickLdsParams];
   __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
+#ifdef M3X_META1
+  __shared__ u32x2_t lds_cnt[2 * 64 * G];  // [stage & 1]: the events' response counts of the stage, as the planner stores them
+#endif
+  __shared__ uint32_t lds_book[G != 4 ? kBrickThreads : 1];  // slab 0's TF1 bookkeeping per lane-slot: code count | the slot's event << 16
+  __shared__ uint32_t lds_bookw[32];            // [wave]: first float2 of the wave-block's rows, [16 + wave]: first code dword
   __shared__ float lds_nv[64];  // PACK: the norm parameters the packed words' 6-bit codes can name, float(params[evw_norm_base + k]) (SampleHandlerFD.cpp:575: the cast the reference makes per event)
   extern __shared__ double lds_hist[];
   const uint32_t lane = threadIdx.x;
@@ -691,6 +697,19 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const uint32_t l = lane < len - 1u ? lane : len - 1u;
       m.w[k] = *(const M3_GLOBAL uint32_t*)(resp + 4u * kBrickThreads * (n_resp > 2u * k * kBrickThreads ? k : 0u) + 4u * l);
     }
+#ifdef M3X_META1
+    {
+      // ONE 8-byte load per lane for the stage's tables: lanes 0 .. 511 the run entries, 512 .. 551 the pair words (two each),
+      // 576 .. 576 + 64 G - 1 the events' counts (they follow the pair words); every other lane re-reads the last run entry.
+      // (A load per table cost every wave three vector-memory instructions a stage, two of them idle in 14 waves of 16.)
+      const uint32_t last = n_runs ? n_runs - 1u : 0u, l = lane < last ? lane : last;
+      uint32_t off = 4u * hd.off_runs + 8u * l;
+      off = lane - 512u < (uint32_t)(M3_STAGE_PAIR_WORDS / 2) ? 4u * hd.off_pairs + 8u * (lane - 512u) : off;
+      off = lane - 576u < 64u * G ? 4u * (hd.off_pairs + (uint32_t)M3_STAGE_PAIR_WORDS) + 8u * (lane - 576u) : off;
+      m.run = *(const M3_GLOBAL u32x2_t*)(uniform_base(wbytes) + off);
+      m.pair = 0;
+    }
+#else
     {
       const uint32_t l = lane < (uint32_t)(M3_STAGE_PAIR_WORDS - 1) ? lane : (uint32_t)(M3_STAGE_PAIR_WORDS - 1);
       m.pair = *(const M3_GLOBAL uint32_t*)(uniform_base(wbytes + 4u * hd.off_pairs) + 4u * l);
@@ -699,6 +718,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const uint32_t last = n_runs ? n_runs - 1u : 0u, l = lane < last ? lane : last;
       m.run = *(const M3_GLOBAL u32x2_t*)(uniform_base(wbytes + 4u * hd.off_runs) + 8u * l);
     }
+#endif
   };
   auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
   // the responses this lane's G events hold in a stage, a nibble each.  Requested at the top of the stage itself: older than
@@ -752,7 +772,22 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
   // requested at the top of the last stage instead
   Tf1Book book_nxt = {0u, 0u, 0u};
-  if (n_stages == 0) book_nxt = tf1_book(0);
+#ifdef M3X_BOOK
+  constexpr bool kBookLds = G != 4;  // (G = 4 has no register for it: 12 bytes of scratch)
+#else
+  constexpr bool kBookLds = false;
+#endif
+  // slab 0's bookkeeping comes in with the prologue's round trip and waits in LDS for the last stage: requested there (as
+  // slabs h > 0 still are) it put a round trip of its own in front of the first TF1 rows
+  uint32_t book0_cnt = 0, book0_w = 0;
+  if (kBookLds) {
+    const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));
+    book0_cnt = *(const M3_GLOBAL uint8_t*)(cb + lane);
+    book0_cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane)) << 16;
+    if (lane < 32) book0_w = tf1h[(lane < 16 ? 0u : 16u * G - 16u) + lane];
+  } else if (n_stages == 0) {
+    book_nxt = tf1_book(0);
+  }
   const M3_GLOBAL RSlot* __restrict__ tf1x = as_global(bd.tf1_x);  // parameter value per dictionary entry (k_prep / k_resolve)
   constexpr bool x_in_lds = !BIGP;  // the dictionary holds spline parameters, so it fits whenever they do
   float x_own = 0.f;
@@ -784,7 +819,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     uint32_t lane = threadIdx.x;
     if (G != 1) asm volatile("" : "+v"(lane));  // G = 2 / 4 have no register to spare for LDS addresses hoisted out of the stage loop
     if (lane < n_runs + 65u) {
+#ifdef M3X_META1
+      const uint32_t p = lane < n_runs ? m.run.y >> 16 : 0u;  // (lanes past the runs may hold pair words or counts)
+#else
       const uint32_t p = m.run.y >> 16;
+#endif
       PTab t;
       if (FROM_LDS) {
         t = lds_ptab[p];
@@ -800,8 +839,19 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       lds_runs[(s & 1u) * kBrickRunSlots + lane] = rr;
     }
     // group g = u * 16 + wave -> [wave][u]: a wave fetches its entries of a stage with one 16-byte read
+#ifdef M3X_META1
+    if (lane - 512u < (uint32_t)(M3_STAGE_PAIR_WORDS / 2)) {
+      const uint32_t g = 2u * (lane - 512u);  // this lane holds pair words g and g + 1: (g & 15) + 1 <= 15, same g >> 4
+      uint16_t* grp = lds_grp + (s & 1u) * 16 * kBrickGrpPerWave + (g >> 4);
+      grp[(g & 15u) * kBrickGrpPerWave] = (uint16_t)m.run.x;
+      grp[((g & 15u) + 1u) * kBrickGrpPerWave] = (uint16_t)m.run.y;
+      if (g < (uint32_t)(16 * G)) *(uint32_t*)(lds_woff + (s & 1u) * 16 * G + g) = (m.run.x >> 16) | (m.run.y & 0xFFFF0000u);
+    }
+    if (lane - 576u < 64u * G) lds_cnt[(s & 1u) * 64 * G + (lane - 576u)] = m.run;
+#else
     if (lane < (uint32_t)M3_STAGE_PAIR_WORDS) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.pair;
     if (lane < (uint32_t)(16 * G)) lds_woff[(s & 1u) * 16 * G + lane] = (uint16_t)(m.pair >> 16);
+#endif
   };
   publish(0, bd.st0[0], m_cur, std::false_type{});
   if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
@@ -809,6 +859,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   if (lane == 0) lds_tf1x[0] = 0.f;
   if (PACK && lane < 64) lds_nv[lane] = nv_own;
   if (tab_in_lds && lane < (uint32_t)a.n_params) lds_ptab[lane] = t_own;
+  if (kBookLds) {
+    lds_book[lane] = book0_cnt;
+    if (lane < 32) lds_bookw[lane] = book0_w;
+  }
   __syncthreads();  // stage 0's tables, the headers and the parameter table visible
   M3_STAMP(1);
   M3_STAMP(2);
@@ -856,15 +910,17 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t tf1_cnt = 0, tf1_cbase = 0, tf1_dbase = 0;
   uint32_t ev_slot = 0;  // the event (relative to its slab) this lane works on from here on: sigma[slot]
   const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
-  auto tf1_issue = [&](uint32_t j0, auto nrows_tag) {  // loads of rows j0 .. j0 + N - 1 (nothing here waits)
-    constexpr int N = decltype(nrows_tag)::value;
+  // loads of rows j0 .. j0 + N - 1 into registers R0 .. R0 + N - 1 of the batch (nothing here waits)
+  auto tf1_issue = [&](uint32_t j0, auto nrows_tag, auto r0_tag) {
+    constexpr int N = decltype(nrows_tag)::value, R0 = decltype(r0_tag)::value;
+    static_assert(N % 4 == 0 && R0 % 4 == 0, "a code dword covers four rows");
 #pragma unroll
     for (int q = 0; q < N / 4; ++q) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + 4 * q);
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      code[q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
+      code[R0 / 4 + q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
-      tf1_on[q] = tf1_cnt > j0 + 4 * q;
+      tf1_on[R0 / 4 + q] = tf1_cnt > j0 + 4 * q;
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -875,10 +931,12 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // of a wave are full for longer and this wins on both configurations (config 3 -0.7 %, config 5 -1.1 %); round 2's unsorted
       // rows preferred non-temporal loads on config 3
       const f32x2_t v = *gp;
-      ab[i] = make_float2(v.x, v.y);
+      ab[R0 + i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
     }
   };
+  constexpr std::integral_constant<int, 0> kR0{};
+  constexpr std::integral_constant<int, kBrickTf1Batch> kFirstBatch{};
   // ---- sample side of the slab's event (CalcWeightTotal's inputs), requested while the TF1 rows stream: first the event's
   // indices (with the first TF1 rows), then what they point at (small tables that live in L2); the tail finds both there
   constexpr int kTailNorm = 4;  // norm slots fetched ahead; further ones are read in the tail itself
@@ -889,6 +947,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint64_t t_pack = 0;
   float t_oscw = 1.f;
   double t_nv[kTailNorm];
+#ifdef M3X_EVWLIN
+  constexpr bool kEvwLin = G == 1 && PACK && (MODE & (kModeFill | kModeEventW)) != 0;
+#else
+  constexpr bool kEvwLin = false;
+#endif
   auto tail_issue_idx = [&](uint32_t h) {
     const ReweightArgs& a = late_args();
     // (the lane number passes through an empty asm: the addresses below must be formed HERE, slab by slab; hoisted to the
@@ -901,11 +964,25 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // the event's oscillation weight itself when the engine has expanded a large, static table into a per-event column
       // (ReweightArgs::oscw): requested with the indices, not behind them.  No branch around the load: without the column
       // every lane reads the same word of the brick descriptors and drops it.
+#ifdef M3X_OSCBR
+      if (a.oscw) t_oscw = a.oscw[ev_own];  // (kernel-uniform branch; the waits behind it are for everything anyway)
+#else
       const float* ow = a.oscw ? a.oscw + ev_own : (const float*)a.bricks;
       t_oscw = *ow;
+#endif
     }
     if ((MODE & (kModeFill | kModeEventW)) && PACK) {  // the event's indices in one 8-byte word
-      t_pack = a.evw[ev_own];
+      if (kEvwLin) {
+        // ... of the event the lane held through the stages (lane = event: one coalesced load); the words change lanes with
+        // the TSpline3 products.  Gathered by lane-slot, every wave asked for most of the brick's 64 lines of them.
+        uint32_t ll = lane;
+        asm volatile("" : "+v"(ll));
+        uint32_t ev_lin = bd.first_event + (ll < bd.n_events ? ll : 0u);
+        if (a.perm) ev_lin = a.perm[ev_lin];
+        t_pack = a.evw[ev_lin];
+      } else {
+        t_pack = a.evw[ev_own];
+      }
       return;
     }
     if (MODE & (kModeFill | kModeEventW)) {
@@ -933,13 +1010,26 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
       const float* ot = a.osc_table ? a.osc_table : (const float*)a.bricks;
       const double* pp = a.params ? a.params : (const double*)a.bricks;
+#ifdef M3X_OSCBR
+      if (!a.oscw) t_oscw = ot[t_osc >= 0 ? t_osc : 0];
+#else
       const float from_table = ot[(t_osc >= 0 && !a.oscw) ? t_osc : 0];  // (with the column: everybody reads entry 0 and drops it)
       t_oscw = a.oscw ? t_oscw : from_table;
+#endif
       if (!PACK) {
 #pragma unroll
         for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
       }
     }
+  };
+  auto tf1_book0 = [&]() -> Tf1Book {  // slab 0's, from LDS
+    Tf1Book b;
+    uint32_t le = lane;
+    asm volatile("" : "+v"(le));
+    b.cnt = lds_book[G != 4 ? le : 0u];
+    b.cbase = __builtin_amdgcn_readfirstlane(lds_bookw[wave]);
+    b.dbase = __builtin_amdgcn_readfirstlane(lds_bookw[16u + wave]);
+    return b;
   };
   auto slab_begin = [&]() {  // the slab whose bookkeeping was requested last becomes the current one
     tf1_cnt = book_nxt.cnt & 0xFFu;
@@ -1000,18 +1090,30 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
   // scattered to its slot of the scatter array, and its register reused at once for the next stage's load (LAST: for the
   // first TF1 rows instead); barrier; every event's responses of the stage, ascending parameter = reference order.
+#ifndef M3X_META1
   uint32_t counts_nxt = fetch_counts(StageHdr{bd.st0[0], bd.st0[1], bd.st0[2], bd.st0[3]});
-  auto stage = [&](uint32_t s, auto last_tag) {
-    constexpr bool LAST = decltype(last_tag)::value;
+#endif
+  // kind 0: a stage with at least two behind it; 1: the last but one (nothing left to request for a stage s + 2: without the
+  // peel all 16 waves load five words of a header of zeros); 2: the last
+  auto stage = [&](uint32_t s, auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool LAST = KIND == 2;
+#ifdef M3X_PEEL
+    constexpr bool AHEAD2 = KIND == 0;
+#else
+    constexpr bool AHEAD2 = KIND != 2;
+#endif
     const uint32_t h0 = hdr(s).h0;
     const uint32_t n_resp = h0 & 0xFFFFu;
     Meta m_nn;
-    if (LAST) book_nxt = tf1_book(0);
+    if (LAST && !kBookLds) book_nxt = tf1_book(0);
+#ifndef M3X_META1
     const uint32_t counts = counts_nxt;                    // requested a stage ago
     if (!LAST) counts_nxt = fetch_counts(hdr(s + 1));
+#endif
     if (!LAST) {
       publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight
-      fetch_meta(hdr(s + 2), m_nn);
+      if (AHEAD2) fetch_meta(hdr(s + 2), m_nn);
     }
     __syncthreads();  // stage s+1's tables visible; every wave is through its events' products of stage s-1: the scatter array is free
     // first slots of this wave's blocks in stage s.  Read HERE: the buffer they sit in is overwritten by the publish of stage
@@ -1019,6 +1121,18 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     uint32_t block0[G];
 #pragma unroll
     for (int h = 0; h < G; ++h) block0[h] = __builtin_amdgcn_readfirstlane((uint32_t)lds_woff[(s & 1u) * 16 * G + 16 * h + wave]);
+#ifdef M3X_META1
+    // the lane's events' counts of this stage (published with the stage's tables); read here for the same reason
+    uint32_t counts;
+    {
+      uint32_t lc = threadIdx.x;
+      asm volatile("" : "+v"(lc));
+      const char* cb = (const char*)(lds_cnt + (s & 1u) * 64 * G);
+      if (G == 1) counts = *(const uint8_t*)(cb + (lc & 511u));
+      else if (G == 2) counts = *(const uint8_t*)(cb + lc);
+      else counts = *(const uint16_t*)(cb + 2u * lc);
+    }
+#endif
     auto scatter = [&](int u) {
       // bits 2..14 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
 #ifdef M3_BRICK_HOLLOW
@@ -1037,9 +1151,17 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     } else {
 #pragma unroll
       for (int u = 0; u < kBrickRPL; ++u) scatter(u);
+      if (kBookLds) book_nxt = tf1_book0();
       slab_begin();
-      if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
+#ifdef M3X_EVWFIRST
+      // the event's sample word BEFORE the rows: behind them (and behind the join of the branch around them) its request waited
+      // for every row to arrive -- one more round trip in front of the oscillation look-up
       tail_issue_idx(0);
+      if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
+#else
+      if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
+      tail_issue_idx(0);
+#endif
     }
 #if !defined(M3_BRICK_HOLLOW) || M3_BRICK_HOLLOW != 2  // (hollow level 2: without this barrier -- nothing is scattered there)
     __syncthreads();  // the stage's scatter is complete
@@ -1049,30 +1171,41 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     column(block0, counts);
     if (!LAST) {
       m_cur = m_nxt;
-      m_nxt = m_nn;
+      if (AHEAD2) m_nxt = m_nn;
     }
   };
   if (n_stages > 0) {
-    for (uint32_t s = 0; s + 1 < n_stages; ++s) {
-      stage(s, std::false_type{});
+#ifdef M3X_PEEL
+    for (uint32_t s = 0; s + 2 < n_stages; ++s) {
+      stage(s, std::integral_constant<int, 0>{});
       if (s < 4) M3_STAMP(3 + s);
     }
-    stage(n_stages - 1, std::true_type{});
+    if (n_stages > 1) stage(n_stages - 2, std::integral_constant<int, 1>{});
+#else
+    for (uint32_t s = 0; s + 1 < n_stages; ++s) {
+      stage(s, std::integral_constant<int, 0>{});
+      if (s < 4) M3_STAMP(3 + s);
+    }
+#endif
+    stage(n_stages - 1, std::integral_constant<int, 2>{});
     M3_STAMP(8);
   } else {  // (a brick without TSpline3 stages)
+    if (kBookLds) book_nxt = tf1_book0();
     slab_begin();
-    if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
+    if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
     tail_issue_idx(0);
   }
 
   // ---- the TSpline3 products change lanes: up to here lane l held event l of every slab, from here on it holds the event of
   // its lane-slot (sigma).  Through the scatter array, which the stages are done with.
   const bool resorted = bd.pad_[1] != 0;  // brick-uniform; otherwise sigma is the identity and the products stay where they are
-  if (n_stages > 0 && resorted) {
+  if ((n_stages > 0 || kEvwLin) && resorted) {
     __syncthreads();  // every wave is through its events' products of the last stage
 #pragma unroll
     for (int h = 0; h < G; ++h) ell[1024 * h + lane] = w[h];
+    if (kEvwLin) ((uint64_t*)(ell + 1024))[lane] = t_pack;  // (waits for the word; the first TF1 rows, younger, stay in flight)
     __syncthreads();
+    if (kEvwLin) t_pack = ((const uint64_t*)(ell + 1024))[ev_slot];
   }
   // ---- slab after slab: the events' TF1 rows, then CalcWeightTotal and the fill.  The next slab's first rows and indices
   // are requested once this slab's tail is through (holding 16 rows in flight across the tail costs it its registers).
@@ -1084,15 +1217,15 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if (G > 1 && h == 1) wh = w[1 % G];
     if (G > 2 && h == 2) wh = w[2 % G];
     if (G > 2 && h == 3) wh = w[3 % G];
-    if (n_stages > 0 && resorted) wh = ell[1024u * h + ev_slot];
+    if ((n_stages > 0 || kEvwLin) && resorted) wh = ell[1024u * h + ev_slot];
     if (any_tf1) {
       uint32_t kd4 = 0;  // 4 * (1 + position in the dictionary)
-      auto tf1_rows = [&](auto nrows_tag) {
-        constexpr int N = decltype(nrows_tag)::value;
+      auto tf1_rows = [&](auto nrows_tag, auto r0_tag) {  // registers R0 .. R0 + N - 1 of the batch
+        constexpr int N = decltype(nrows_tag)::value, R0 = decltype(r0_tag)::value;
 #pragma unroll
-        for (int q = 0; q < N / 4; ++q) code[q] = tf1_on[q] ? code[q] : 0u;  // ... dropped here
+        for (int q = 0; q < N / 4; ++q) code[R0 / 4 + q] = tf1_on[R0 / 4 + q] ? code[R0 / 4 + q] : 0u;  // ... dropped here
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
+        for (int i = R0; i < R0 + N; ++i) {
 #ifdef M3_BRICK_HOLLOW
           const float2 abi = ab[i];
           const uint32_t cdw = code[i / 4];
@@ -1110,12 +1243,35 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
           wh *= (cd - 1u < (uint32_t)(M3_TF1_SKIP - 1)) ? t : 1.0f;
         }
       };
-      tf1_rows(std::integral_constant<int, kBrickTf1Batch>{});
+#ifdef M3X_TF1PIPE
+      constexpr bool kTf1Pipe = G == 1;
+#else
+      constexpr bool kTf1Pipe = false;
+#endif
+      if constexpr (kTf1Pipe) {
+      // The rows behind the first batch are requested as the first batch's registers come free, half a batch at a time, by every
+      // wave and without a branch around the loads (a wave whose events have no such rows reads one and the same line and drops
+      // it): a wave's second and third batch travel together instead of one after the other, each behind a wait for everything
+      constexpr std::integral_constant<int, 8> kHalf0{};
+      constexpr std::integral_constant<int, kBrickTf1Batch - 8> kHalf1{};
+      tf1_rows(kHalf0, kR0);
+      tf1_issue(kBrickTf1Batch, kHalf0, kR0);
+      tf1_rows(kHalf1, kHalf0);
+      tf1_issue(kBrickTf1Batch + 8, kHalf1, kHalf0);
+      for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Batch) {
+        tf1_rows(kHalf0, kR0);
+        tf1_issue(j0 + kBrickTf1Batch, kHalf0, kR0);
+        tf1_rows(kHalf1, kHalf0);
+        tf1_issue(j0 + kBrickTf1Batch + 8, kHalf1, kHalf0);
+      }
+      } else {
+      tf1_rows(kFirstBatch, kR0);
       // further rows in batches of 8 (16 at a time measured 1.6 % slower on config 3: the extra loads of rows nobody has)
-      constexpr int kBrickTf1Next = 8;
-      for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Next) {
-        tf1_issue(j0, std::integral_constant<int, kBrickTf1Next>{});
-        tf1_rows(std::integral_constant<int, kBrickTf1Next>{});
+      constexpr std::integral_constant<int, 8> kNext{};
+      for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += 8) {
+        tf1_issue(j0, kNext, kR0);
+        tf1_rows(kNext, kR0);
+      }
       }
     }
     if (h == (uint32_t)(G - 1)) M3_STAMP(9);
@@ -1194,7 +1350,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     if (h + 1 < (uint32_t)G) {
       if (h == 0) M3_STAMP(13);  // diagnostics: slab 0 is through
       slab_begin();
-      if (any_tf1) tf1_issue(0, std::integral_constant<int, kBrickTf1Batch>{});
+      if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
       tail_issue_idx(h + 1);
     }
   }
