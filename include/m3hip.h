@@ -436,6 +436,12 @@ int m3hip_debug_host_times(m3hip_handle h, double* out6);
  * clock at k_prep start, at k_llh end, host clock at the k_prep launch, at completion seen}. */
 int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us);
 
+/* Host-only probe of the rule that evens out a brick launch (m3hip_api.hip, ShortBrickPlan): the bricks an all-ragged
+ * sample of expect_events events ends up in when it arrives in chunks of chunk_events events on a device of n_cu compute
+ * units, bricks of brick_groups x 1024 events; n_short: how many of them are three-quarter bricks.  Used by the CPU tests. */
+int m3hip_debug_short_brick_plan(uint64_t expect_events, uint64_t chunk_events, int brick_groups, int n_cu,
+                                 uint64_t* n_bricks, uint64_t* n_short);
+
 /* Host-only probe of the upload re-layout (no device needed): sizes[8] = {n_tiles,
  * spline store in float4, TF1 store in float2, slot-meta in int32, n_bricks, brick words,
  * first word of the bricks' TF1 parameter dictionary inside the brick words, its entries};

@@ -29,7 +29,7 @@ M3HIP_SYMBOLS = [
     "m3hip_comm_get_unique_id", "m3hip_comm_init", "m3hip_comm_destroy", "m3hip_comm_available", "m3hip_device_synchronize", "m3hip_upload_event_weights", "m3hip_upload_weight_index",
     "m3hip_set_weight_table", "m3hip_set_deterministic", "m3hip_monolith_expect_events",
     "m3hip_comm_set_validate", "m3hip_comm_last_validation", "m3hip_xch_create", "m3hip_xch_open", "m3hip_xch_destroy", "m3hip_xch_set_timeout", "m3hip_par_upload", "m3hip_par_launch", "m3hip_par_result",
-    "m3hip_debug_layout", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
+    "m3hip_debug_layout", "m3hip_debug_short_brick_plan", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
     "m3hip_get_info", "m3hip_timing_enable", "m3hip_timing_read", "m3hip_timing_reset", "m3hip_version",
 ]
 
@@ -169,6 +169,7 @@ def load_m3hip():
         "m3hip_debug_set_knobs": [vp, i32, i32, i32],
         "m3hip_debug_set_hist_replicas": [vp, i32],
         "m3hip_debug_device_span": [vp, i32, C.POINTER(C.c_double)],
+        "m3hip_debug_short_brick_plan": [u64, u64, i32, i32, vp, vp],
         "m3hip_debug_layout": [i32, i32, vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():

@@ -89,6 +89,16 @@ std::string g_create_err;
 
 }  // namespace
 
+// which events of an upload get bricks of three quarters of the size (described at ShortBrickPlan::begin)
+struct ShortBrickPlan {
+  bool decided = false;   // begin() has run for this upload
+  uint64_t B = 0;         // events of a full brick
+  uint64_t zone0 = 0;     // first event (global) that may be converted
+  uint64_t left = 0;      // conversions (three full bricks -> four short ones) still to place
+  void begin(uint64_t expect_events, uint64_t first_chunk_events, int G, int n_cu);
+  void take(uint64_t chunk_first, uint64_t chunk_events, uint64_t* from, uint64_t* to);
+};
+
 struct m3hip_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -222,6 +232,8 @@ struct m3hip_ctx {
   int brick_groups = 0;           // G of this monolith's bricks (m3hip_layout.h); 0 until the first chunk with ragged events fixes it
   uint64_t expect_events = 0;     // m3hip_monolith_expect_events: the events this device will hold (0: unknown); taken by the next monolith_begin
   uint64_t upload_expect = 0;     // ... the hint of the upload in progress
+  int n_cu = 0;                   // compute units of the device
+  ShortBrickPlan short_bricks;    // of the upload in progress
   uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
@@ -678,6 +690,7 @@ int m3hip_create(int device_id, m3hip_handle* out) try {
   }
   m3hip_ctx* h = new m3hip_ctx();
   h->device = device_id;
+  (void)hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess || (e = hipEventCreate(&h->ev2)) != hipSuccess) {
     std::string m = hipGetErrorString(e);
@@ -780,6 +793,7 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   { const char* f = getenv("M3HIP_REBIN"); h->sw_rebin = f && f[0] ? f[0] : 'p'; }
   { const char* f = getenv("M3HIP_OSC_COLUMN"); h->oscw_mode = f && f[0] ? atoi(f) : -1; }
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
+  h->short_bricks = ShortBrickPlan();
   h->expect_events = 0;
   h->P = n_params;
   h->K = max_knots;
@@ -829,6 +843,43 @@ static int choose_brick_groups(const ChunkInput& in, uint64_t expect_events) {
   return g;
 }
 
+// Equal shares of a brick launch.  The device hands workgroups to its XCDs in turn and each compute unit works on two at a time,
+// so a launch of nb equal bricks lasts as long as the compute unit with the most of them: ceil(nb / n_cu) bricks' worth, whatever
+// nb % n_cu is (config 3: 9 766 bricks on 256 units = 38.15 each; measured 71.9 ns per brick against 71.2 for 9 728 / 9 984 /
+// 10 240 bricks).  When the upload announced its size (m3hip_monolith_expect_events), the count is brought to the next multiple
+// of n_cu by cutting bricks near the END of the sample at three quarters of the size -- four where three would be, so that a
+// converted stretch ends where the full bricks' boundaries are and chunk borders cost nothing; last, so that the greedy
+// dispatch finishes on the small ones.  begin(): the rule, from the announced size and the first chunk's (the stretch is
+// started early by one conversion per chunk border expected inside it, because a chunk's share of it is rounded down to whole
+// conversions); take(): a chunk's share.  Not applied: size unknown, more than 150 bricks per unit (the imbalance is below
+// 0.3 % then), or more than a quarter of the sample would be converted.  M3HIP_SHORT_BRICKS=0 switches it off.
+void ShortBrickPlan::begin(uint64_t expect_events, uint64_t first_chunk_events, int G, int n_cu) {
+  *this = ShortBrickPlan();
+  decided = true;
+  if (const char* f = getenv("M3HIP_SHORT_BRICKS")) if (f[0] == '0') return;
+  if (expect_events == 0 || n_cu <= 0 || first_chunk_events == 0) return;
+  B = uint64_t(M3_GROUP) * uint64_t(G);
+  const uint64_t nb = (expect_events + B - 1) / B, cu = uint64_t(n_cu);
+  if (nb % cu == 0 || nb / cu >= 150) return;
+  const uint64_t extra = (nb + cu - 1) / cu * cu - nb;              // bricks to gain: one per conversion of 3 B events
+  const uint64_t slack = (3 * B * extra + first_chunk_events - 1) / first_chunk_events + 1;
+  const uint64_t full_end = expect_events / B * B;                    // (the events behind it are the sample's last, partial brick)
+  if (3 * B * (extra + slack) * 4 > full_end) return;
+  zone0 = full_end - 3 * B * (extra + slack);
+  left = extra;
+}
+void ShortBrickPlan::take(uint64_t chunk_first, uint64_t chunk_events, uint64_t* from, uint64_t* to) {
+  *from = *to = ~0ull;
+  if (left == 0) return;
+  const uint64_t a = std::max(zone0, chunk_first), b = chunk_first + chunk_events;
+  if (a >= b || (a - chunk_first) % B != 0) return;
+  const uint64_t n = std::min(left, (b - a) / (3 * B));
+  if (n == 0) return;
+  *from = a - chunk_first;
+  *to = *from + 3 * B * n;
+  left -= n;
+}
+
 int m3hip_monolith_expect_events(m3hip_handle h, uint64_t n_events) try {
   if (!h) return M3HIP_EINVAL;
   h->expect_events = n_events;
@@ -867,7 +918,10 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
   if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->upload_expect);
   const int G = h->brick_groups;
-  if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err, G)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
+  if (!h->short_bricks.decided) h->short_bricks.begin(h->upload_expect, n_events, G, h->n_cu);
+  uint64_t short_from, short_to;  // chunk-local
+  h->short_bricks.take(h->E, n_events, &short_from, &short_to);
+  if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err, G, short_from, short_to)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
   // Grouping.  When a sizeable part of the chunk would end up in bricks, try the chunk with its events grouped by
   // parameter list (stable sort): events of one interaction mode then sit together and form uniform (or padded)
@@ -908,7 +962,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
       in_g.npe_tf1 = npe_tf1_g.data();
       ChunkPlan plan_g;
       std::string err_g;
-      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g, G)) {
+      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g, G, short_from, short_to)) {
         uint64_t ragged_g = 0;
         for (const BrickHost& bh : plan_g.bricks) ragged_g += bh.n_events;
         if (ragged_g * 2 <= ragged) {  // at least halves what goes through bricks
@@ -2704,7 +2758,11 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
   { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
-  if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err, choose_brick_groups(in, 0))) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
+  // M3HIP_DEBUG_SHORT_FROM: the event from which on bricks are cut short (tests/test_layout.py; an engine gets it from short_bricks_from)
+  uint64_t short_from = ~0ull, short_to = ~0ull;
+  if (const char* f = getenv("M3HIP_DEBUG_SHORT_FROM")) if (f[0]) short_from = strtoull(f, nullptr, 10);
+  if (const char* f = getenv("M3HIP_DEBUG_SHORT_TO")) if (f[0]) short_to = strtoull(f, nullptr, 10);
+  if (!plan_chunk(n_params, max_knots, npts, in, &plan, &err, choose_brick_groups(in, 0), short_from, short_to)) return fail(nullptr, M3HIP_EINVAL, "debug_layout: " + err);
   sizes[0] = plan.tiles.size();
   sizes[1] = plan.spl_float4;
   sizes[2] = plan.tf1_float2;
@@ -2728,6 +2786,26 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
     d[4] = bh.n_tf1_f2; d[5] = bh.n_events; d[6] = bh.first_event; d[7] = bh.n_words;
   }
   if (!plan.brick_words.empty()) memcpy(brick_words, plan.brick_words.data(), plan.brick_words.size() * sizeof(uint32_t));
+  return M3HIP_OK;
+} M3_API_CATCH(nullptr)
+
+int m3hip_debug_short_brick_plan(uint64_t expect_events, uint64_t chunk_events, int brick_groups, int n_cu, uint64_t* n_bricks,
+                                 uint64_t* n_short) try {
+  if (!n_bricks || !n_short || chunk_events == 0 || chunk_events % M3_GROUP != 0 || (brick_groups != 1 && brick_groups != 2 && brick_groups != 4))
+    return fail(nullptr, M3HIP_EINVAL, "debug_short_brick_plan: bad arguments");
+  ShortBrickPlan sp;
+  const uint64_t B = uint64_t(M3_GROUP) * uint64_t(brick_groups);
+  *n_bricks = *n_short = 0;
+  for (uint64_t e0 = 0; e0 < expect_events; e0 += chunk_events) {
+    const uint64_t n = std::min(chunk_events, expect_events - e0);
+    if (!sp.decided) sp.begin(expect_events, n, brick_groups, n_cu);
+    uint64_t from, to;
+    sp.take(e0, n, &from, &to);
+    if (from == ~0ull) { *n_bricks += (n + B - 1) / B; continue; }  // what plan_chunk cuts: full bricks, short ones in [from, to)
+    const uint64_t shorts = (to - from) / (3 * B / 4);
+    *n_short += shorts;
+    *n_bricks += from / B + shorts + (n - to + B - 1) / B;
+  }
   return M3HIP_OK;
 } M3_API_CATCH(nullptr)
 

@@ -607,6 +607,7 @@ struct RRun {      // per-step resolved run: quad address = base + r, dx of the 
 };
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // k_reweight_brick: one 1024-lane workgroup per brick (<= G x 1024 events with ragged parameter lists); lane l owns the
@@ -648,9 +649,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   __shared__ __attribute__((aligned(16))) uint32_t lds_hdr[kBrickHdrWords];
   __shared__ PTab lds_ptab[kBrickLdsParams];
   __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
-#ifdef M3X_META1
   __shared__ u32x2_t lds_cnt[2 * 64 * G];  // [stage & 1]: the events' response counts of the stage, as the planner stores them
-#endif
   __shared__ uint32_t lds_book[G != 4 ? kBrickThreads : 1];  // slab 0's TF1 bookkeeping per lane-slot: code count | the slot's event << 16
   __shared__ uint32_t lds_bookw[32];            // [wave]: first float2 of the wave-block's rows, [16 + wave]: first code dword
   __shared__ float lds_nv[64];  // PACK: the norm parameters the packed words' 6-bit codes can name, float(params[evw_norm_base + k]) (SampleHandlerFD.cpp:575: the cast the reference makes per event)
@@ -681,23 +680,27 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // do not exist have an all-zero header and read the brick's first words), and nothing is ever done with the value.
   struct Meta {
     uint32_t w[kWordRegs];  // response words, two per register
-    uint32_t pair;          // lanes < M3_STAGE_PAIR_WORDS: run of the group's first response | first slot of wave-block `lane` << 16
-    u32x2_t run;            // lanes < n_runs: the raw entry of run `lane`
+    u32x2_t run;            // the stage's tables, 8 bytes per lane: lanes < n_runs the raw entry of run `lane`; lanes 512 .. 551 two pair
+                            // words each (run of a group's first response | first slot of a wave-block << 16); lanes 576 .. the events' counts
   };
   struct StageHdr { uint32_t h0, off_runs, off_pairs, off_resp; };  // wave-uniform (SGPRs): bases of SGPR + lane-offset loads
   auto fetch_meta = [&](const StageHdr& hd, Meta& m) {
     // lanes past the end of a list re-read its last element (one line): an unclamped read would drag 10+ KB of foreign
     // lines per stage through the memory system
     const uint32_t n_resp = hd.h0 & 0xFFFFu, n_runs = (hd.h0 >> 16) & 0x3FFu;
-    const M3_GLOBAL char* resp = uniform_base(wbytes + 4u * hd.off_resp);
-#pragma unroll
-    for (int k = 0; k < kWordRegs; ++k) {
-      // block k: one dword per response of batch 2k
-      const uint32_t len = n_resp > 2u * k * kBrickThreads ? n_resp - 2u * k * kBrickThreads : 1u;  // scalar
-      const uint32_t l = lane < len - 1u ? lane : len - 1u;
-      m.w[k] = *(const M3_GLOBAL uint32_t*)(resp + 4u * kBrickThreads * (n_resp > 2u * k * kBrickThreads ? k : 0u) + 4u * l);
+    {
+      // the lane's response words: ONE load of three dwords from its record of nd = 1, 2 or 3 (m3hip_layout.h); what lies behind a
+      // shorter record belongs to the next lane and is never looked at as a response (scatter and ballots check the count).
+      // Lanes without a response re-read the last record.
+      const uint32_t nd = ((n_resp + 1023u) / 1024u + 1u) / 2u;  // scalar
+      const uint32_t lanes = n_resp < (uint32_t)kBrickThreads ? (n_resp ? n_resp : 1u) : (uint32_t)kBrickThreads;
+      const uint32_t l = lane < lanes - 1u ? lane : lanes - 1u;
+      const u32x3_t v = *(const M3_GLOBAL u32x3_t*)(uniform_base(wbytes + 4u * hd.off_resp) + 4u * nd * l);
+      static_assert(kWordRegs == 3, "a lane's response words of a stage travel as three dwords");
+      m.w[0] = v.x;
+      m.w[1] = v.y;
+      m.w[2] = v.z;
     }
-#ifdef M3X_META1
     {
       // ONE 8-byte load per lane for the stage's tables: lanes 0 .. 511 the run entries, 512 .. 551 the pair words (two each),
       // 576 .. 576 + 64 G - 1 the events' counts (they follow the pair words); every other lane re-reads the last run entry.
@@ -707,28 +710,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       off = lane - 512u < (uint32_t)(M3_STAGE_PAIR_WORDS / 2) ? 4u * hd.off_pairs + 8u * (lane - 512u) : off;
       off = lane - 576u < 64u * G ? 4u * (hd.off_pairs + (uint32_t)M3_STAGE_PAIR_WORDS) + 8u * (lane - 576u) : off;
       m.run = *(const M3_GLOBAL u32x2_t*)(uniform_base(wbytes) + off);
-      m.pair = 0;
     }
-#else
-    {
-      const uint32_t l = lane < (uint32_t)(M3_STAGE_PAIR_WORDS - 1) ? lane : (uint32_t)(M3_STAGE_PAIR_WORDS - 1);
-      m.pair = *(const M3_GLOBAL uint32_t*)(uniform_base(wbytes + 4u * hd.off_pairs) + 4u * l);
-    }
-    {
-      const uint32_t last = n_runs ? n_runs - 1u : 0u, l = lane < last ? lane : last;
-      m.run = *(const M3_GLOBAL u32x2_t*)(uniform_base(wbytes + 4u * hd.off_runs) + 8u * l);
-    }
-#endif
   };
   auto word = [&](const Meta& m, int u) -> uint32_t { return (u & 1) ? (m.w[u / 2] >> 16) : (m.w[u / 2] & 0xFFFFu); };
-  // the responses this lane's G events hold in a stage, a nibble each.  Requested at the top of the stage itself: older than
-  // the next stage's quads, so the wait in front of the events' products leaves those in flight
-  auto fetch_counts = [&](const StageHdr& hd) -> uint32_t {
-    const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (hd.off_pairs + (uint32_t)M3_STAGE_PAIR_WORDS));
-    if (G == 1) return *(const M3_GLOBAL uint8_t*)(cb + (lane & 511u));
-    if (G == 2) return *(const M3_GLOBAL uint8_t*)(cb + lane);
-    return *(const M3_GLOBAL uint16_t*)(cb + 2u * lane);
-  };
+  // the responses this lane's G events hold in a stage: a nibble each of the stage's count word (lds_cnt)
   auto count_of = [&](uint32_t packed, int h) -> uint32_t {
     if (G != 1) return (packed >> (4 * h)) & 15u;
     // G = 1: two events share a byte.  The lane's shift is recomputed where it is used: hoisted out of the stage loop it would
@@ -772,11 +757,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
   // requested at the top of the last stage instead
   Tf1Book book_nxt = {0u, 0u, 0u};
-#ifdef M3X_BOOK
   constexpr bool kBookLds = G != 4;  // (G = 4 has no register for it: 12 bytes of scratch)
-#else
-  constexpr bool kBookLds = false;
-#endif
   // slab 0's bookkeeping comes in with the prologue's round trip and waits in LDS for the last stage: requested there (as
   // slabs h > 0 still are) it put a round trip of its own in front of the first TF1 rows
   uint32_t book0_cnt = 0, book0_w = 0;
@@ -819,11 +800,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     uint32_t lane = threadIdx.x;
     if (G != 1) asm volatile("" : "+v"(lane));  // G = 2 / 4 have no register to spare for LDS addresses hoisted out of the stage loop
     if (lane < n_runs + 65u) {
-#ifdef M3X_META1
       const uint32_t p = lane < n_runs ? m.run.y >> 16 : 0u;  // (lanes past the runs may hold pair words or counts)
-#else
-      const uint32_t p = m.run.y >> 16;
-#endif
       PTab t;
       if (FROM_LDS) {
         t = lds_ptab[p];
@@ -839,7 +816,6 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       lds_runs[(s & 1u) * kBrickRunSlots + lane] = rr;
     }
     // group g = u * 16 + wave -> [wave][u]: a wave fetches its entries of a stage with one 16-byte read
-#ifdef M3X_META1
     if (lane - 512u < (uint32_t)(M3_STAGE_PAIR_WORDS / 2)) {
       const uint32_t g = 2u * (lane - 512u);  // this lane holds pair words g and g + 1: (g & 15) + 1 <= 15, same g >> 4
       uint16_t* grp = lds_grp + (s & 1u) * 16 * kBrickGrpPerWave + (g >> 4);
@@ -848,10 +824,6 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       if (g < (uint32_t)(16 * G)) *(uint32_t*)(lds_woff + (s & 1u) * 16 * G + g) = (m.run.x >> 16) | (m.run.y & 0xFFFF0000u);
     }
     if (lane - 576u < 64u * G) lds_cnt[(s & 1u) * 64 * G + (lane - 576u)] = m.run;
-#else
-    if (lane < (uint32_t)M3_STAGE_PAIR_WORDS) lds_grp[(s & 1u) * 16 * kBrickGrpPerWave + (lane & 15u) * kBrickGrpPerWave + (lane >> 4)] = (uint16_t)m.pair;
-    if (lane < (uint32_t)(16 * G)) lds_woff[(s & 1u) * 16 * G + lane] = (uint16_t)(m.pair >> 16);
-#endif
   };
   publish(0, bd.st0[0], m_cur, std::false_type{});
   if (lane < kBrickHdrWords) lds_hdr[lane] = hdr_w;
@@ -947,11 +919,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint64_t t_pack = 0;
   float t_oscw = 1.f;
   double t_nv[kTailNorm];
-#ifdef M3X_EVWLIN
   constexpr bool kEvwLin = G == 1 && PACK && (MODE & (kModeFill | kModeEventW)) != 0;
-#else
-  constexpr bool kEvwLin = false;
-#endif
   auto tail_issue_idx = [&](uint32_t h) {
     const ReweightArgs& a = late_args();
     // (the lane number passes through an empty asm: the addresses below must be formed HERE, slab by slab; hoisted to the
@@ -964,12 +932,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // the event's oscillation weight itself when the engine has expanded a large, static table into a per-event column
       // (ReweightArgs::oscw): requested with the indices, not behind them.  No branch around the load: without the column
       // every lane reads the same word of the brick descriptors and drops it.
-#ifdef M3X_OSCBR
       if (a.oscw) t_oscw = a.oscw[ev_own];  // (kernel-uniform branch; the waits behind it are for everything anyway)
-#else
-      const float* ow = a.oscw ? a.oscw + ev_own : (const float*)a.bricks;
-      t_oscw = *ow;
-#endif
     }
     if ((MODE & (kModeFill | kModeEventW)) && PACK) {  // the event's indices in one 8-byte word
       if (kEvwLin) {
@@ -1010,12 +973,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
       const float* ot = a.osc_table ? a.osc_table : (const float*)a.bricks;
       const double* pp = a.params ? a.params : (const double*)a.bricks;
-#ifdef M3X_OSCBR
       if (!a.oscw) t_oscw = ot[t_osc >= 0 ? t_osc : 0];
-#else
-      const float from_table = ot[(t_osc >= 0 && !a.oscw) ? t_osc : 0];  // (with the column: everybody reads entry 0 and drops it)
-      t_oscw = a.oscw ? t_oscw : from_table;
-#endif
       if (!PACK) {
 #pragma unroll
         for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
@@ -1090,27 +1048,16 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // One stage: tables of the next stage -> LDS while this stage's quads are in flight; then every quad is evaluated,
   // scattered to its slot of the scatter array, and its register reused at once for the next stage's load (LAST: for the
   // first TF1 rows instead); barrier; every event's responses of the stage, ascending parameter = reference order.
-#ifndef M3X_META1
-  uint32_t counts_nxt = fetch_counts(StageHdr{bd.st0[0], bd.st0[1], bd.st0[2], bd.st0[3]});
-#endif
   // kind 0: a stage with at least two behind it; 1: the last but one (nothing left to request for a stage s + 2: without the
   // peel all 16 waves load five words of a header of zeros); 2: the last
   auto stage = [&](uint32_t s, auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
     constexpr bool LAST = KIND == 2;
-#ifdef M3X_PEEL
     constexpr bool AHEAD2 = KIND == 0;
-#else
-    constexpr bool AHEAD2 = KIND != 2;
-#endif
     const uint32_t h0 = hdr(s).h0;
     const uint32_t n_resp = h0 & 0xFFFFu;
     Meta m_nn;
     if (LAST && !kBookLds) book_nxt = tf1_book(0);
-#ifndef M3X_META1
-    const uint32_t counts = counts_nxt;                    // requested a stage ago
-    if (!LAST) counts_nxt = fetch_counts(hdr(s + 1));
-#endif
     if (!LAST) {
       publish(s + 1, hdr(s + 1).h0, m_nxt, std::integral_constant<bool, tab_in_lds>{});  // waits for stage s+1's metadata only: it is older than the quads in flight
       if (AHEAD2) fetch_meta(hdr(s + 2), m_nn);
@@ -1121,7 +1068,6 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     uint32_t block0[G];
 #pragma unroll
     for (int h = 0; h < G; ++h) block0[h] = __builtin_amdgcn_readfirstlane((uint32_t)lds_woff[(s & 1u) * 16 * G + 16 * h + wave]);
-#ifdef M3X_META1
     // the lane's events' counts of this stage (published with the stage's tables); read here for the same reason
     uint32_t counts;
     {
@@ -1132,7 +1078,6 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       else if (G == 2) counts = *(const uint8_t*)(cb + lc);
       else counts = *(const uint16_t*)(cb + 2u * lc);
     }
-#endif
     auto scatter = [&](int u) {
       // bits 2..14 of a response word: byte offset of its slot.  Lanes past the stage's end hold no response.
 #ifdef M3_BRICK_HOLLOW
@@ -1153,15 +1098,10 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       for (int u = 0; u < kBrickRPL; ++u) scatter(u);
       if (kBookLds) book_nxt = tf1_book0();
       slab_begin();
-#ifdef M3X_EVWFIRST
       // the event's sample word BEFORE the rows: behind them (and behind the join of the branch around them) its request waited
       // for every row to arrive -- one more round trip in front of the oscillation look-up
       tail_issue_idx(0);
       if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
-#else
-      if (any_tf1) tf1_issue(0, kFirstBatch, kR0);
-      tail_issue_idx(0);
-#endif
     }
 #if !defined(M3_BRICK_HOLLOW) || M3_BRICK_HOLLOW != 2  // (hollow level 2: without this barrier -- nothing is scattered there)
     __syncthreads();  // the stage's scatter is complete
@@ -1175,18 +1115,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     }
   };
   if (n_stages > 0) {
-#ifdef M3X_PEEL
     for (uint32_t s = 0; s + 2 < n_stages; ++s) {
       stage(s, std::integral_constant<int, 0>{});
       if (s < 4) M3_STAMP(3 + s);
     }
     if (n_stages > 1) stage(n_stages - 2, std::integral_constant<int, 1>{});
-#else
-    for (uint32_t s = 0; s + 1 < n_stages; ++s) {
-      stage(s, std::integral_constant<int, 0>{});
-      if (s < 4) M3_STAMP(3 + s);
-    }
-#endif
     stage(n_stages - 1, std::integral_constant<int, 2>{});
     M3_STAMP(8);
   } else {  // (a brick without TSpline3 stages)
@@ -1243,35 +1176,13 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
           wh *= (cd - 1u < (uint32_t)(M3_TF1_SKIP - 1)) ? t : 1.0f;
         }
       };
-#ifdef M3X_TF1PIPE
-      constexpr bool kTf1Pipe = G == 1;
-#else
-      constexpr bool kTf1Pipe = false;
-#endif
-      if constexpr (kTf1Pipe) {
-      // The rows behind the first batch are requested as the first batch's registers come free, half a batch at a time, by every
-      // wave and without a branch around the loads (a wave whose events have no such rows reads one and the same line and drops
-      // it): a wave's second and third batch travel together instead of one after the other, each behind a wait for everything
-      constexpr std::integral_constant<int, 8> kHalf0{};
-      constexpr std::integral_constant<int, kBrickTf1Batch - 8> kHalf1{};
-      tf1_rows(kHalf0, kR0);
-      tf1_issue(kBrickTf1Batch, kHalf0, kR0);
-      tf1_rows(kHalf1, kHalf0);
-      tf1_issue(kBrickTf1Batch + 8, kHalf1, kHalf0);
-      for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += kBrickTf1Batch) {
-        tf1_rows(kHalf0, kR0);
-        tf1_issue(j0 + kBrickTf1Batch, kHalf0, kR0);
-        tf1_rows(kHalf1, kHalf0);
-        tf1_issue(j0 + kBrickTf1Batch + 8, kHalf1, kHalf0);
-      }
-      } else {
       tf1_rows(kFirstBatch, kR0);
-      // further rows in batches of 8 (16 at a time measured 1.6 % slower on config 3: the extra loads of rows nobody has)
+      // further rows in batches of 8 (16 at a time measured 1.6 % slower on config 3: the extra loads of rows nobody has; requested
+      // ahead by every wave as the first batch's registers come free, without a branch: +8 % -- round 4, 380 more loads per brick)
       constexpr std::integral_constant<int, 8> kNext{};
       for (uint32_t j0 = kBrickTf1Batch; __any(tf1_cnt > j0); j0 += 8) {
         tf1_issue(j0, kNext, kR0);
         tf1_rows(kNext, kR0);
-      }
       }
     }
     if (h == (uint32_t)(G - 1)) M3_STAMP(9);

@@ -101,8 +101,9 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 //   off_resp  one uint16 per response: slot << 2 | last response of its run (bits 2..14 are the byte offset of the
 //             response's slot in the scatter array).  Slots: wave-block after wave-block, inside a block event after event
 //             (lane order), an event's responses in ascending parameter order.  Stored two per
-//             dword the way a lane fetches them: dword [k][l] = word of response l + 2k * 1024 | word of response
-//             l + (2k + 1) * 1024 << 16; block k has one dword for every response of batch 2k (1024, fewer in the last)
+//             dword, a lane's dwords next to each other (the kernel fetches them with one load): record [l] of lane l = nd
+//             dwords, dword k = word of response l + 2k * 1024 | word of response l + (2k + 1) * 1024 << 16,
+//             nd = stage_word_dwords(n_resp) = 1, 2 or 3; one record for every lane that holds a response
 //   off_tf1   [0 .. 16 G)       float2 index (from the brick's TF1 store) of the first slot of wave-block b
 //             [16 G .. 32 G)    word offset (from the brick's first word) of wave-block b's first code dword
 //             [32 G .. 32 G + 256 G)  codes per lane-slot, uint8, four per word (slot k = 1024 h + l: what lane l works on in slab h)
@@ -179,14 +180,17 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   // `n_aim` = 0: every stage as long as the limits allow (the fewest stages there can be).  Otherwise: aim at `n_aim` stages
   // of equal size, re-aimed after every stage (one that the row limit closed early must not leave a stub of a few
   // responses behind: it would cost the same barriers as a full stage).
-  auto split = [&](uint32_t n_aim) {
+  // `n_4k`: the first n_4k stages hold at most 4096 responses and are filled to that; the others share what is left
+  auto split = [&](uint32_t n_aim, uint32_t n_4k) {
     std::vector<Range> st;
     std::vector<uint8_t> mult(ne, 0);
     int p0 = 0;
     uint32_t done = 0;  // responses in the stages closed so far
     while (p0 < n_params) {
-      uint32_t soft = uint32_t(M3_STAGE_CAP);
-      if (n_aim) {
+      const bool is_4k = st.size() < n_4k;
+      const uint32_t hard = is_4k ? 4096u : uint32_t(M3_STAGE_CAP);
+      uint32_t soft = hard;
+      if (n_aim && !is_4k) {
         const uint32_t left = S_ext - done, n_left = n_aim > st.size() ? n_aim - uint32_t(st.size()) : 1u;
         soft = std::min<uint32_t>(soft, (left + n_left - 1) / n_left);
       }
@@ -197,7 +201,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         const uint32_t a = cnt_s[p1], b = cnt_s[p1 + 1], n_run = ext(b - a);
         if (n_run == 0) { ++p1; continue; }
         if (tot > 0) {
-          bool fits = tot + n_run <= uint32_t(M3_STAGE_CAP) && runs < uint32_t(M3_STAGE_MAX_RUNS);
+          bool fits = tot + n_run <= hard && runs < uint32_t(M3_STAGE_MAX_RUNS);
           for (uint32_t r = a; fits && r < b; ++r) fits = mult[inv_ev[r]] < uint8_t(M3_STAGE_EVENT_MAX);
           if (!fits) break;
         }
@@ -213,10 +217,23 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     }
     return st;
   };
-  std::vector<Range> st_s = split(0);
+  std::vector<Range> st_s = split(0, 0);
   if (st_s.size() > 1) {
-    std::vector<Range> even = split(uint32_t(st_s.size()));
+    std::vector<Range> even = split(uint32_t(st_s.size()), 0);
     if (even.size() <= st_s.size()) st_s.swap(even);
+    // A lane's response words of a stage are stored next to each other, two per dword: a stage of up to 4096 responses takes two
+    // dwords per lane, one of up to 5120 three, whatever it holds -- so as many stages as the count allows are filled to 4096
+    // exactly and the others share the rest (config 3, 17.3 k list entries in four stages: 3 x 4096 + 5012; four stages of
+    // 4330 would carry a third dword per lane for 234 responses each)
+    const uint32_t n = uint32_t(st_s.size());
+    const uint32_t room = n * uint32_t(M3_STAGE_CAP) > S_ext ? n * uint32_t(M3_STAGE_CAP) - S_ext : 0u;
+    // (only where equal shares would need the third dword; run-count cuts and light bricks keep their even stages)
+    uint32_t n4k = (S_ext + n - 1) / n > 4096u ? std::min<uint32_t>(n, room / uint32_t(M3_STAGE_CAP - 4096)) : 0u;
+    // (a stage closes up to one run short of its limit: try with fewer 4096-stages until the count holds)
+    for (; n4k > 0; --n4k) {
+      std::vector<Range> packed = split(n, n4k);
+      if (packed.size() <= n) { st_s.swap(packed); break; }
+    }
   }
   const uint32_t n_stages = uint32_t(st_s.size());
   if (n_stages > uint32_t(M3_BRICK_MAX_STAGES)) {
@@ -312,14 +329,17 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         w.push_back(d);
       }
     }
-    // response words, two per dword the way a lane fetches them: lane l of the workgroup works on responses
-    // l, l + 1024, l + 2048, ... of the stage; dword [k][l] = word of response l + 2k * 1024 | word of response
-    // l + (2k + 1) * 1024 << 16.  Block k holds one dword for every response of batch 2k (1024 but for the last block).
+    // response words, two per dword, a lane's dwords next to each other (one load fetches them): lane l of the workgroup works on
+    // responses l, l + 1024, l + 2048, ... of the stage; record [l] = nd dwords, dword k = word of response l + 2k * 1024 |
+    // word of response l + (2k + 1) * 1024 << 16, nd = stage_word_dwords(n_resp); records for the lanes that hold a response
     const uint32_t off_resp = uint32_t(w.size());
-    for (uint32_t k = 0; 2 * k * uint32_t(M3_GROUP) < n_resp; ++k) {
-      const uint32_t lo0 = 2 * k * uint32_t(M3_GROUP), hi0 = lo0 + uint32_t(M3_GROUP);
-      const uint32_t len = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp - lo0);
-      for (uint32_t l = 0; l < len; ++l) w.push_back(uint32_t(resp[lo0 + l]) | (hi0 + l < n_resp ? uint32_t(resp[hi0 + l]) << 16 : 0u));
+    {
+      const uint32_t nd = stage_word_dwords(n_resp), lanes = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp);
+      for (uint32_t l = 0; l < lanes; ++l)
+        for (uint32_t k = 0; k < nd; ++k) {
+          const uint32_t lo = 2 * k * uint32_t(M3_GROUP) + l, hi = lo + uint32_t(M3_GROUP);
+          w.push_back((lo < n_resp ? uint32_t(resp[lo]) : 0u) | (hi < n_resp ? uint32_t(resp[hi]) << 16 : 0u));
+        }
     }
     uint32_t* h = &w[size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * stage];
     h[0] = n_resp | (n_runs << 16) | (rows << 26);
@@ -449,7 +469,7 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
       // their words point into the scatter array's slack)
       auto word_at = [&](uint32_t i) -> uint32_t {
         const uint32_t u = i / uint32_t(M3_GROUP), l = i % uint32_t(M3_GROUP);
-        const uint32_t d = words[h[3] + uint32_t(M3_GROUP) * (u / 2) + l];
+        const uint32_t d = words[h[3] + stage_word_dwords(n_resp) * l + u / 2];
         return (u & 1u) ? d >> 16 : d & 0xFFFFu;
       };
       while (n_run > 0 && ((word_at(start_r + n_run - 1) & 0x7FFCu) >> 2) >= uint32_t(M3_STAGE_CAP)) --n_run;
@@ -475,7 +495,7 @@ int g_tf1_sort = 2;
 int g_pad_runs = 2;
 
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
-                std::string* err, int brick_groups) {
+                std::string* err, int brick_groups, uint64_t short_from, uint64_t short_to) {
   if (brick_groups != 1 && brick_groups != 2 && brick_groups != 4) { *err = "brick_groups must be 1, 2 or 4"; return false; }
   const uint32_t G = uint32_t(brick_groups);
   plan->tiles.clear();
@@ -560,7 +580,8 @@ bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInp
     if (!uniform[t0]) {
       // stages hold 3 000 - 5 120 responses (an event may hold 15 of a stage): stay well inside M3_BRICK_MAX_STAGES
       uint64_t resp = tile_resp(t0);
-      while (t1 < n_tiles && t1 - t0 < tiles_per_group * G && !uniform[t1] &&
+      const uint64_t cap = t0 * M3_TE >= short_from && t0 * M3_TE < short_to ? tiles_per_group * G * 3 / 4 : tiles_per_group * G;
+      while (t1 < n_tiles && t1 - t0 < cap && t1 * M3_TE != short_from && t1 * M3_TE != short_to && !uniform[t1] &&
              (t1 - t0 < tiles_per_group || resp + tile_resp(t1) <= 3000ull * uint64_t(M3_BRICK_MAX_STAGES))) {
         resp += tile_resp(t1);
         ++t1;

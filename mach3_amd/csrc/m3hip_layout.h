@@ -51,6 +51,8 @@ constexpr int M3_STAGE_CAP = 5120;       // TSpline3 responses per brick stage (
 constexpr int M3_STAGE_MAX_RUNS = 512;   // runs per stage (the resolved run table lives in LDS)
 constexpr int M3_STAGE_EVENT_MAX = 15;   // responses one event may hold in a stage (its count is a nibble)
 constexpr int M3_BRICK_MAX_GROUPS = 4;   // a brick holds up to 4 x M3_GROUP events
+// dwords of response words a lane holds in a stage of n_resp list entries (two 16-bit words per dword)
+constexpr uint32_t stage_word_dwords(uint32_t n_resp) { return ((n_resp + 1023u) / 1024u + 1u) / 2u; }
 constexpr int M3_STAGE_PAIR_WORDS = M3_STAGE_CAP / 64;  // {run of the group's first response, first slot of wave-block} pairs per stage
 constexpr int M3_BRICK_MAX_STAGES = 250; // stage headers are staged in LDS (one load per lane of the workgroup)
 constexpr int M3_BRICK_HDR0 = 8;         // words in front of the stage headers
@@ -149,8 +151,11 @@ extern int g_pad_runs;  // runs padded to whole lines in the stages' response li
 // Returns false and sets err on inconsistent input.
 // brick_groups: G of the bricks (1, 2 or 4); a brick whose TSpline3 responses would need more stages than the header block
 // holds falls back to a smaller G.
+// [short_from, short_to): chunk-local events (multiples of M3_TE) whose bricks are cut at three quarters of the size -- four short
+// bricks where three full ones would be -- and whose ends no brick spans: the engine's way of handing every compute unit the same
+// number of bricks (m3hip_api.hip: ShortBrickPlan)
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
-                std::string* err, int brick_groups = 1);
+                std::string* err, int brick_groups = 1, uint64_t short_from = ~0ull, uint64_t short_to = ~0ull);
 
 // Fills caller-provided stores (sizes from the plan).  Multi-threaded.
 void fill_chunk(int n_params, const int16_t* npts, const ChunkInput& in, const ChunkPlan& plan, float* spl /*float4*/,

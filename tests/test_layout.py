@@ -165,14 +165,16 @@ def brick_event_lists(npts, ch, lay, b):
             for h in range(4):
                 cnt[1024 * h: 1024 * (h + 1)] = (hw >> (4 * h)) & 15
         assert not cnt[nev:].any() and cnt.max() == rows <= STAGE_EVENT_MAX
-        resp = np.zeros(n_resp, np.uint16)                # two per dword, the way a lane fetches them
-        for k in range((n_resp + 2047) // 2048):
-            ln = min(1024, n_resp - 2048 * k)
-            blk = w[off_resp + 1024 * k: off_resp + 1024 * k + ln]
-            resp[2048 * k: 2048 * k + ln] = blk & 0xFFFF
-            hi = min(ln, max(0, n_resp - 2048 * k - 1024))
-            resp[2048 * k + 1024: 2048 * k + 1024 + hi] = blk[:hi] >> 16
-            assert not (blk[hi:] >> 16).any()
+        resp = np.zeros(n_resp, np.uint16)                # two per dword, a lane's dwords next to each other
+        nd, lanes = ((n_resp + 1023) // 1024 + 1) // 2, min(1024, n_resp)
+        rec = w[off_resp: off_resp + nd * lanes].reshape(lanes, nd)
+        for k in range(nd):
+            lo = 2048 * k
+            n_lo = max(0, min(lanes, n_resp - lo))
+            resp[lo: lo + n_lo] = rec[:n_lo, k] & 0xFFFF
+            n_hi = max(0, min(lanes, n_resp - lo - 1024))
+            resp[lo + 1024: lo + 1024 + n_hi] = rec[:n_hi, k] >> 16
+            assert not (rec[n_hi:, k] >> 16).any() and not (rec[n_lo:, k] & 0xFFFF).any()
         ell = {}
         run = -1
         n_pad = 0
@@ -413,6 +415,51 @@ def test_bricks_of_several_event_groups(monkeypatch, groups, n_events, cfg):
     assert lay["n_bricks"] == -(-n_events // (1024 * groups)) and lay["n_tiles"] == 0
     assert [int(d[5]) for d in lay["bdesc"]] == [min(1024 * groups, n_events - 1024 * groups * b) for b in range(lay["n_bricks"])]
     check_bricks(npts, ch, lay)
+
+
+@pytest.mark.parametrize("groups,n_events,short_from,short_to,sizes", [
+    (1, 2048 + 3072 + 1024 + 300, 2048, 2048 + 3072, [1024, 1024, 768, 768, 768, 768, 1024, 300]),
+    (2, 2048 + 6144 + 1000, 2048, 2048 + 6144, [2048, 1536, 1536, 1536, 1536, 1000]),
+    (1, 3072 + 600, 0, 3072, [768, 768, 768, 768, 600]),
+])
+def test_short_bricks_near_the_end_of_a_launch(monkeypatch, groups, n_events, short_from, short_to, sizes):
+    """Between two given events the planner cuts bricks at three quarters of their size, four where three full ones would be (the
+    engine asks for that when it knows the sample's size, so that every compute unit gets the same number of bricks:
+    m3hip_api.hip ShortBrickPlan); no brick spans the stretch's ends, and the short bricks replay event by event like the full ones."""
+    monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
+    monkeypatch.setenv("M3HIP_DEBUG_SHORT_FROM", str(short_from))
+    monkeypatch.setenv("M3HIP_DEBUG_SHORT_TO", str(short_to))
+    spec = synth.CONFIGS["c3"].scaled(n_events)
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, n_events)
+    rc, err, lay = debug_layout(spec.n_params, spec.n_knots, npts, ch)
+    assert rc == 0, err
+    assert [int(d[5]) for d in lay["bdesc"]] == sizes and lay["n_tiles"] == 0
+    assert [int(d[6]) for d in lay["bdesc"]] == list(np.cumsum([0] + sizes[:-1]))
+    check_bricks(npts, ch, lay)
+
+
+@pytest.mark.parametrize("events,chunk,groups,bricks", [
+    (10_000_000, 131072, 1, 9984),          # config 3 as bench.py uploads it: 9 766 bricks -> 39 for each of 256 units
+    (10_000_000, 10_000_384, 1, 9984),      # ... in one call
+    (12_500_000, 131072, 4, 3072),          # one GPU's share of config 5: 3 052 bricks of 4096 events -> 12 each
+    (5_000_000, 131072, 1, 4883 + 237),     # config 4's share: 4 883 -> 5 120
+    (9984 * 1024, 131072, 1, 9984),         # a multiple already: left alone
+    (100_000_000, 131072, 1, 97657),        # 381 bricks per unit: the imbalance is below the rule's threshold
+    (300_000, 131072, 1, 293),              # 293 bricks for 256 units: 219 more would convert the whole sample -- left alone
+])
+def test_brick_count_is_a_multiple_of_the_compute_units(events, chunk, groups, bricks):
+    """the rule itself, walked chunk by chunk on the host (ShortBrickPlan through m3hip_debug_short_brick_plan)"""
+    import ctypes as C
+    from mach3_amd import capi
+    lib = capi.load_m3hip()
+    nb, ns = C.c_uint64(0), C.c_uint64(0)
+    assert lib.m3hip_debug_short_brick_plan(events, chunk, groups, 256, C.byref(nb), C.byref(ns)) == 0
+    assert nb.value == bricks
+    full = -(-events // (1024 * groups))
+    assert ns.value == 4 * (bricks - full)              # a conversion of three full bricks into four short ones gains one
+    if bricks != full:
+        assert bricks % 256 == 0
 
 
 def test_layout_under_sanitizers(tmp_path):
