@@ -844,23 +844,31 @@ static int choose_brick_groups(const ChunkInput& in, uint64_t expect_events) {
 }
 
 // Equal shares of a brick launch.  The device hands workgroups to its XCDs in turn and each compute unit works on two at a time,
-// so a launch of nb equal bricks lasts as long as the compute unit with the most of them: ceil(nb / n_cu) bricks' worth, whatever
-// nb % n_cu is (config 3: 9 766 bricks on 256 units = 38.15 each; measured 71.9 ns per brick against 71.2 for 9 728 / 9 984 /
-// 10 240 bricks).  When the upload announced its size (m3hip_monolith_expect_events), the count is brought to the next multiple
-// of n_cu by cutting bricks near the END of the sample at three quarters of the size -- four where three would be, so that a
-// converted stretch ends where the full bricks' boundaries are and chunk borders cost nothing; last, so that the greedy
-// dispatch finishes on the small ones.  begin(): the rule, from the announced size and the first chunk's (the stretch is
-// started early by one conversion per chunk border expected inside it, because a chunk's share of it is rounded down to whole
-// conversions); take(): a chunk's share.  Not applied: size unknown, more than 150 bricks per unit (the imbalance is below
-// 0.3 % then), or more than a quarter of the sample would be converted.  M3HIP_SHORT_BRICKS=0 switches it off.
+// so a launch of nb equal bricks lasts about as long as the compute unit with the most of them: ceil(nb / n_cu) bricks' worth.
+// When the upload announced its size (m3hip_monolith_expect_events) and the last, partly filled round would idle more than
+// 3 % of the launch, the count is brought to the next multiple of n_cu by cutting bricks near the END of the sample at three
+// quarters of the size -- four where three would be, so that a converted stretch ends where the full bricks' boundaries are
+// and chunk borders cost nothing; last, so that the greedy dispatch finishes on the small ones.  Measured (round 4, config-3
+// events, kernel time without / with): 5e6 events = 19.07 bricks per unit 360 / 357 us (four samples of 800 bins: 373.5 /
+// 361.8), 2.5e6 = 9.5 per unit 185.3 / 183.4; NOT applied where it measured level or worse: 1e7 events = 38.15 per unit
+// (693.3 / 692.8: the short bricks' fixed costs eat what the even finish gains), 1.25e6 = 4.8 per unit (86.6 / 88.3: with so
+// few rounds the units stay in step and a fifth of the bricks short only costs).  begin(): the rule, from the announced size
+// and the first chunk's (the stretch is started early by one conversion per chunk border expected inside it, because a
+// chunk's share of it is rounded down to whole conversions); take(): a chunk's share.  M3HIP_SHORT_BRICKS=0 switches it off,
+// =2 applies it wherever bricks can be gained (tests).
 void ShortBrickPlan::begin(uint64_t expect_events, uint64_t first_chunk_events, int G, int n_cu) {
   *this = ShortBrickPlan();
   decided = true;
-  if (const char* f = getenv("M3HIP_SHORT_BRICKS")) if (f[0] == '0') return;
+  bool force = false;
+  if (const char* f = getenv("M3HIP_SHORT_BRICKS")) {
+    if (f[0] == '0') return;
+    force = f[0] == '2';
+  }
   if (expect_events == 0 || n_cu <= 0 || first_chunk_events == 0) return;
   B = uint64_t(M3_GROUP) * uint64_t(G);
   const uint64_t nb = (expect_events + B - 1) / B, cu = uint64_t(n_cu);
-  if (nb % cu == 0 || nb / cu >= 150) return;
+  if (nb % cu == 0) return;
+  if (!force && (nb / cu < 8 || (cu - nb % cu) * 100 < 3 * nb)) return;  // few rounds, or less than 3 % of the launch to gain
   const uint64_t extra = (nb + cu - 1) / cu * cu - nb;              // bricks to gain: one per conversion of 3 B events
   const uint64_t slack = (3 * B * extra + first_chunk_events - 1) / first_chunk_events + 1;
   const uint64_t full_end = expect_events / B * B;                    // (the events behind it are the sample's last, partial brick)

@@ -440,13 +440,14 @@ def test_short_bricks_near_the_end_of_a_launch(monkeypatch, groups, n_events, sh
 
 
 @pytest.mark.parametrize("events,chunk,groups,bricks", [
-    (10_000_000, 131072, 1, 9984),          # config 3 as bench.py uploads it: 9 766 bricks -> 39 for each of 256 units
-    (10_000_000, 10_000_384, 1, 9984),      # ... in one call
-    (12_500_000, 131072, 4, 3072),          # one GPU's share of config 5: 3 052 bricks of 4096 events -> 12 each
-    (5_000_000, 131072, 1, 4883 + 237),     # config 4's share: 4 883 -> 5 120
-    (9984 * 1024, 131072, 1, 9984),         # a multiple already: left alone
-    (100_000_000, 131072, 1, 97657),        # 381 bricks per unit: the imbalance is below the rule's threshold
-    (300_000, 131072, 1, 293),              # 293 bricks for 256 units: 219 more would convert the whole sample -- left alone
+    (5_000_000, 131072, 1, 5120),           # half of config 3 / config 4's share of one GPU in eight: 4 883 bricks = 19.07 per unit -> 20
+    (5_000_000, 5_000_192, 1, 5120),        # ... in one call
+    (2_500_000, 131072, 1, 2560),           # a quarter: 9.54 per unit -> 10
+    (10_000_000, 131072, 1, 9766),          # config 3: 38.15 per unit, 2.2 % of the launch to gain: measured level, left alone
+    (12_500_000, 131072, 4, 3052),          # one GPU's share of config 5: 11.92 per unit, 0.7 % to gain: left alone
+    (1_250_000, 131072, 1, 1221),           # 4.8 rounds: too few (measured 2 % worse with short bricks)
+    (5120 * 1024, 131072, 1, 5120),         # a multiple already
+    (100_000_000, 131072, 1, 97657),        # 381 bricks per unit
 ])
 def test_brick_count_is_a_multiple_of_the_compute_units(events, chunk, groups, bricks):
     """the rule itself, walked chunk by chunk on the host (ShortBrickPlan through m3hip_debug_short_brick_plan)"""
