@@ -889,11 +889,30 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 #pragma unroll
     for (int q = 0; q < N / 4; ++q) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + 4 * q);
+      tf1_on[R0 / 4 + q] = tf1_cnt > j0 + 4 * q;
+#ifdef M3X_TF1TRIM
+      // four rows none of the wave's events has: no loads at all (the slots are sorted by code count, so the waves at the end of a
+      // slab stop early; the waits behind this are for everything anyway -- the branch costs them nothing)
+      if (q > 0 && act == 0ull) {
+        code[R0 / 4 + q] = 0u;
+        continue;
+      }
+#endif
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
       code[R0 / 4 + q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
-      tf1_on[R0 / 4 + q] = tf1_cnt > j0 + 4 * q;
+#ifdef M3X_TF1TRIM
+#pragma unroll
+      for (int i = 4 * q; i < 4 * q + 4; ++i) {
+        const unsigned long long acti = __ballot(tf1_cnt > j0 + i);
+        const uint32_t posi = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(acti >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acti, 0u));
+        const f32x2_t v = *(const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * posi);
+        ab[R0 + i] = make_float2(v.x, v.y);
+        tf1_cbase += (uint32_t)__popcll(acti);
+      }
+#endif
     }
+#ifndef M3X_TF1TRIM
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + i);
@@ -906,6 +925,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       ab[R0 + i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
     }
+#endif
   };
   constexpr std::integral_constant<int, 0> kR0{};
   constexpr std::integral_constant<int, kBrickTf1Batch> kFirstBatch{};
