@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   __shared__ PTab lds_ptab[kBrickLdsParams];
   __shared__ float lds_tf1x[kBrickLdsParams + 1];  // [1 + k]: parameter value of entry k of the TF1 dictionary
   __shared__ u32x2_t lds_cnt[2 * 64 * G];  // [stage & 1]: the events' response counts of the stage, as the planner stores them
-  __shared__ uint32_t lds_book[G != 4 ? kBrickThreads : 1];  // slab 0's TF1 bookkeeping per lane-slot: code count | the slot's event << 16
+  __shared__ uint32_t lds_book[kBrickThreads];  // slab 0's TF1 bookkeeping per lane-slot: code count | the slot's event << 16
   __shared__ uint32_t lds_bookw[32];            // [wave]: first float2 of the wave-block's rows, [16 + wave]: first code dword
   __shared__ float lds_nv[64];  // PACK: the norm parameters the packed words' 6-bit codes can name, float(params[evw_norm_base + k]) (SampleHandlerFD.cpp:575: the cast the reference makes per event)
   extern __shared__ double lds_hist[];
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
   // requested at the top of the last stage instead
   Tf1Book book_nxt = {0u, 0u, 0u};
-  constexpr bool kBookLds = G != 4;  // (G = 4 has no register for it: 12 bytes of scratch)
+  constexpr bool kBookLds = true;
   // slab 0's bookkeeping comes in with the prologue's round trip and waits in LDS for the last stage: requested there (as
   // slabs h > 0 still are) it put a round trip of its own in front of the first TF1 rows
   uint32_t book0_cnt = 0, book0_w = 0;
@@ -883,49 +883,44 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t ev_slot = 0;  // the event (relative to its slab) this lane works on from here on: sigma[slot]
   const M3_GLOBAL char* __restrict__ tf1_bytes = (const M3_GLOBAL char*)as_global(bd.tf1);
   // loads of rows j0 .. j0 + N - 1 into registers R0 .. R0 + N - 1 of the batch (nothing here waits)
+  // kTrim (bricks of several slabs): four rows none of the wave's events has are not requested at all -- the slots are sorted by
+  // code count, so the waves at the end of a slab stop early, and with 8 codes per event (config 5) most waves of a slab do: one
+  // GPU's share of config 5 480 -> 475 us.  The branch costs the waits behind it nothing (they are for everything anyway).  At
+  // G = 1 (config 3: 16 codes per event, the first batch is full in nearly every wave) it measured level to 0.3 % worse: off.
+  constexpr bool kTrim = G != 1;
   auto tf1_issue = [&](uint32_t j0, auto nrows_tag, auto r0_tag) {
     constexpr int N = decltype(nrows_tag)::value, R0 = decltype(r0_tag)::value;
     static_assert(N % 4 == 0 && R0 % 4 == 0, "a code dword covers four rows");
+    auto row = [&](int i) {
+      const unsigned long long act = __ballot(tf1_cnt > j0 + i);
+      const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+      // plain (cached) loads: the lines at the seams of two rows are wanted twice.  With the slots sorted by code count the rows
+      // of a wave are full for longer and this wins on both configurations (config 3 -0.7 %, config 5 -1.1 %); round 2's unsorted
+      // rows preferred non-temporal loads on config 3
+      const f32x2_t v = *(const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos);
+      ab[R0 + i] = make_float2(v.x, v.y);
+      tf1_cbase += (uint32_t)__popcll(act);
+    };
 #pragma unroll
     for (int q = 0; q < N / 4; ++q) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + 4 * q);
       tf1_on[R0 / 4 + q] = tf1_cnt > j0 + 4 * q;
-#ifdef M3X_TF1TRIM
-      // four rows none of the wave's events has: no loads at all (the slots are sorted by code count, so the waves at the end of a
-      // slab stop early; the waits behind this are for everything anyway -- the branch costs them nothing)
-      if (q > 0 && act == 0ull) {
+      if (kTrim && q > 0 && act == 0ull) {
         code[R0 / 4 + q] = 0u;
         continue;
       }
-#endif
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
       code[R0 / 4 + q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
-#ifdef M3X_TF1TRIM
+      if (kTrim) {
 #pragma unroll
-      for (int i = 4 * q; i < 4 * q + 4; ++i) {
-        const unsigned long long acti = __ballot(tf1_cnt > j0 + i);
-        const uint32_t posi = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(acti >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acti, 0u));
-        const f32x2_t v = *(const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * posi);
-        ab[R0 + i] = make_float2(v.x, v.y);
-        tf1_cbase += (uint32_t)__popcll(acti);
+        for (int i = 4 * q; i < 4 * q + 4; ++i) row(i);
       }
-#endif
     }
-#ifndef M3X_TF1TRIM
+    if (!kTrim) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const unsigned long long act = __ballot(tf1_cnt > j0 + i);
-      const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      const M3_GLOBAL f32x2_t* gp = (const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos);
-      // plain (cached) loads: the lines at the seams of two rows are wanted twice.  With the slots sorted by code count the rows
-      // of a wave are full for longer and this wins on both configurations (config 3 -0.7 %, config 5 -1.1 %); round 2's unsorted
-      // rows preferred non-temporal loads on config 3
-      const f32x2_t v = *gp;
-      ab[R0 + i] = make_float2(v.x, v.y);
-      tf1_cbase += (uint32_t)__popcll(act);
+      for (int i = 0; i < N; ++i) row(i);
     }
-#endif
   };
   constexpr std::integral_constant<int, 0> kR0{};
   constexpr std::integral_constant<int, kBrickTf1Batch> kFirstBatch{};
@@ -1004,7 +999,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     Tf1Book b;
     uint32_t le = lane;
     asm volatile("" : "+v"(le));
-    b.cnt = lds_book[G != 4 ? le : 0u];
+    b.cnt = lds_book[le];
     b.cbase = __builtin_amdgcn_readfirstlane(lds_bookw[wave]);
     b.dbase = __builtin_amdgcn_readfirstlane(lds_bookw[16u + wave]);
     return b;
