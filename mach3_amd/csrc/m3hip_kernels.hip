@@ -549,7 +549,7 @@ static_assert(kBrickRPL <= kBrickGrpPerWave, "group entries of a wave");
 static_assert(16 * M3_BRICK_MAX_GROUPS <= M3_STAGE_PAIR_WORDS, "a wave-block's first slot travels in the high half of a pair word");
 static_assert(4 * (M3_STAGE_CAP + kBrickEllSlack) <= 0x8000, "bits 2..14 of a response word are a byte offset into the scatter array");
 // LDS budget: two workgroups per CU (what __launch_bounds__(1024, 8) and the 64-VGPR kernel are tuned for) leave each 80 KB of
-// gfx950's 160 KB.  The static arrays below take 46 KB at any G; the dynamic bin vector of a fill launch is capped at
+// gfx950's 160 KB.  The static arrays below take 55 KB at any G (round 4: + the TF1 bookkeeping of slab 0 and the stages' count words); the dynamic bin vector of a fill launch is capped at
 // M3_HIST_LDS_MAX_BYTES, so the sum fits whatever the bin space (round 2's [rank][event] scatter array did not leave that room).
 constexpr size_t kBrickStaticLds = sizeof(float) * (M3_STAGE_CAP + kBrickEllSlack) + 8 * 2 * (size_t)kBrickRunSlots + 2 * 2 * 16 * kBrickGrpPerWave +
                                    2 * 2 * 16 * M3_BRICK_MAX_GROUPS + 4 * (size_t)kBrickHdrWords + 8 * (size_t)kBrickLdsParams + 4 * ((size_t)kBrickLdsParams + 1) +
