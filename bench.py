@@ -341,6 +341,10 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
     in_library = comm_mode.startswith("rccl")
     if in_library:
         eng.comm_set_validate(True)
+    # torch's own device context is created by its first cuda call; with one rank that would be the synchronize() that opens the
+    # timed region, and what the runtime does in the background after it (observed on config 5's shard: one stall of ~30 ms inside
+    # the first timed steps) belongs in front of the untimed spin-up steps instead
+    torch.cuda.synchronize()
     t_spin = time.perf_counter()
     n_spin = 0
 
@@ -393,6 +397,16 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         t[rank] = k_ms
         dist.all_reduce(t)
         k_all = [float(x) for x in t.cpu()]
+    if os.environ.get("M3_BENCH_PHASES") == "1":  # diagnostics: where the host side of a step spends its time (untimed extra steps)
+        import ctypes as C
+        ph, acc = (C.c_double * 6)(), np.zeros(6)
+        t_ph = time.perf_counter()
+        for i in range(40):
+            step(2000 + i)
+            eng.lib.m3hip_debug_host_times(eng.h, ph)
+            acc += np.array(list(ph))
+        log(f"[bench] rank {rank}: 40 extra steps {(time.perf_counter() - t_ph) / 40 * 1e6:.1f} us each; host phases per step (us): "
+            "stage params, launch prep, launch reweight, launch llh, wait, collect = " + ", ".join(f"{x / 40 * 1e6:.1f}" for x in acc))
     check = None
     if args.check:  # LLH of a few laps, for the comparison with a one-rank run of the same sample
         check = []
