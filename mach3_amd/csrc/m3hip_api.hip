@@ -234,6 +234,9 @@ struct m3hip_ctx {
   uint64_t upload_expect = 0;     // ... the hint of the upload in progress
   int n_cu = 0;                   // compute units of the device
   ShortBrickPlan short_bricks;    // of the upload in progress
+  uint64_t re_tables = 0, re_book = 0, re_codes = 0;  // bytes of the bricks' small re-read streams (stage tables, TF1 bookkeeping, TF1 codes)
+  int nt_force = -1;              // M3HIP_NT_MASK: ReweightArgs::nt_mask as given instead of the engine's choice (experiments)
+  double cached_mb = 200.0;       // M3HIP_CACHED_MB: what the engine plans to keep in the Infinity Cache from step to step
   uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts
@@ -544,6 +547,7 @@ void free_monolith(m3hip_handle h) {
   h->M = 0;
   h->max_osc_idx = h->max_norm_idx = h->max_parmap = h->max_bin_idx = -1;
   h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
+  h->re_tables = h->re_book = h->re_codes = 0;
   h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
   h->parmap_set = false;
@@ -586,6 +590,27 @@ int bins_from_word(m3hip_handle h) {
 bool evw_fits(m3hip_handle h) {
   bool ok = !h->f64 && !h->h_bricks.empty() && h->max_bin_idx < (1 << 20) - 2 && h->n_bins < (1 << 20) - 2 && h->max_osc_idx < (1 << 24) - 2 && h->d_bin && h->d_osc;
   return ok && h->sw_packed != '0';
+}
+
+// Which of the brick kernel's small streams stay cached from step to step (ReweightArgs::nt_mask: a set bit = loaded non-temporally,
+// around the Infinity Cache).  The kernel's large streams -- coefficients, TF1 rows, response words -- never allocate there, so
+// what does is what a step re-reads: the stages' tables (always cached: a stage's idle waves re-read them), the sample words, slab
+// 0's TF1 bookkeeping and the TF1 codes, taken in that order while they fit the budget (200 MB of the 256: a table survives a
+// non-temporal stream up to about 192 MB, tools/mall_probe.hip).  Measured on config 3 (kernel, one box per line):
+// 1e7 events -- tables + sample words + bookkeeping cached (160 MB), codes (176 MB) around: 690.5 us; codes cached alone 695.0;
+// sample words + bookkeeping only 701; everything plain (round 3's way) 712; everything non-temporal 721.5.
+// 5e6 events -- all four cached (168 MB): 347.4; codes alone 354.4; everything plain 362.9.
+static uint32_t choose_nt_mask(m3hip_handle h, bool word_valid) {
+  if (h->nt_force >= 0) return uint32_t(h->nt_force) & 7u;
+  const double budget = h->cached_mb * 1e6;
+  const bool lin = h->brick_groups <= 1;  // bricks of 1024 events load the sample words in event order; larger ones gather them (cached)
+  const double evw = word_valid ? 8.0 * double(h->E) : 0.0;
+  double used = double(h->re_tables) + (lin ? 0.0 : evw);
+  uint32_t mask = 0;
+  if (lin && word_valid) { if (used + evw <= budget) used += evw; else mask |= 2u; }
+  if (used + double(h->re_book) <= budget) used += double(h->re_book); else mask |= 1u;
+  if (used + double(h->re_codes) <= budget) used += double(h->re_codes); else mask |= 4u;
+  return mask;
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
@@ -794,6 +819,8 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   { const char* f = getenv("M3HIP_OSC_COLUMN"); h->oscw_mode = f && f[0] ? atoi(f) : -1; }
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
   h->short_bricks = ShortBrickPlan();
+  { const char* f = getenv("M3HIP_NT_MASK"); h->nt_force = f && f[0] ? atoi(f) : -1; }
+  { const char* f = getenv("M3HIP_CACHED_MB"); h->cached_mb = f && f[0] ? atof(f) : 200.0; }
   h->expect_events = 0;
   h->P = n_params;
   h->K = max_knots;
@@ -1065,6 +1092,9 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     }
   }
   for (const BrickHost& bh : plan.bricks) {
+    h->re_tables += bh.bytes_tables;
+    h->re_book += bh.bytes_book;
+    h->re_codes += bh.bytes_codes;
     h->brick_res_off.push_back(dict_res);
     BrickDev bd;
     bd.spl = reinterpret_cast<const float4*>(c.d_spl) + bh.spl_off;
@@ -2214,6 +2244,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.dyn.compute_nominal = 0;
   }
   if (h->oscw_valid && !h->f64) a.oscw = h->d_oscw;
+  a.nt_mask = choose_nt_mask(h, word_valid);
   if (word_valid) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);

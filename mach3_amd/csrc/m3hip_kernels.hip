@@ -601,6 +601,16 @@ __device__ __forceinline__ const M3_GLOBAL T* uniform_base(const M3_GLOBAL T* p)
   return (const M3_GLOBAL T*)(((uint64_t)hi << 32) | lo);
 }
 
+// Which of a brick's streams go around the Infinity Cache.  Non-temporal loads do not allocate in its 256 MB and a plain stream
+// evicts it (tools/mall_probe.hip), so the two large streams a step reads once besides the coefficients -- the TF1 rows (1.28 GB
+// per step of config 3) and the response words (350 MB) -- are loaded non-temporally like the coefficients, and the small ones a
+// step re-reads -- the stages' tables always (idle waves re-read them from L1), bookkeeping, sample words and TF1 codes as far
+// as the engine's budget goes (ReweightArgs::nt_mask) -- then stay there from step to step and come back in 545 instead of 900+
+// cycles, which is what a compute unit's outstanding misses turn into bandwidth (round 4, config 3: 712 -> 690 us).
+template <class T>
+__device__ __forceinline__ T load_maybe_nt(const M3_GLOBAL T* p, bool nt) {
+  return nt ? __builtin_nontemporal_load(p) : *p;
+}
 struct RRun {      // per-step resolved run: quad address = base + r, dx of the run's parameter
   int32_t base;    // coef_off - start_r + seg * stride   (float4 units from the brick's store)
   float dx;
@@ -695,7 +705,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       const uint32_t nd = ((n_resp + 1023u) / 1024u + 1u) / 2u;  // scalar
       const uint32_t lanes = n_resp < (uint32_t)kBrickThreads ? (n_resp ? n_resp : 1u) : (uint32_t)kBrickThreads;
       const uint32_t l = lane < lanes - 1u ? lane : lanes - 1u;
-      const u32x3_t v = *(const M3_GLOBAL u32x3_t*)(uniform_base(wbytes + 4u * hd.off_resp) + 4u * nd * l);
+      const u32x3_t v = __builtin_nontemporal_load((const M3_GLOBAL u32x3_t*)(uniform_base(wbytes + 4u * hd.off_resp) + 4u * nd * l));
       static_assert(kWordRegs == 3, "a lane's response words of a stage travel as three dwords");
       m.w[0] = v.x;
       m.w[1] = v.y;
@@ -763,8 +773,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t book0_cnt = 0, book0_w = 0;
   if (kBookLds) {
     const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));
-    book0_cnt = *(const M3_GLOBAL uint8_t*)(cb + lane);
-    book0_cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane)) << 16;
+    const bool nt_book = (a.nt_mask & 1u) != 0;  // (kernel-uniform; the prologue's waits are for everything)
+    book0_cnt = load_maybe_nt((const M3_GLOBAL uint8_t*)(cb + lane), nt_book);
+    book0_cnt |= (uint32_t)load_maybe_nt((const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane), nt_book) << 16;
     if (lane < 32) book0_w = tf1h[(lane < 16 ? 0u : 16u * G - 16u) + lane];
   } else if (n_stages == 0) {
     book_nxt = tf1_book(0);
@@ -891,13 +902,13 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   auto tf1_issue = [&](uint32_t j0, auto nrows_tag, auto r0_tag) {
     constexpr int N = decltype(nrows_tag)::value, R0 = decltype(r0_tag)::value;
     static_assert(N % 4 == 0 && R0 % 4 == 0, "a code dword covers four rows");
+    const bool nt_codes = (late_args().nt_mask & 4u) != 0;
     auto row = [&](int i) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + i);
       const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      // plain (cached) loads: the lines at the seams of two rows are wanted twice.  With the slots sorted by code count the rows
-      // of a wave are full for longer and this wins on both configurations (config 3 -0.7 %, config 5 -1.1 %); round 2's unsorted
-      // rows preferred non-temporal loads on config 3
-      const f32x2_t v = *(const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos);
+      // non-temporal: a seam line wanted by two rows is asked for twice (cached loads were 0.7 % ahead on that in round 3), but the
+      // rows are 1.3 GB a step that would sweep the Infinity Cache clean of what the kernel re-reads (see load_maybe_nt)
+      const f32x2_t v = __builtin_nontemporal_load((const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos));
       ab[R0 + i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
     };
@@ -910,7 +921,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         continue;
       }
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      code[R0 / 4 + q] = *(const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);  // idle lanes: some word behind the row ...
+      code[R0 / 4 + q] = load_maybe_nt((const M3_GLOBAL uint32_t*)(wbytes + 4u * pos), nt_codes);  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
       if (kTrim) {
 #pragma unroll
@@ -957,7 +968,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         asm volatile("" : "+v"(ll));
         uint32_t ev_lin = bd.first_event + (ll < bd.n_events ? ll : 0u);
         if (a.perm) ev_lin = a.perm[ev_lin];
-        t_pack = a.evw[ev_lin];
+        t_pack = load_maybe_nt(as_global(a.evw) + ev_lin, (a.nt_mask & 2u) != 0);
       } else {
         t_pack = a.evw[ev_own];
       }

@@ -122,6 +122,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   bh->groups = G;
   bh->first_event = e0;
   bh->words_off = words_all->size();
+  bh->bytes_tables = bh->bytes_book = bh->bytes_codes = 0;
   std::vector<uint32_t> w;  // this brick's stream
 
   // the per-event product must visit parameters in the event's own order; the brick regroups
@@ -341,6 +342,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
           w.push_back((lo < n_resp ? uint32_t(resp[lo]) : 0u) | (hi < n_resp ? uint32_t(resp[hi]) << 16 : 0u));
         }
     }
+    bh->bytes_tables += 4ull * (off_resp - off_runs);
     uint32_t* h = &w[size_t(M3_BRICK_HDR0) + size_t(M3_STAGE_HDR) * stage];
     h[0] = n_resp | (n_runs << 16) | (rows << 26);
     h[1] = off_runs;
@@ -403,6 +405,8 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   const uint32_t n_waves = n_blocks;  // wave-blocks
   const uint32_t n_slots = G * uint32_t(M3_GROUP);
   w.resize(w.size() + 2 * n_waves + size_t(n_slots) / 4 + size_t(n_slots) / 2, 0u);
+  bh->bytes_book = 4ull * (w.size() - off_tf1);
+  const size_t codes_from = w.size();
   for (uint32_t k = 0; k < n_slots; ++k) {
     const std::vector<uint8_t>* c = slot_codes(k);
     w[off_tf1 + 2 * n_waves + k / 4] |= uint32_t(c ? c->size() : 0) << (8 * (k % 4));
@@ -436,6 +440,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   bh->tf1_sorted = sort_slots;
   bh->n_tf1_f2 = tf1_f2;
   while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);  // the next brick's stream starts on a line
+  bh->bytes_codes = 4ull * (w.size() - codes_from);
   bh->n_words = w.size();
   words_all->insert(words_all->end(), w.begin(), w.end());
   return true;

@@ -98,6 +98,7 @@ struct BrickHost {
   // fill-time copy lists: source spline / TF1 index of every response, in store order
   std::vector<uint32_t> spl_src;   // per spline response (run-major): index into the chunk's spline arrays
   std::vector<uint32_t> tf1_src;   // per TF1 slot (wave-major, jagged rows inside); 0xFFFFFFFF: skip slot -> identity {0,1}
+  uint64_t bytes_tables = 0, bytes_book = 0, bytes_codes = 0;  // of the metadata stream: the stages' tables (run entries, pair words, counts), the TF1 bookkeeping, the TF1 codes
   uint32_t n_stages = 0;           // TSpline3 stages
   uint32_t groups = 1;             // G: the brick spans up to G x M3_GROUP events
   bool tf1_sorted = false;         // the TF1 lane-slots take the events in order of descending code count

@@ -454,6 +454,36 @@ def test_ragged_bricks_match_oracle(fresh_engine, monkeypatch, cfg, n_events, n_
 
 
 @pytest.mark.parametrize("groups", [1, 4])
+@pytest.mark.parametrize("mask", [0, 7, 4, 3])
+def test_streams_around_or_through_the_infinity_cache_give_the_same_numbers(fresh_engine, monkeypatch, mask, groups):
+    """Which of the brick kernel's small streams are loaded non-temporally (ReweightArgs::nt_mask: slab 0's TF1 bookkeeping, the
+    sample words, the TF1 codes; the engine chooses by their size, M3HIP_NT_MASK forces a choice) is a matter of speed only: event
+    weights bit-exact against the serial oracle, bins 1e-12, LLH 1e-9 for every choice."""
+    monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
+    monkeypatch.setenv("M3HIP_NT_MASK", str(mask))
+    n_events = 4096 + 1500
+    spec = synth.CONFIGS["c3"].scaled(n_events, n_params=128)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine)
+    assert eng.info().n_tiles_brick > 0 and eng.info().n_tiles_uniform == 0
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    for lap in (1, 2):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventWeights(0, n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+    osamp.close()
+    omono.close()
+
+
+@pytest.mark.parametrize("groups", [1, 4])
 @pytest.mark.parametrize("n_norm", [40, 300])
 def test_bricks_with_more_norm_parameters_than_the_packed_word_holds(fresh_engine, monkeypatch, groups, n_norm):
     """Up to six norm parameters per event: out of 40, the brick kernel takes an event's first three from its packed sample
