@@ -235,7 +235,7 @@ struct m3hip_ctx {
   int n_cu = 0;                   // compute units of the device
   ShortBrickPlan short_bricks;    // of the upload in progress
   uint64_t re_tables = 0, re_book = 0, re_codes = 0;  // bytes of the bricks' small re-read streams (stage tables, TF1 bookkeeping, TF1 codes)
-  int nt_force = -1;              // M3HIP_NT_MASK: ReweightArgs::nt_mask as given instead of the engine's choice (experiments)
+  int nt_force = -1;              // M3HIP_NT_MASK = 0 | 4: the TF1 codes cached / around the Infinity Cache instead of the engine's choice (experiments)
   double cached_mb = 200.0;       // M3HIP_CACHED_MB: what the engine plans to keep in the Infinity Cache from step to step
   uint64_t n_grouped_chunks = 0;
 
@@ -592,25 +592,22 @@ bool evw_fits(m3hip_handle h) {
   return ok && h->sw_packed != '0';
 }
 
-// Which of the brick kernel's small streams stay cached from step to step (ReweightArgs::nt_mask: a set bit = loaded non-temporally,
-// around the Infinity Cache).  The kernel's large streams -- coefficients, TF1 rows, response words -- never allocate there, so
-// what does is what a step re-reads: the stages' tables (always cached: a stage's idle waves re-read them), the sample words, slab
-// 0's TF1 bookkeeping and the TF1 codes, taken in that order while they fit the budget (200 MB of the 256: a table survives a
-// non-temporal stream up to about 192 MB, tools/mall_probe.hip).  Measured on config 3 (kernel, one box per line):
+// What stays in the Infinity Cache from step to step.  The brick kernel's large streams -- coefficients, TF1 rows, response
+// words -- are loaded non-temporally and never allocate there, so what does is what a step re-reads: the stages' tables (a
+// stage's idle waves re-read them), the sample words, slab 0's TF1 bookkeeping and the TF1 codes.  When all four fit the budget
+// (200 MB of the 256: a table survives a non-temporal stream up to about 192 MB, tools/mall_probe.hip) they all keep their cached
+// loads; when the first three fit and the codes -- the largest -- do not, the codes go around too (ReweightArgs::nt_codes: the
+// kernel's NTC instantiation); a sample so large that not even those three fit keeps everything cached (nothing would stay, and
+// cached loads at least share lines inside a step).  Measured on config 3 (kernel time, one box per group):
 // 1e7 events -- tables + sample words + bookkeeping cached (160 MB), codes (176 MB) around: 690.5 us; codes cached alone 695.0;
-// sample words + bookkeeping only 701; everything plain (round 3's way) 712; everything non-temporal 721.5.
-// 5e6 events -- all four cached (168 MB): 347.4; codes alone 354.4; everything plain 362.9.
-static uint32_t choose_nt_mask(m3hip_handle h, bool word_valid) {
-  if (h->nt_force >= 0) return uint32_t(h->nt_force) & 7u;
+// sample words + bookkeeping only 701; everything cached, large streams included (round 3's way) 712; everything around 721.5.
+// 5e6 events -- all four cached (168 MB): 341.0; codes alone 354.4; round 3's way 362.9.
+// M3HIP_NT_MASK = 0 | 4 forces the choice (experiments), M3HIP_CACHED_MB the budget.
+static uint32_t choose_nt_codes(m3hip_handle h, bool word_valid) {
+  if (h->nt_force >= 0) return (uint32_t(h->nt_force) & 4u) ? 1u : 0u;
   const double budget = h->cached_mb * 1e6;
-  const bool lin = h->brick_groups <= 1;  // bricks of 1024 events load the sample words in event order; larger ones gather them (cached)
-  const double evw = word_valid ? 8.0 * double(h->E) : 0.0;
-  double used = double(h->re_tables) + (lin ? 0.0 : evw);
-  uint32_t mask = 0;
-  if (lin && word_valid) { if (used + evw <= budget) used += evw; else mask |= 2u; }
-  if (used + double(h->re_book) <= budget) used += double(h->re_book); else mask |= 1u;
-  if (used + double(h->re_codes) <= budget) used += double(h->re_codes); else mask |= 4u;
-  return mask;
+  const double small3 = double(h->re_tables) + (word_valid ? 8.0 * double(h->E) : 0.0) + double(h->re_book);
+  return small3 <= budget && small3 + double(h->re_codes) > budget ? 1u : 0u;
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
@@ -2244,7 +2241,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.dyn.compute_nominal = 0;
   }
   if (h->oscw_valid && !h->f64) a.oscw = h->d_oscw;
-  a.nt_mask = choose_nt_mask(h, word_valid);
+  a.nt_codes = choose_nt_codes(h, word_valid);
   if (word_valid) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);

@@ -146,10 +146,9 @@ struct ReweightArgs {
   // bin + 1 in bits 0..19, osc + 1 in bits 20..43, up to three norm indices in bits 44..61 as 6-bit codes idx - evw_norm_base + 1
   // (0: none).  14 B -> 8 B per event; rebuilt on the device (k_pack_events) whenever one of the arrays changes.
   const uint64_t* evw;
-  // brick kernel: which of the small streams a step re-reads go AROUND the Infinity Cache (non-temporal loads): bit 0 slab 0's TF1
-  // bookkeeping, bit 1 the packed sample words (bricks of 1024 events: loaded in event order), bit 2 the TF1 codes.  The engine
-  // keeps as many of them cached as fit its budget (m3hip_api.hip: choose_nt_mask); the large streams are always non-temporal.
-  uint32_t nt_mask;
+  // brick kernel: 1 = the TF1 codes are loaded non-temporally, around the Infinity Cache -- the engine's choice when the small
+  // streams a step re-reads do not all fit its budget there (m3hip_api.hip: choose_nt_codes); the large streams always are
+  uint32_t nt_codes;
   int32_t evw_norm_base;
   uint32_t evw_norm_slots;  // norm slots held in the word (M3_EVW_NORM_SLOTS or 0); an event's further slots are read from nidx
   const double* params;      // [n_par + 1], last entry 1.0

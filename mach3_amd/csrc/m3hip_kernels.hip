@@ -604,13 +604,10 @@ __device__ __forceinline__ const M3_GLOBAL T* uniform_base(const M3_GLOBAL T* p)
 // Which of a brick's streams go around the Infinity Cache.  Non-temporal loads do not allocate in its 256 MB and a plain stream
 // evicts it (tools/mall_probe.hip), so the two large streams a step reads once besides the coefficients -- the TF1 rows (1.28 GB
 // per step of config 3) and the response words (350 MB) -- are loaded non-temporally like the coefficients, and the small ones a
-// step re-reads -- the stages' tables always (idle waves re-read them from L1), bookkeeping, sample words and TF1 codes as far
-// as the engine's budget goes (ReweightArgs::nt_mask) -- then stay there from step to step and come back in 545 instead of 900+
-// cycles, which is what a compute unit's outstanding misses turn into bandwidth (round 4, config 3: 712 -> 690 us).
-template <class T>
-__device__ __forceinline__ T load_maybe_nt(const M3_GLOBAL T* p, bool nt) {
-  return nt ? __builtin_nontemporal_load(p) : *p;
-}
+// step re-reads -- the stages' tables, the sample words, the TF1 bookkeeping, and the TF1 codes when they still fit the engine's
+// budget (template parameter NTC = they do not: m3hip_api.hip choose_nt_codes) -- then stay there from step to step and come back
+// in 545 instead of 900+ cycles, which is what a compute unit's outstanding misses turn into bandwidth (round 4, config 3:
+// 712 -> 682-690 us).  NTC is a template parameter: as a kernel argument with a branch per load it cost 1 %.
 struct RRun {      // per-step resolved run: quad address = base + r, dx of the run's parameter
   int32_t base;    // coef_off - start_r + seg * stride   (float4 units from the brick's store)
   float dx;
@@ -650,7 +647,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // separate instantiation, because a run-time branch around those loads would cost the common case its counted waits
 // PACK: the event's bin, oscillation index and norm indices come as one 8-byte word (ReweightArgs::evw) instead of from three
 // arrays; a template parameter, because both forms in one kernel cost the slabs' tails more registers than there are
-template <int MODE, bool NT, bool DYN = false, bool BIGP = false, int G = 1, bool PACK = false>
+template <int MODE, bool NT, bool DYN = false, bool BIGP = false, int G = 1, bool PACK = false, bool NTC = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
   __shared__ __attribute__((aligned(16))) float ell[M3_STAGE_CAP + kBrickEllSlack];  // compact scatter array: one slot per response of the stage
   __shared__ RRun lds_runs[2 * kBrickRunSlots];   // resolved run tables of two stages
@@ -773,9 +770,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t book0_cnt = 0, book0_w = 0;
   if (kBookLds) {
     const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));
-    const bool nt_book = (a.nt_mask & 1u) != 0;  // (kernel-uniform; the prologue's waits are for everything)
-    book0_cnt = load_maybe_nt((const M3_GLOBAL uint8_t*)(cb + lane), nt_book);
-    book0_cnt |= (uint32_t)load_maybe_nt((const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane), nt_book) << 16;
+    book0_cnt = *(const M3_GLOBAL uint8_t*)(cb + lane);
+    book0_cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane)) << 16;
     if (lane < 32) book0_w = tf1h[(lane < 16 ? 0u : 16u * G - 16u) + lane];
   } else if (n_stages == 0) {
     book_nxt = tf1_book(0);
@@ -902,12 +898,11 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   auto tf1_issue = [&](uint32_t j0, auto nrows_tag, auto r0_tag) {
     constexpr int N = decltype(nrows_tag)::value, R0 = decltype(r0_tag)::value;
     static_assert(N % 4 == 0 && R0 % 4 == 0, "a code dword covers four rows");
-    const bool nt_codes = (late_args().nt_mask & 4u) != 0;
     auto row = [&](int i) {
       const unsigned long long act = __ballot(tf1_cnt > j0 + i);
       const uint32_t pos = tf1_cbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
       // non-temporal: a seam line wanted by two rows is asked for twice (cached loads were 0.7 % ahead on that in round 3), but the
-      // rows are 1.3 GB a step that would sweep the Infinity Cache clean of what the kernel re-reads (see load_maybe_nt)
+      // rows are 1.3 GB a step that would sweep the Infinity Cache clean of what the kernel re-reads (see the note above RRun)
       const f32x2_t v = __builtin_nontemporal_load((const M3_GLOBAL f32x2_t*)(tf1_bytes + 8u * pos));
       ab[R0 + i] = make_float2(v.x, v.y);
       tf1_cbase += (uint32_t)__popcll(act);
@@ -921,7 +916,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         continue;
       }
       const uint32_t pos = tf1_dbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-      code[R0 / 4 + q] = load_maybe_nt((const M3_GLOBAL uint32_t*)(wbytes + 4u * pos), nt_codes);  // idle lanes: some word behind the row ...
+      const M3_GLOBAL uint32_t* cp = (const M3_GLOBAL uint32_t*)(wbytes + 4u * pos);
+      code[R0 / 4 + q] = NTC ? __builtin_nontemporal_load(cp) : *cp;  // idle lanes: some word behind the row ...
       tf1_dbase += (uint32_t)__popcll(act);
       if (kTrim) {
 #pragma unroll
@@ -968,7 +964,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         asm volatile("" : "+v"(ll));
         uint32_t ev_lin = bd.first_event + (ll < bd.n_events ? ll : 0u);
         if (a.perm) ev_lin = a.perm[ev_lin];
-        t_pack = load_maybe_nt(as_global(a.evw) + ev_lin, (a.nt_mask & 2u) != 0);
+        t_pack = a.evw[ev_lin];
       } else {
         t_pack = a.evw[ev_own];
       }
@@ -1329,10 +1325,12 @@ static void launch_brick_g(const ReweightArgs& a, dim3 g, size_t lds, const Rewe
     // registers (no scratch; G = 4: 53 spilled); every other shape is re-binned by a pass of its own (m3hip_api.hip)
     static_assert(G == 1 && kSampleSide, "the fused re-binning exists for bricks of 1024 events with the packed sample word");
     if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, true, 1, true>), g, b, lds, s, k, a);
+    else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true, true>), g, b, lds, s, k, a);
     else M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true>), g, b, lds, s, k, a);
   } else {
     if (kSampleSide && a.evw) {
       if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, false, true, G, kSampleSide>), g, b, lds, s, k, a);
+      else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G, kSampleSide, true>), g, b, lds, s, k, a);
       else M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G, kSampleSide>), g, b, lds, s, k, a);
       return;
     }
