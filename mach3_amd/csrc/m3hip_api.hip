@@ -596,9 +596,10 @@ bool evw_fits(m3hip_handle h) {
 // words -- are loaded non-temporally and never allocate there, so what does is what a step re-reads: the stages' tables (a
 // stage's idle waves re-read them), the sample words, slab 0's TF1 bookkeeping and the TF1 codes.  When all four fit the budget
 // (200 MB of the 256: a table survives a non-temporal stream up to about 192 MB, tools/mall_probe.hip) they all keep their cached
-// loads; when the first three fit and the codes -- the largest -- do not, the codes go around too (ReweightArgs::nt_codes: the
-// kernel's NTC instantiation); a sample so large that not even those three fit keeps everything cached (nothing would stay, and
-// cached loads at least share lines inside a step).  Measured on config 3 (kernel time, one box per group):
+// loads; when they do not, the codes -- the largest -- go around too (ReweightArgs::nt_codes: the kernel's NTC instantiation),
+// unless the other three alone are beyond twice the budget: such a sample keeps everything cached (nothing would stay, and cached
+// loads at least share lines inside a step).  Measured (kernel time, one box per group) on one GPU's share of config 5 (the three
+// are 200.5 MB, the codes 125 MB): codes around 459.6 us, cached 474.0; on config 3:
 // 1e7 events -- tables + sample words + bookkeeping cached (160 MB), codes (176 MB) around: 690.5 us; codes cached alone 695.0;
 // sample words + bookkeeping only 701; everything cached, large streams included (round 3's way) 712; everything around 721.5.
 // 5e6 events -- all four cached (168 MB): 341.0; codes alone 354.4; round 3's way 362.9.
@@ -607,7 +608,7 @@ static uint32_t choose_nt_codes(m3hip_handle h, bool word_valid) {
   if (h->nt_force >= 0) return (uint32_t(h->nt_force) & 4u) ? 1u : 0u;
   const double budget = h->cached_mb * 1e6;
   const double small3 = double(h->re_tables) + (word_valid ? 8.0 * double(h->E) : 0.0) + double(h->re_book);
-  return small3 <= budget && small3 + double(h->re_codes) > budget ? 1u : 0u;
+  return small3 <= 2.0 * budget && small3 + double(h->re_codes) > budget ? 1u : 0u;
 }
 
 ReweightArgs make_rw_args(m3hip_handle h) {
