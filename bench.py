@@ -389,6 +389,7 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     k_ms, k_n = eng.timing_read(0)
+    info = eng.info()  # (again: with what the reweights planned for the Infinity Cache)
     gap_ms, gap_n = eng.timing_read(2) if in_library else (0.0, 0)
     eng.timing_enable(False)
     k_all = [k_ms]
@@ -651,6 +652,10 @@ def main():
                 "comm": m["comm"],
                 "last_llh": m["llh"],
                 "brick_events": 1024 * int(m["info"].brick_groups or 1),
+                # rank 0's brick kernel: MB of the small streams a step re-reads that the engine keeps cached, to find them in the
+                # 256 MB Infinity Cache again next step, and whether the TF1 codes had to go around it
+                "infinity_cache": {"cached_small_streams_MB": round(int(m["info"].cached_stream_bytes) / 1e6, 1),
+                                   "tf1_codes_around": bool(m["info"].tf1_codes_around)},
             },
             "roofline": roofline(base.name, m, per_gpu),
         }

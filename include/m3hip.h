@@ -401,6 +401,10 @@ typedef struct {
   uint64_t n_grouped_chunks; /* upload chunks whose events the engine grouped by parameter list (processing order only:
                               * every per-event array and result keeps the caller's event order) */
   uint64_t brick_groups;     /* G: a brick holds up to G x 1024 events (1, 2 or 4; 0 before the first chunk) */
+  uint64_t cached_stream_bytes; /* brick kernel, as of the last fused reweight: bytes of the small streams a step re-reads that keep
+                                 * cached loads, i.e. that the engine plans to find in the Infinity Cache again next step (stage
+                                 * tables, sample words, TF1 bookkeeping, and the TF1 codes unless tf1_codes_around) */
+  uint64_t tf1_codes_around;    /* 1: the TF1 codes are loaded non-temporally, around the Infinity Cache (they did not fit beside the others) */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

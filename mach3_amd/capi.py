@@ -56,6 +56,7 @@ class Info(C.Structure):
         ("coeff_bytes", C.c_uint64), ("alg_bytes_eval", C.c_uint64), ("alg_bytes_fused", C.c_uint64),
         ("n_params", C.c_int), ("max_knots", C.c_int), ("n_bins", C.c_int), ("n_samples", C.c_int),
         ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64), ("brick_groups", C.c_uint64),
+        ("cached_stream_bytes", C.c_uint64), ("tf1_codes_around", C.c_uint64),
     ]
 
 

@@ -235,6 +235,7 @@ struct m3hip_ctx {
   int n_cu = 0;                   // compute units of the device
   ShortBrickPlan short_bricks;    // of the upload in progress
   uint64_t re_tables = 0, re_book = 0, re_codes = 0;  // bytes of the bricks' small re-read streams (stage tables, TF1 bookkeeping, TF1 codes)
+  uint64_t last_cached_bytes = 0, last_nt_codes = 0;  // what the last fused reweight planned (m3hip_get_info)
   int nt_force = -1;              // M3HIP_NT_MASK = 0 | 4: the TF1 codes cached / around the Infinity Cache instead of the engine's choice (experiments)
   double cached_mb = 200.0;       // M3HIP_CACHED_MB: what the engine plans to keep in the Infinity Cache from step to step
   uint64_t n_grouped_chunks = 0;
@@ -2243,6 +2244,8 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   }
   if (h->oscw_valid && !h->f64) a.oscw = h->d_oscw;
   a.nt_codes = choose_nt_codes(h, word_valid);
+  h->last_nt_codes = a.nt_codes;
+  h->last_cached_bytes = h->h_bricks.empty() ? 0 : h->re_tables + (word_valid ? 8 * h->E : 0) + h->re_book + (a.nt_codes ? 0 : h->re_codes);
   if (word_valid) {
     a.evw = h->d_evw;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);
@@ -2867,6 +2870,8 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) try {
   out->pad_responses = h->pad_responses;
   out->n_grouped_chunks = h->n_grouped_chunks;
   out->brick_groups = uint64_t(h->brick_groups);
+  out->cached_stream_bytes = h->last_cached_bytes;
+  out->tf1_codes_around = h->last_nt_codes;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

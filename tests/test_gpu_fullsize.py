@@ -108,6 +108,7 @@ def _check_full_size(spec, e0, e1, windows, chunk_events=131072, laps=(1, 2), sh
     for omono, osamp, *_ in oracles:
         osamp.close()
         omono.close()
+    info = eng.info()  # (again: with what the reweights planned)
     eng.close()
     if shard_check:  # two ranks' worth of events on two handles: what the all-reduce would sum
         cut = e0 + ((E // 2 + 1023) // 1024) * 1024
@@ -131,6 +132,9 @@ def test_config3_full_size_properties():
     info = _check_full_size(spec, 0, E, [(0, 2500), (5_000_000, 5_002_048), (E - 3000, E)])
     assert info.brick_groups == 1 and info.n_tiles_brick == (E + 1023) // 1024 and info.n_tiles_uniform == 0
     assert info.n_splines * spec.n_knots * 4 > 2 ** 32
+    # the small streams a step re-reads: stage tables + sample words + TF1 bookkeeping stay in the Infinity Cache (about 165 MB),
+    # the TF1 codes (176 MB more) do not fit beside them and go around it (m3hip_api.hip choose_nt_codes)
+    assert info.tf1_codes_around == 1 and 150e6 < info.cached_stream_bytes < 200e6
 
 
 def test_config4_shard_properties():

@@ -479,6 +479,8 @@ def test_streams_around_or_through_the_infinity_cache_give_the_same_numbers(fres
         assert np.array_equal(sh.GetEventWeights(0, n_events).view(np.uint32), osamp.event_weights().view(np.uint32))
         assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
         _llh_close(llh, osamp.get_likelihood())
+    info = eng.info()
+    assert info.tf1_codes_around == (1 if mask == 4 else 0) and 0 < info.cached_stream_bytes < 10_000_000
     osamp.close()
     omono.close()
 
