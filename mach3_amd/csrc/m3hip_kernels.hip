@@ -760,10 +760,9 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     b.dbase = __builtin_amdgcn_readfirstlane(tf1h[16u * G + 16u * h + wave]);
     return b;
   };
-  // G = 1 requests slab 0's bookkeeping here; with more slabs per lane the stage loop has no register for it (one more
-  // product per slab is live there: a spill, and a kernel that uses scratch at all dispatches measurably slower), so it is
-  // requested at the top of the last stage instead
   Tf1Book book_nxt = {0u, 0u, 0u};
+  // (a constant since round 4's last kernel step -- every G has the register now; the other path is kept as written because
+  // removing it perturbs the G = 4 instantiations' register allocation, which could not be re-measured)
   constexpr bool kBookLds = true;
   // slab 0's bookkeeping comes in with the prologue's round trip and waits in LDS for the last stage: requested there (as
   // slabs h > 0 still are) it put a round trip of its own in front of the first TF1 rows
