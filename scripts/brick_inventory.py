@@ -36,13 +36,15 @@ for b in range(nb):
         h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
         n_resp, n_runs = h0 & 0xFFFF, (h0 >> 16) & 0x3FF
         runs = w[off_runs: off_runs + 2 * n_runs].reshape(-1, 2)
-        resp = np.zeros(n_resp, np.uint16)
-        for k in range((n_resp + 2047) // 2048):
-            ln = min(1024, n_resp - 2048 * k)
-            blk = w[off_resp + 1024 * k: off_resp + 1024 * k + ln]
-            resp[2048 * k: 2048 * k + ln] = blk & 0xFFFF
-            hi = min(ln, max(0, n_resp - 2048 * k - 1024))
-            resp[2048 * k + 1024: 2048 * k + 1024 + hi] = blk[:hi] >> 16
+        resp = np.zeros(n_resp, np.uint16)   # per-lane records of nd dwords, two words per dword (m3hip_layout.h: stage_word_dwords)
+        nd, lanes = ((n_resp + 1023) // 1024 + 1) // 2, min(1024, n_resp)
+        rec = w[off_resp: off_resp + nd * lanes].reshape(lanes, nd)
+        for k in range(nd):
+            lo = 2048 * k
+            n_lo = max(0, min(lanes, n_resp - lo))
+            resp[lo: lo + n_lo] = rec[:n_lo, k] & 0xFFFF
+            n_hi = max(0, min(lanes, n_resp - lo - 1024))
+            resp[lo + 1024: lo + 1024 + n_hi] = rec[:n_hi, k] >> 16
         ends = np.flatnonzero(resp & 1) + 1
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
@@ -52,7 +54,7 @@ for b in range(nb):
             tot["quads_used"] += 16 * int(((resp[first_r[rn]: ends[rn]] >> 2) < 5120).sum())
             for L in range((16 * q0) // 128, (16 * (q0 + n) - 1) // 128 + 1):
                 lines.add(L)
-        tot["resp_words"] += 4 * ((n_resp + 1) // 2)
+        tot["resp_words"] += 4 * nd * lanes
         tot["run_tab"] += 8 * n_runs
         tot["pair_tab"] += 4 * (5120 // 64)
         tot["stage_counts"] += 512 * G
