@@ -1107,6 +1107,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
       M3_HOLLOW_USE4(cu);
       M3_HOLLOW_USE1(du);
       (void)n_resp;
+      (void)word;
 #else
       if (lane + u * kBrickThreads < n_resp)
         *(float*)((char*)ell + (word(m_cur, u) & 0x7FFCu)) = spline_poly(dx[u], c[u]);
