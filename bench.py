@@ -27,7 +27,8 @@ Prints ONE JSON line on rank 0 (contract in the task description), carrying `roo
 reweight kernel: algorithmic bytes / dispatch-stamped launch time vs 8 TB/s; traffic from the committed
 PMC passes), at N = 1 `cpu_baseline` (the OpenMP oracle port timed on this host on a bounded sample of
 the same configuration, arrays first-touched inside OpenMP loops, best of a thread sweep) and `extra`
-(the configs[1] line of round 1, measured the same way).
+(the configs[1] line of round 1, measured the same way).  `config.infinity_cache` says what rank 0's brick kernel keeps in the
+256 MB Infinity Cache from step to step (m3hip_info::cached_stream_bytes, tf1_codes_around; DESIGN.md section 3).
 """
 import argparse
 import json
