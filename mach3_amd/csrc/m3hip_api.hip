@@ -549,6 +549,7 @@ void free_monolith(m3hip_handle h) {
   h->max_osc_idx = h->max_norm_idx = h->max_parmap = h->max_bin_idx = -1;
   h->E = h->S = h->T = h->coeff_bytes = h->E_pad = 0;
   h->re_tables = h->re_book = h->re_codes = 0;
+  h->last_cached_bytes = h->last_nt_codes = 0;
   h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
   h->parmap_set = false;
@@ -2798,7 +2799,7 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
   { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
-  // M3HIP_DEBUG_SHORT_FROM: the event from which on bricks are cut short (tests/test_layout.py; an engine gets it from short_bricks_from)
+  // M3HIP_DEBUG_SHORT_FROM / _TO: the stretch of events whose bricks are cut short (tests/test_layout.py; an engine gets them from its ShortBrickPlan)
   uint64_t short_from = ~0ull, short_to = ~0ull;
   if (const char* f = getenv("M3HIP_DEBUG_SHORT_FROM")) if (f[0]) short_from = strtoull(f, nullptr, 10);
   if (const char* f = getenv("M3HIP_DEBUG_SHORT_TO")) if (f[0]) short_to = strtoull(f, nullptr, 10);
