@@ -15,19 +15,22 @@ A step = one pass of the hot path over one batch of synthetic MC:
 (the pair MR2T2::ProposeStep runs per proposal, ref: Fitters/MR2T2.cpp:66-76), timed
 DragRace-style (ref: Fitters/FitterBase.cpp:461-489).
 
-Workload.  N = 1: BASELINE.json configs[2] ("c3": 1e7 events, 512 mixed TSpline3/TF1 systematics at
+Workload.  EVERY N runs BASELINE.json configs[2] ("c3": 1e7 events, 512 mixed TSpline3/TF1 systematics at
 occupancy 1/16, 200 bins, Barlow-Beeston) -- the largest configuration BASELINE sizes for one GPU and
-the one north_star's targets are stated on.  N > 1: ONE sample of fixed size sharded over the ranks
-by events (strong scaling): configs[2] for N <= 2, configs[3] ("c4": 4 samples x 1e7 events) for
-N = 4 and 8, as north_star plans them; shard boundaries balance the responses per rank
-(mach3_amd/dist.py).  Every step ends in ONE in-library RCCL all-reduce of the bin vector.
-value = K / t: LLH evaluations (MCMC steps) per second of the whole sample.  `--config` overrides.
+the one north_star states its 1-GPU and its 8-GPU target on.  N > 1: that ONE sample sharded over the ranks
+by events (strong scaling: `value` at N = 1 is the one-GPU line, and value(N) / value(1) is the curve);
+shard boundaries balance the responses per rank (mach3_amd/dist.py).  Every step ends in ONE in-library RCCL
+all-reduce of the bin vector.  value = K / t: LLH evaluations (MCMC steps) per second of the whole sample.
+N >= 4 additionally measures configs[3] ("c4": 4 samples x 1e7 events, 800 bins -- BASELINE sizes it for eight GPUs)
+the same way, AFTER the headline numbers are in hand and behind a watchdog, under `extra.configs[3]` (its own
+ms_per_step, roofline and event_steps_per_s).  `--config` overrides the headline workload.
 
 Prints ONE JSON line on rank 0 (contract in the task description), carrying `roofline` (fused
 reweight kernel: algorithmic bytes / dispatch-stamped launch time vs 8 TB/s; traffic from the committed
 PMC passes), at N = 1 `cpu_baseline` (the OpenMP oracle port timed on this host on a bounded sample of
 the same configuration, arrays first-touched inside OpenMP loops, best of a thread sweep) and `extra`
-(the configs[1] line of round 1, measured the same way).  `config.infinity_cache` says what rank 0's brick kernel keeps in the
+(the configs[1] line of round 1, measured the same way).  Nothing under `extra` can cost a run its line: a leg that does not
+return within its limit is reported as text in its place; `--strict` turns such a leg (or a failed one) into exit code 6.  `config.infinity_cache` says what rank 0's brick kernel keeps in the
 256 MB Infinity Cache from step to step (m3hip_info::cached_stream_bytes, tf1_codes_around; DESIGN.md section 3).
 """
 import argparse
@@ -246,7 +249,7 @@ def shard_of(spec, rank, n_ranks, tdist=None):
     return dist.shard_ranges(spec.n_events, n_ranks, weights=w)[rank]
 
 
-def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
+def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback, oneshot=True):
     """Build this rank's shard, run warm-up + the timed steps, return the numbers of the JSON line."""
     from mach3_amd import synth
     from mach3_amd.engine import build_from_synth
@@ -417,7 +420,7 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback):
     # the one-shot leg runs AFTER the caller has the line's numbers in hand (main() guards it with a watchdog: nothing that
     # happens in an `extra` may cost the run its line)
     after = None
-    if in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
+    if oneshot and in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
         after = lambda: oneshot_leg(eng, step, rank, n_ranks, dist, torch, args)  # noqa: E731
     out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=None,
                comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all, after=after, close=eng.close)
@@ -558,7 +561,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="auto", help="c1..c5; auto = c3 for 1-2 GPUs, c4 for 4 and 8 (BASELINE configs[2] / [3])")
+    ap.add_argument("--config", default="auto", help="c1..c5; auto = c3 (BASELINE configs[2]) for every N, with configs[3] under `extra` from 4 GPUs on")
+    ap.add_argument("--no-c4-extra", action="store_true", help="N >= 4: skip the configs[3] leg under `extra`")
+    ap.add_argument("--strict", action="store_true", help="exit with code 6 when a leg under `extra` failed or was abandoned (the line is printed either way)")
     ap.add_argument("--events", type=int, default=0, help="override the TOTAL number of events (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] line under `extra`")
@@ -602,7 +607,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    cfg = args.config if args.config != "auto" else ("c3" if n_gpus <= 2 else "c4")
+    cfg = args.config if args.config != "auto" else "c3"  # ONE workload for the whole --gpus series
     base = synth.CONFIGS[cfg]
     spec = base.scaled(args.events) if args.events else base
 
@@ -626,6 +631,7 @@ def main():
         dist.barrier()
 
     out = None
+    failed_extras = []  # legs under `extra` that failed or were abandoned (the line says so: `extra_failed`)
     if rank == 0:
         per_gpu = m["e1"] - m["e0"]
         out = {
@@ -645,8 +651,7 @@ def main():
                 "workload": workload_text(base, spec, n_gpus),
                 "total_events": spec.n_events,
                 "ranks_seen": ranks_seen,
-                # the job's work rate, comparable across the two workloads the N-series uses (N <= 2: configs[2], 1e7
-                # events; N = 4, 8: configs[3], 4e7 events): scaling efficiency across that switch is the ratio of THESE
+                # the job's work rate in events x steps per second (comparable with `extra.configs[3]`, four times the events)
                 "event_steps_per_s": spec.n_events * args.steps / m["el"],
                 "events_per_gpu": per_gpu,
                 "responses_rank0": int(m["info"].n_splines + m["info"].n_tf1),
@@ -660,8 +665,6 @@ def main():
             },
             "roofline": roofline(base.name, m, per_gpu),
         }
-        if m.get("after") is not None:
-            out.setdefault("extra", {})["oneshot_exchange"] = None  # filled in below
         if m["comm_val"] is not None:
             # self-validation of the exchange on the untimed steps (every rank; the worst bin of the worst rank), the time the
             # exchange adds between the reweight kernel's end and the bin likelihood's start, and every rank's kernel time
@@ -690,38 +693,67 @@ def main():
                                                "ms_per_step": 1e3 * m2["el"] / args.steps, "roofline": roofline("c2", m2, c2.n_events)}
             except Exception as e:
                 out.setdefault("extra", {})["configs[1]"] = {"failed": str(e)}
-    if m.get("after") is not None:
-        # every rank runs the leg (its steps are collectives); a rank whose leg does not return within the limit prints the
-        # line without it (rank 0) and leaves -- a hung `extra` must not cost the run its line
-        import threading
-        limit = float(os.environ.get("M3_BENCH_ONESHOT_LIMIT_S", "180"))
+                failed_extras.append("configs[1]")
+    # ---- legs under `extra` that are collectives (every rank runs them): the one-shot exchange beside RCCL, and from four
+    # GPUs on BASELINE configs[3].  The headline numbers are in hand; each leg runs behind a watchdog, and a leg that does not
+    # return within its limit is reported as text in its place -- rank 0 prints the line as it stands and every rank leaves.
+    import threading
 
+    def run_leg(name, limit, fn):
         def give_up():
             if rank == 0:
-                out["extra"]["oneshot_exchange"] = {"error": f"did not finish within {limit:.0f} s; abandoned (the line above it stands)"}
+                out.setdefault("extra", {})[name] = {"error": f"did not finish within {limit:.0f} s; abandoned (the line above it stands)"}
                 print(json.dumps(out), file=json_out, flush=True)
-            log(f"[bench] rank {rank}: the one-shot leg did not return within {limit:.0f} s; leaving without it")
-            os._exit(0 if check is None or check["ok"] else 4)
+            log(f"[bench] rank {rank}: `extra.{name}` did not return within {limit:.0f} s; leaving without it")
+            os._exit(4 if check is not None and not check["ok"] else (6 if args.strict else 0))
         wd = threading.Timer(limit, give_up)
         wd.daemon = True
         wd.start()
         try:
-            res = m["after"]()
-        except Exception as e:  # (the leg reports its own failures as text; this is the belt to those braces)
-            res = {"error": f"rank {rank}: {e}"}
+            res = fn()
+        except BaseException as e:  # (the legs report their own failures as text; this is the belt to those braces)
+            res = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
         wd.cancel()
+        if isinstance(res, dict) and ("error" in res or "failed" in res or res.get("ok") is False):
+            failed_extras.append(name)
         if rank == 0:
-            out["extra"]["oneshot_exchange"] = res
+            out.setdefault("extra", {})[name] = res
+        return res
+
+    if m.get("after") is not None:
+        run_leg("oneshot_exchange", float(os.environ.get("M3_BENCH_ONESHOT_LIMIT_S", "180")), m["after"])
         try:
             m["close"]()
         except Exception:
             pass
+    if n_gpus >= 4 and args.config == "auto" and not args.no_c4_extra:
+        def c4_leg():
+            a4 = argparse.Namespace(**vars(args))
+            a4.check = False
+            a4.spinup_seconds = min(args.spinup_seconds, 0.5)
+            c4 = synth.CONFIGS["c4"]
+            spec4 = c4.scaled(4 * args.events) if args.events else c4  # (a reduced --events keeps the 1 : 4 ratio of the two)
+            m4 = measure(spec4, rank, n_gpus, local_rank, a4, dist, torch, args.allow_host_fallback, oneshot=False)
+            per4 = m4["e1"] - m4["e0"]
+            res = {"workload": workload_text(c4, spec4, n_gpus), "value": args.steps / m4["el"], "unit": "steps/s", "ms_per_step": 1e3 * m4["el"] / args.steps,
+                   "event_steps_per_s": spec4.n_events * args.steps / m4["el"], "events_per_gpu": per4, "comm": m4["comm"], "comm_us": m4["comm_us"],
+                   "roofline": roofline("c4", m4, per4)}
+            if m4["comm_val"] is not None:
+                res["comm_validated_steps"], res["comm_max_rel"] = m4["comm_val"]["validated_steps"], m4["comm_val"]["max_rel"]
+            if len(m4["k_all"]) > 1:
+                res["roofline"]["avg_kernel_ms_by_rank"] = {"min": min(m4["k_all"]), "max": max(m4["k_all"])}
+            return res
+        run_leg("configs[3]", float(os.environ.get("M3_BENCH_C4_LIMIT_S", "420")), c4_leg)
     if rank == 0:
+        if failed_extras:
+            out["extra_failed"] = failed_extras
         print(json.dumps(out), file=json_out, flush=True)
         if check is not None and not check["ok"]:
             raise SystemExit(4)
     if dist is not None:
         dist.destroy_process_group()
+    if failed_extras and args.strict:
+        raise SystemExit(6)
 
 
 if __name__ == "__main__":

@@ -57,6 +57,9 @@ int m3hip_destroy(m3hip_handle h);
 const char* m3hip_last_error(m3hip_handle h);
 /* run on a caller-owned hipStream_t instead of the handle's own stream (NULL restores it) */
 int m3hip_set_stream(m3hip_handle h, void* hip_stream);
+/* number of usable HIP devices (no handle needed).  Replaces the cudaGetDeviceCount of PrintNdevices / SetDevice
+ * (Manager/gpuUtils.cu:60-72, 85-100); one process per GPU picks device = local rank % count. */
+int m3hip_device_count(int* out);
 /* device memory in use / total, bytes.  Replaces checkGpuMem (Manager/gpuUtils.cu:40-56) */
 int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes);
 
@@ -353,7 +356,11 @@ int m3hip_comm_set_validate(m3hip_handle h, int on);
  *   m3hip_xch_create  after the bin space is defined; allocates this rank's buffer, returns its IPC handle
  *   m3hip_xch_open    handles of all ranks in rank order (this rank's own entry is ignored); from here on
  *                     m3hip_reweight / m3hip_step exchange through the buffers instead of RCCL
- *   m3hip_xch_set_timeout  how long a rank waits for its peers' vectors of a step (default 2 s; also M3HIP_XCH_TIMEOUT_S
+ *                     Ranks that live in the SAME process (one process driving several engines) are recognised by their
+ *                     handles and wired up directly; such a process must issue m3hip_reweight for all of its ranks before it
+ *                     waits for the likelihood of any (the step is a collective).
+ *   m3hip_xch_set_timeout  how long a rank waits for its peers' vectors of a step (default 2 s, at most 50 s -- the spin runs on
+ *                     the device, and the host-side waits around it give up after 60 s; also M3HIP_XCH_TIMEOUT_S
  *                     in the environment of m3hip_xch_create).  Choose it above the largest host-side skew between two
  *                     ranks of one step (chain output, checkpoints, a new throw matrix).
  * A peer that does not push in time (a dead rank) is reported as M3HIP_ECOMM by whichever call reads the step's bins next
@@ -371,6 +378,9 @@ int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n
 /* ------------------------------------------------------------------------------------
  * The parameter handler's O(nPar^2) work of a Metropolis step, on the device (the callers of the hot
  * path; at the 1 040 parameters of BASELINE configs[4] these sweeps take longer on one host core than the GPU's step).
+ *   m3hip_par_create             a context for ONE parameter handler (its matrices, its results, its ticket); a fit with several
+ *                                handlers on one engine (MCMCBase loops over all systematics objects, Fitters/MCMCBase.cpp:32-77)
+ *                                creates one each.  Up to M3HIP_MAX_PAR_SLOTS; m3hip_par_destroy gives a slot back.
  *   m3hip_par_upload(which = 0)  InvCovMatrix, nPar x nPar row-major (lower triangle read)
  *   m3hip_par_upload(which = 1)  the lower Cholesky factor of the throw matrix (ParameterHandlerBase::SetThrowMatrix,
  *                                Parameters/ParameterHandlerBase.cpp:1140-1200); again whenever the adaptive proposal replaces it
@@ -379,12 +389,16 @@ int m3hip_comm_last_validation(m3hip_handle h, double* max_rel_diff, uint64_t* n
  *                                flat) and the correlated throw L z of CorrelateSteps (:726-745, M3::MatrixVectorMulti,
  *                                Parameters/ParameterHandlerUtils.h:118-135; z = the random vector of Randomize, :690-707, drawn
  *                                on the host).  Runs on a stream of its own beside the step's reweight kernel.
- *   m3hip_par_result             waits for the last launch; prior and corr_throw[nPar].  Fixed summation order: reproducible,
- *                                equal to the host loops up to fp64 rounding.
- * include/mach3_amd/Fitters.h: ParameterHandlerBase::AttachDevice uses these. */
-int m3hip_par_upload(m3hip_handle h, int which, const double* matrix, int n);
-int m3hip_par_launch(m3hip_handle h, const double* d, const double* z, int n);
-int m3hip_par_result(m3hip_handle h, double* prior, double* corr_throw, int n);
+ *   m3hip_par_result             waits for the slot's last launch; prior and corr_throw[nPar].  Fixed summation order:
+ *                                reproducible, equal to the host loops up to fp64 rounding.
+ * Slots are independent: launches of different slots may be in flight together, and a slot's results stay until ITS next launch.
+ * include/mach3_amd/Fitters.h: ParameterHandlerBase::AttachDevice uses these (one slot per attached handler). */
+#define M3HIP_MAX_PAR_SLOTS 16
+int m3hip_par_create(m3hip_handle h, int* slot_out);
+int m3hip_par_destroy(m3hip_handle h, int slot);
+int m3hip_par_upload(m3hip_handle h, int slot, int which, const double* matrix, int n);
+int m3hip_par_launch(m3hip_handle h, int slot, const double* d, const double* z, int n);
+int m3hip_par_result(m3hip_handle h, int slot, double* prior, double* corr_throw, int n);
 
 /* ------------------------------------------------------------------------------------
  * Introspection / measurement

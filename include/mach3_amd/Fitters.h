@@ -139,11 +139,27 @@ class ParameterHandlerBase {
   /// The host keeps the random numbers (Randomize, :690-707), the bounds, the special proposals and the Haario update.
   /// At the 1 040 parameters of BASELINE configs[4] the sweeps take 0.4 ms on one host core and a few microseconds there.
   /// Same numbers up to fp64 rounding (fixed summation order on the device; tests/test_cpp_facade.py).
+  /// Every attached handler owns a context of its own on the engine (m3hip_par_create): several handlers of one fit -- MCMCBase
+  /// loops over all systematics objects -- may share an engine, with equal or different numbers of parameters.
   void AttachDevice(m3hip_handle h) {
     if (!h) throw MaCh3Exception(__FILE__, __LINE__, "AttachDevice: null engine handle");
-    if (m3hip_par_upload(h, 0, InvertCovMatrix.data(), _fNumPar) != M3HIP_OK || m3hip_par_upload(h, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
-      throw MaCh3Exception(__FILE__, __LINE__, std::string("AttachDevice: ") + m3hip_last_error(h));
+    DetachDevice();
+    int slot = -1;
+    if (m3hip_par_create(h, &slot) != M3HIP_OK) throw MaCh3Exception(__FILE__, __LINE__, std::string("AttachDevice: ") + m3hip_last_error(h));
+    if (m3hip_par_upload(h, slot, 0, InvertCovMatrix.data(), _fNumPar) != M3HIP_OK ||
+        m3hip_par_upload(h, slot, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK) {
+      const std::string why = m3hip_last_error(h);
+      m3hip_par_destroy(h, slot);
+      throw MaCh3Exception(__FILE__, __LINE__, "AttachDevice: " + why);
+    }
     dev = h;
+    dev_slot = slot;
+  }
+  /// back to the host loops (call before the engine behind the handle is destroyed)
+  void DetachDevice() {
+    if (dev) m3hip_par_destroy(dev, dev_slot);
+    dev = nullptr;
+    dev_slot = -1;
   }
   bool OnDevice() const { return dev != nullptr; }
   /// enqueue (nothing waits): the prior of the CURRENT proposal and the correlated throw of the NEXT one
@@ -155,7 +171,7 @@ class ParameterHandlerBase {
       for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
       throw_drawn = true;
     }
-    if (m3hip_par_launch(dev, d.data(), randParams.data(), _fNumPar) != M3HIP_OK)
+    if (m3hip_par_launch(dev, dev_slot, d.data(), randParams.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("LaunchDeviceStep: ") + m3hip_last_error(dev));
     launched_epoch = throw_epoch;
   }
@@ -165,7 +181,7 @@ class ParameterHandlerBase {
     double prior = 0.0;
     std::vector<double>& t = throw_scratch;
     t.resize(size_t(_fNumPar));
-    if (m3hip_par_result(dev, &prior, t.data(), _fNumPar) != M3HIP_OK)
+    if (m3hip_par_result(dev, dev_slot, &prior, t.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("CollectDeviceStep: ") + m3hip_last_error(dev));
     if (launched_epoch == throw_epoch && throw_drawn) {
       corr_throw.swap(t);
@@ -395,7 +411,7 @@ M3_OMP(omp for schedule(static, 4))
     throwMatrixCholDecomp = L;
     throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)
     ++throw_epoch;
-    if (dev && m3hip_par_upload(dev, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
+    if (dev && m3hip_par_upload(dev, dev_slot, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("SetThrowMatrix: ") + m3hip_last_error(dev));
   }
 
@@ -452,6 +468,7 @@ M3_OMP(omp for schedule(static, 4))
   bool adaption_pending = false, throw_ready = false, throw_drawn = false;
   // device side (AttachDevice)
   m3hip_handle dev = nullptr;
+  int dev_slot = -1;  // this handler's context on the engine (m3hip_par_create)
   uint64_t throw_epoch = 0, launched_epoch = 0;  // bumped whenever a throw in flight would be stale
 #if defined(_OPENMP)
   int adaption_threads = std::max(1, std::min(8, omp_get_max_threads()));
@@ -492,7 +509,9 @@ class MCMCBase {
     }
     for (int i = 0; i < n_steps; ++i) {
       const auto t0 = std::chrono::steady_clock::now();
+      const int acc_before = accCount;
       DoStep();
+      AccStore.push_back(char(accCount != acc_before));
       for (auto* s : systematics)
         if (s->GetDoAdaption()) s->UpdateAdaptiveCovariance();  // MCMCBase::AdaptiveStep
       ++step;
@@ -507,6 +526,12 @@ class MCMCBase {
   int GetOutOfBoundsCount() const { return oobCount; }
   const std::vector<double>& GetStepStore() const { return StepStore; }  ///< [step][all parameters of all handlers]
   const std::vector<double>& GetLogLStore() const { return LogLStore; }
+  const std::vector<char>& GetAcceptStore() const { return AccStore; }  ///< [step] 1: the step was accepted
+  /// the last proposal's likelihood per sample handler / per systematics object (the reference writes both to its output
+  /// tree every step: Fitters/FitterBase.cpp:195-215)
+  const std::vector<double>& GetSampleLikelihoods() const { return sample_llh; }
+  const std::vector<double>& GetSystLikelihoods() const { return syst_llh; }
+  double GetLogLProp() const { return logLProp; }
   const std::vector<double>& GetStepTimes() const { return stepTime; }
 
   /// ref: Fitters/FitterBase.cpp:461-520
@@ -550,7 +575,6 @@ class MCMCBase {
     // the samples' kernels; the others compute both here, under the GPU's work
     for (auto* s : systematics)
       if (s->OnDevice() && !out_of_bounds) s->LaunchDeviceStep();
-    double llh = 0.0;
     for (size_t s = 0; s < systematics.size(); ++s)
       if (!systematics[s]->OnDevice() || out_of_bounds) syst_llh[s] = systematics[s]->GetLikelihood();
     for (auto* s : systematics) {
@@ -558,18 +582,20 @@ class MCMCBase {
       if (!s->OnDevice() || out_of_bounds) s->PrepareNextThrow();
     }
     if (!out_of_bounds) {
-      for (size_t i = 0; i < samples.size(); ++i) {
-        sample_llh[i] = samples[i]->GetLikelihood();
-        llh += sample_llh[i];
-      }
+      for (size_t i = 0; i < samples.size(); ++i) sample_llh[i] = samples[i]->GetLikelihood();
     } else {
       ++oobCount;
       for (size_t i = 0; i < samples.size(); ++i) sample_llh[i] = M3::_LARGE_LOGL_;
     }
-    for (size_t s = 0; s < systematics.size(); ++s) {
+    for (size_t s = 0; s < systematics.size(); ++s)
       if (systematics[s]->OnDevice() && !out_of_bounds) syst_llh[s] = systematics[s]->CollectDeviceStep();
-      llh += syst_llh[s];
-    }
+    // the sum in the reference's order whatever order the terms became available in: systematics first, then the samples
+    // (MR2T2.cpp:33-84) -- logLProp is then the same double as the reference's, and an accept / reject on the threshold
+    // cannot flip between a device-attached and a host-only chain
+    double llh = 0.0;
+    for (size_t s = 0; s < systematics.size(); ++s) llh += syst_llh[s];
+    if (!out_of_bounds)
+      for (size_t i = 0; i < samples.size(); ++i) llh += sample_llh[i];
     logLProp = llh;
   }
   void ProposeStepAtCurrent() {
@@ -589,6 +615,7 @@ class MCMCBase {
   std::mt19937_64 random;
   std::uniform_real_distribution<double> unif{0.0, 1.0};
   std::vector<double> StepStore, LogLStore, stepTime;
+  std::vector<char> AccStore;
 };
 
 /// ref: Fitters/MR2T2.cpp:11-115

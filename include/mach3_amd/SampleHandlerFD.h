@@ -353,6 +353,55 @@ class SampleHandlerFD : public SampleHandlerBase {
       else std::printf("%s: data %.3f  MC %.3f\n", GetSampleTitle(s).c_str(), d, m);
     }
   }
+  // ---- one sample over several GPUs (new: the reference is one device, Manager/gpuUtils.cu:71).  Every rank -- one process
+  // per GPU -- builds this object over ITS events only (M3::ShardRanges, Sharding.h); from InitComm / OpenExchange on,
+  // Reweight() ends in one exchange of the bin vector, and GetLikelihood(), GetMCArray() and GetW2Array() return the whole
+  // sample's numbers on every rank.  Every rank must then make the same calls in the same order (each Reweight is a
+  // collective); a fitter seeded alike on all ranks does, because it sees the same likelihoods everywhere.  The transport of
+  // the two small blobs (128 / 64 bytes) between the ranks is the caller's: MPI_Bcast / MPI_Allgather, a file, a socket.
+
+  /// rank 0 creates the RCCL unique id and hands it to all ranks (ncclGetUniqueId)
+  static std::array<char, M3HIP_UNIQUE_ID_BYTES> GetCommUniqueId() {
+    std::array<char, M3HIP_UNIQUE_ID_BYTES> id{};
+    if (m3hip_comm_get_unique_id(id.data()) != M3HIP_OK) throw MaCh3Exception(__FILE__, __LINE__, m3hip_last_error(nullptr));
+    return id;
+  }
+  static bool CommAvailable() { return m3hip_comm_available() != 0; }
+  /// collective over all ranks (ncclCommInitRank): Reweight() then all-reduces [mc | w2] in place over RCCL / xGMI.
+  /// Validate: every step also gathers the ranks' partial vectors and checks the reduced one against their host-side sum
+  /// (first runs on a new node; costs a synchronisation per step).
+  void InitComm(const void* UniqueId, int Rank, int nRanks, bool Validate = false) {
+    M3HIP_CALL(h, m3hip_comm_init(h, UniqueId, Rank, nRanks));
+    M3HIP_CALL(h, m3hip_comm_set_validate(h, Validate ? 1 : 0));
+    comm_rank = Rank;
+    comm_ranks = nRanks;
+  }
+  /// The one-shot form of the same exchange (one xGMI hop instead of a ring's 2 (N - 1); bit-identical bins on every rank by
+  /// construction): CreateExchange allocates this rank's slot buffer and returns its 64-byte IPC handle; once every rank has
+  /// everybody's, OpenExchange(handles of all ranks in rank order) switches Reweight() over.  TimeoutSeconds: how long a rank
+  /// waits on the device for its peers' vectors of a step before the next GetLikelihood / GetMCArray throws (<= 50).
+  std::array<char, M3HIP_XCH_HANDLE_BYTES> CreateExchange(int Rank, int nRanks) {
+    std::array<char, M3HIP_XCH_HANDLE_BYTES> hdl{};
+    M3HIP_CALL(h, m3hip_xch_create(h, Rank, nRanks, hdl.data()));
+    comm_rank = Rank;
+    comm_ranks = nRanks;
+    return hdl;
+  }
+  void OpenExchange(const std::vector<std::array<char, M3HIP_XCH_HANDLE_BYTES>>& Handles, double TimeoutSeconds = 0.0) {
+    if (int(Handles.size()) != comm_ranks) throw MaCh3Exception(__FILE__, __LINE__, "OpenExchange: one handle per rank, in rank order");
+    M3HIP_CALL(h, m3hip_xch_open(h, Handles.data()));
+    if (TimeoutSeconds > 0.0) M3HIP_CALL(h, m3hip_xch_set_timeout(h, TimeoutSeconds));
+  }
+  /// back to one device (collective for RCCL: every rank calls it)
+  void CloseComm() {
+    M3HIP_CALL(h, m3hip_xch_destroy(h));
+    M3HIP_CALL(h, m3hip_comm_destroy(h));
+    comm_rank = 0;
+    comm_ranks = 1;
+  }
+  int GetCommRank() const { return comm_rank; }
+  int GetCommSize() const { return comm_ranks; }
+
   const BinningHandler* GetBinning() const { return Binning.get(); }
   SplineBase* GetSplineHandler() { return SplineHandler.get(); }
 
@@ -386,4 +435,5 @@ class SampleHandlerFD : public SampleHandlerBase {
   std::vector<double> data;
   mutable std::vector<double> per_sample;
   unsigned int n_added = 0;
+  int comm_rank = 0, comm_ranks = 1;
 };

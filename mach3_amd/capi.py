@@ -28,7 +28,7 @@ M3HIP_SYMBOLS = [
     "m3hip_get_segments",
     "m3hip_comm_get_unique_id", "m3hip_comm_init", "m3hip_comm_destroy", "m3hip_comm_available", "m3hip_device_synchronize", "m3hip_upload_event_weights", "m3hip_upload_weight_index",
     "m3hip_set_weight_table", "m3hip_set_deterministic", "m3hip_monolith_expect_events",
-    "m3hip_comm_set_validate", "m3hip_comm_last_validation", "m3hip_xch_create", "m3hip_xch_open", "m3hip_xch_destroy", "m3hip_xch_set_timeout", "m3hip_par_upload", "m3hip_par_launch", "m3hip_par_result",
+    "m3hip_comm_set_validate", "m3hip_comm_last_validation", "m3hip_xch_create", "m3hip_xch_open", "m3hip_xch_destroy", "m3hip_xch_set_timeout", "m3hip_device_count", "m3hip_par_create", "m3hip_par_destroy", "m3hip_par_upload", "m3hip_par_launch", "m3hip_par_result",
     "m3hip_debug_layout", "m3hip_debug_short_brick_plan", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
     "m3hip_get_info", "m3hip_timing_enable", "m3hip_timing_read", "m3hip_timing_reset", "m3hip_version",
 ]
@@ -158,9 +158,12 @@ def load_m3hip():
         "m3hip_xch_open": [vp, vp],
         "m3hip_xch_destroy": [vp],
         "m3hip_xch_set_timeout": [vp, C.c_double],
-        "m3hip_par_upload": [vp, i32, vp, i32],
-        "m3hip_par_launch": [vp, vp, vp, i32],
-        "m3hip_par_result": [vp, C.POINTER(C.c_double), vp, i32],
+        "m3hip_device_count": [C.POINTER(i32)],
+        "m3hip_par_create": [vp, C.POINTER(i32)],
+        "m3hip_par_destroy": [vp, i32],
+        "m3hip_par_upload": [vp, i32, i32, vp, i32],
+        "m3hip_par_launch": [vp, i32, vp, vp, i32],
+        "m3hip_par_result": [vp, i32, C.POINTER(C.c_double), vp, i32],
         "m3hip_get_info": [vp, C.POINTER(Info)],
         "m3hip_timing_enable": [vp, i32],
         "m3hip_timing_read": [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)],

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -86,6 +87,12 @@ struct Rccl {
 static_assert(sizeof(ncclUniqueId) == M3HIP_UNIQUE_ID_BYTES, "m3hip.h documents the unique id as 128 bytes");
 Rccl g_rccl;
 std::string g_create_err;
+
+// One-shot exchange buffers created in THIS process, by the bytes of their IPC handle: a rank whose peer lives in the same
+// process (one process driving several engines / devices) takes the peer's pointer from here -- hipIpcOpenMemHandle refuses
+// a handle of the opening process's own.
+std::mutex g_xch_mu;
+std::map<std::string, void*> g_xch_local;
 
 }  // namespace
 
@@ -297,6 +304,7 @@ struct m3hip_ctx {
   // through IPC, the slots this rank pushes into, the step counter and the time-out word
   double* xch_own = nullptr;
   std::vector<void*> xch_peer;     // [N] base of every rank's buffer as mapped here (own: xch_own)
+  std::vector<char> xch_peer_local;  // [N] 1: the buffer belongs to an engine of this process (nothing to close)
   double** d_xch_targets = nullptr;  // [2][N] device array: slot [parity][rank] of every rank's buffer
   int xch_ranks = 0, xch_rank = 0, xch_slot = 0;  // slot: doubles per slot (2 * n_bins + 2)
   bool xch_active = false;
@@ -315,7 +323,9 @@ struct m3hip_ctx {
     uint64_t ticket = 0;        // launches so far
     uint64_t collected = 0;     // ... whose results have been waited for
     bool have_inv = false, have_chol = false;
-  } par;
+    bool live = false;          // handed out by m3hip_par_create
+  };
+  std::vector<ParDev> pars;     // one per attached parameter handler (m3hip_par_create)
   hipStream_t par_stream = nullptr;  // its own stream: two latency-bound launches that need not queue behind the reweight kernel
   double xch_timeout_s = 2.0;     // every ticket spin of k_xch gives up after this long (m3hip_xch_set_timeout, M3HIP_XCH_TIMEOUT_S)
   uint64_t* h_xch_status = nullptr;  // mapped pinned host word (0: fine; else the step whose tickets did not arrive)
@@ -400,14 +410,16 @@ hipError_t wait_stream(hipStream_t s) {
   }
 }
 
-void par_free(m3hip_handle h) {
-  auto& p = h->par;
+void par_free(m3hip_handle h, m3hip_ctx::ParDev& p) {  // buffers only: the slot stays live
   if (h->par_stream) (void)hipStreamSynchronize(h->par_stream);
+  else if (h->stream) (void)hipStreamSynchronize(h->stream);
   dev_free(p.d_inv); dev_free(p.d_chol); dev_free(p.d_rows); dev_free(p.d_in);
   for (int i = 0; i < 2; ++i)
     if (p.h_in[i]) (void)hipHostFree(p.h_in[i]);
   if (p.h_out) (void)hipHostFree(p.h_out);
+  const bool live = p.live;
   p = m3hip_ctx::ParDev();
+  p.live = live;
 }
 
 // The one-shot exchange's verdict on the last step (the stream is idle up to that step's k_xch).  The status word holds
@@ -756,7 +768,8 @@ int m3hip_destroy(m3hip_handle h) try {
   dev_free(h->d_hist);
   dev_free(h->d_llh_terms);
   dev_free(h->d_dbg_clock);
-  par_free(h);
+  for (auto& p : h->pars) par_free(h, p);
+  h->pars.clear();
   if (h->par_stream) (void)hipStreamDestroy(h->par_stream);
   if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -773,6 +786,16 @@ int m3hip_set_stream(m3hip_handle h, void* hip_stream) try {
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
   return M3HIP_OK;
 } M3_API_CATCH(h)
+
+int m3hip_device_count(int* out) try {
+  if (!out) return M3HIP_EINVAL;
+  *out = 0;
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(nullptr, M3HIP_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  *out = n;
+  return M3HIP_OK;
+} M3_API_CATCH(nullptr)
 
 int m3hip_mem_info(m3hip_handle h, size_t* free_bytes, size_t* total_bytes) try {
   if (!h) return M3HIP_EINVAL;
@@ -893,7 +916,10 @@ void ShortBrickPlan::begin(uint64_t expect_events, uint64_t first_chunk_events, 
   }
   if (expect_events == 0 || n_cu <= 0 || first_chunk_events == 0) return;
   B = uint64_t(M3_GROUP) * uint64_t(G);
-  const uint64_t nb = (expect_events + B - 1) / B, cu = uint64_t(n_cu);
+  // bricks are cut chunk by chunk: every chunk of the first one's size ends in a partial brick of its own when that size is no
+  // multiple of B (G > 1 with chunks that are multiples of 1024 only)
+  const uint64_t c = first_chunk_events, cu = uint64_t(n_cu);
+  const uint64_t nb = expect_events / c * ((c + B - 1) / B) + (expect_events % c + B - 1) / B;
   if (nb % cu == 0) return;
   if (!force && (nb / cu < 8 || (cu - nb % cu) * 100 < 3 * nb)) return;  // few rounds, or less than 3 % of the launch to gain
   const uint64_t extra = (nb + cu - 1) / cu * cu - nb;              // bricks to gain: one per conversion of 3 B events
@@ -906,8 +932,11 @@ void ShortBrickPlan::begin(uint64_t expect_events, uint64_t first_chunk_events, 
 void ShortBrickPlan::take(uint64_t chunk_first, uint64_t chunk_events, uint64_t* from, uint64_t* to) {
   *from = *to = ~0ull;
   if (left == 0) return;
-  const uint64_t a = std::max(zone0, chunk_first), b = chunk_first + chunk_events;
-  if (a >= b || (a - chunk_first) % B != 0) return;
+  // bricks are cut chunk-locally (a chunk's first brick starts at its first event): the stretch starts on the chunk's own
+  // next brick boundary at or behind zone0, wherever the chunk borders fall against the global multiples of B
+  const uint64_t b = chunk_first + chunk_events;
+  const uint64_t a = chunk_first + (std::max(zone0, chunk_first) - chunk_first + B - 1) / B * B;
+  if (a >= b) return;
   const uint64_t n = std::min(left, (b - a) / (3 * B));
   if (n == 0) return;
   *from = a - chunk_first;
@@ -2544,8 +2573,14 @@ int m3hip_xch_destroy(m3hip_handle h) try {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int r = 0; r < int(h->xch_peer.size()); ++r)
-    if (h->xch_peer[r] && h->xch_peer[r] != (void*)h->xch_own) (void)hipIpcCloseMemHandle(h->xch_peer[r]);
+    if (h->xch_peer[r] && !h->xch_peer_local[size_t(r)]) (void)hipIpcCloseMemHandle(h->xch_peer[r]);
   h->xch_peer.clear();
+  h->xch_peer_local.clear();
+  if (h->xch_own) {
+    std::lock_guard<std::mutex> lk(g_xch_mu);
+    for (auto it = g_xch_local.begin(); it != g_xch_local.end();)
+      it = it->second == (void*)h->xch_own ? g_xch_local.erase(it) : std::next(it);
+  }
   if (h->xch_own) (void)hipFree(h->xch_own);
   h->xch_own = nullptr;
   if (h->d_xch_targets) (void)hipFree(h->d_xch_targets);
@@ -2561,7 +2596,9 @@ int m3hip_xch_destroy(m3hip_handle h) try {
 } M3_API_CATCH(h)
 
 int m3hip_xch_set_timeout(m3hip_handle h, double seconds) try {
-  if (!h || !(seconds > 0.0) || seconds > 3600.0) return fail(h, M3HIP_EINVAL, "xch_set_timeout: between 0 and 3600 s");
+  // the spin runs ON THE DEVICE: a time-out beyond a minute would outlast every host-side limit around it (the likelihood wait
+  // gives up after 60 s, bench.py's watchdog after 180 s) and leave a kernel spinning behind a caller that has already left
+  if (!h || !(seconds > 0.0) || seconds > 50.0) return fail(h, M3HIP_EINVAL, "xch_set_timeout: between 0 and 50 s (below the host-side 60 s wait)");
   h->xch_timeout_s = seconds;
   return M3HIP_OK;
 } M3_API_CATCH(h)
@@ -2577,7 +2614,7 @@ int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) tr
   h->xch_rank = rank;
   if (const char* f = getenv("M3HIP_XCH_TIMEOUT_S")) {
     const double v = atof(f);
-    if (v > 0.0 && v <= 3600.0) h->xch_timeout_s = v;
+    if (v > 0.0 && v <= 50.0) h->xch_timeout_s = v;
   }
   h->xch_slot = 2 * h->n_bins + 2;
   const size_t bytes = sizeof(double) * 2 * size_t(n_ranks) * size_t(h->xch_slot);
@@ -2596,6 +2633,10 @@ int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) tr
   }
   memset(handle_out, 0, M3HIP_XCH_HANDLE_BYTES);
   memcpy(handle_out, &ipc, sizeof(ipc));
+  {
+    std::lock_guard<std::mutex> lk(g_xch_mu);
+    g_xch_local[std::string(static_cast<const char*>(handle_out), M3HIP_XCH_HANDLE_BYTES)] = h->xch_own;
+  }
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -2605,10 +2646,17 @@ int m3hip_xch_open(m3hip_handle h, const void* handles) try {
   HIPCHK(h, hipSetDevice(h->device));
   const int N = h->xch_ranks;
   h->xch_peer.assign(size_t(N), nullptr);
+  h->xch_peer_local.assign(size_t(N), 0);
   for (int r = 0; r < N; ++r) {
-    if (r == h->xch_rank) { h->xch_peer[r] = h->xch_own; continue; }
+    if (r == h->xch_rank) { h->xch_peer[r] = h->xch_own; h->xch_peer_local[r] = 1; continue; }
+    const char* hb = static_cast<const char*>(handles) + size_t(r) * M3HIP_XCH_HANDLE_BYTES;
+    {  // a peer in this process: its buffer as it is (another device of this process: peer access through the runtime's default)
+      std::lock_guard<std::mutex> lk(g_xch_mu);
+      auto it = g_xch_local.find(std::string(hb, M3HIP_XCH_HANDLE_BYTES));
+      if (it != g_xch_local.end()) { h->xch_peer[r] = it->second; h->xch_peer_local[r] = 1; continue; }
+    }
     hipIpcMemHandle_t ipc;
-    memcpy(&ipc, static_cast<const char*>(handles) + size_t(r) * M3HIP_XCH_HANDLE_BYTES, sizeof(ipc));
+    memcpy(&ipc, hb, sizeof(ipc));
     void* p = nullptr;
     const hipError_t e = hipIpcOpenMemHandle(&p, ipc, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
@@ -2637,8 +2685,15 @@ int m3hip_xch_open(m3hip_handle h, const void* handles) try {
 
 /* ---------------------------------------------------------------- parameter handler on the device */
 
-static int par_wait(m3hip_handle h) {  // every launched par step has published its results
-  auto& p = h->par;
+static m3hip_ctx::ParDev* par_slot(m3hip_handle h, int slot, const char* who) {
+  if (slot < 0 || slot >= int(h->pars.size()) || !h->pars[size_t(slot)].live) {
+    fail(h, M3HIP_EINVAL, std::string(who) + ": no such parameter-handler slot (m3hip_par_create)");
+    return nullptr;
+  }
+  return &h->pars[size_t(slot)];
+}
+
+static int par_wait(m3hip_handle h, m3hip_ctx::ParDev& p) {  // every launched step of this slot has published its results
   if (p.collected == p.ticket) return M3HIP_OK;
   volatile uint64_t* flag = reinterpret_cast<volatile uint64_t*>(p.h_out + 1 + p.n);
   hipStream_t st = h->par_stream ? h->par_stream : h->stream;
@@ -2649,6 +2704,8 @@ static int par_wait(m3hip_handle h) {  // every launched par step has published 
     if ((++spins & 0xFFu) == 0) {
       hipError_t e = hipStreamQuery(st);
       if (e != hipSuccess && e != hipErrorNotReady) return fail(h, M3HIP_EHIP, std::string("par_result: ") + hipGetErrorString(e));
+      // the stream has drained and the ticket is not there: the kernels that would publish it never ran
+      if (e == hipSuccess && *flag != p.ticket && now_s() - t0 > 2.0) return fail(h, M3HIP_EHIP, "par_result: the stream is idle but the step's results were never published");
       if (now_s() - t0 > 60.0) return fail(h, M3HIP_EHIP, "par_result: timed out waiting for the device");
     }
   }
@@ -2657,14 +2714,42 @@ static int par_wait(m3hip_handle h) {  // every launched par step has published 
   return M3HIP_OK;
 }
 
-int m3hip_par_upload(m3hip_handle h, int which, const double* m, int n) try {
+int m3hip_par_create(m3hip_handle h, int* slot_out) try {
+  if (!h || !slot_out) return M3HIP_EINVAL;
+  for (size_t i = 0; i < h->pars.size(); ++i)
+    if (!h->pars[i].live) {
+      h->pars[i] = m3hip_ctx::ParDev();
+      h->pars[i].live = true;
+      *slot_out = int(i);
+      return M3HIP_OK;
+    }
+  if (h->pars.size() >= size_t(M3HIP_MAX_PAR_SLOTS)) return fail(h, M3HIP_ESTATE, "par_create: all " + std::to_string(M3HIP_MAX_PAR_SLOTS) + " parameter-handler slots are in use");
+  h->pars.emplace_back();
+  h->pars.back().live = true;
+  *slot_out = int(h->pars.size()) - 1;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_par_destroy(m3hip_handle h, int slot) try {
   if (!h) return M3HIP_EINVAL;
+  m3hip_ctx::ParDev* p = par_slot(h, slot, "par_destroy");
+  if (!p) return M3HIP_EINVAL;
+  (void)hipSetDevice(h->device);
+  par_free(h, *p);
+  p->live = false;
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
+int m3hip_par_upload(m3hip_handle h, int slot, int which, const double* m, int n) try {
+  if (!h) return M3HIP_EINVAL;
+  m3hip_ctx::ParDev* pp = par_slot(h, slot, "par_upload");
+  if (!pp) return M3HIP_EINVAL;
   if ((which != 0 && which != 1) || !m || n < 1 || n > 16384) return fail(h, M3HIP_EINVAL, "par_upload: which is 0 (inverse covariance) or 1 (Cholesky factor), 1 <= n <= 16384");
   HIPCHK(h, hipSetDevice(h->device));
-  auto& p = h->par;
+  auto& p = *pp;
   int rc;
   if (p.n != n) {  // (re)size everything
-    par_free(h);
+    par_free(h, p);
     if (!h->par_stream) {
       const char* f = getenv("M3HIP_PAR_STREAM");
       if (!(f && f[0] == '0')) HIPCHK(h, hipStreamCreateWithFlags(&h->par_stream, hipStreamNonBlocking));
@@ -2682,36 +2767,43 @@ int m3hip_par_upload(m3hip_handle h, int which, const double* m, int n) try {
     HIPCHK(h, hipHostGetDevicePointer((void**)&p.d_out, p.h_out, 0));
     p.n = n;
   }
-  if ((rc = par_wait(h))) return rc;  // a step in flight still reads the old matrix
+  if ((rc = par_wait(h, p))) return rc;  // a step in flight still reads the old matrix
   HIPCHK(h, hipMemcpy(which == 0 ? p.d_inv : p.d_chol, m, sizeof(double) * size_t(n) * n, hipMemcpyHostToDevice));
   (which == 0 ? p.have_inv : p.have_chol) = true;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
-int m3hip_par_launch(m3hip_handle h, const double* d, const double* z, int n) try {
+int m3hip_par_launch(m3hip_handle h, int slot, const double* d, const double* z, int n) try {
   if (!h) return M3HIP_EINVAL;
-  auto& p = h->par;
+  m3hip_ctx::ParDev* pp = par_slot(h, slot, "par_launch");
+  if (!pp) return M3HIP_EINVAL;
+  auto& p = *pp;
   if (!p.have_inv || !p.have_chol) return fail(h, M3HIP_ESTATE, "par_launch before both matrices were uploaded (m3hip_par_upload)");
   if (!d || !z || n != p.n) return fail(h, M3HIP_EINVAL, "par_launch: NULL vectors or n differs from the uploaded matrices");
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
-  if (p.ticket > p.collected && (rc = par_wait(h))) return rc;  // results nobody collected: the output block is about to be rewritten
-  const int slot = int(p.ticket & 1);
-  memcpy(p.h_in[slot], d, sizeof(double) * n);
-  memcpy(p.h_in[slot] + n, z, sizeof(double) * n);
-  ++p.ticket;
-  launch_par_step(p.d_inv, p.d_chol, p.d_in_host[slot], p.d_in, n, p.d_rows, p.d_out, reinterpret_cast<volatile uint64_t*>(p.d_out + 1 + n), p.ticket,
+  if (p.ticket > p.collected && (rc = par_wait(h, p))) return rc;  // results nobody collected: the output block is about to be rewritten
+  const int in = int(p.ticket & 1);
+  memcpy(p.h_in[in], d, sizeof(double) * n);
+  memcpy(p.h_in[in] + n, z, sizeof(double) * n);
+  // the ticket counts a step only once its launches went out: a failed launch must not leave every later wait spinning
+  // for a ticket no kernel will ever publish
+  const uint64_t ticket = p.ticket + 1;
+  launch_par_step(p.d_inv, p.d_chol, p.d_in_host[in], p.d_in, n, p.d_rows, p.d_out, reinterpret_cast<volatile uint64_t*>(p.d_out + 1 + n), ticket,
                   h->par_stream ? h->par_stream : h->stream);
   HIPCHK(h, hipGetLastError());
+  p.ticket = ticket;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
-int m3hip_par_result(m3hip_handle h, double* prior, double* corr_throw, int n) try {
+int m3hip_par_result(m3hip_handle h, int slot, double* prior, double* corr_throw, int n) try {
   if (!h) return M3HIP_EINVAL;
-  auto& p = h->par;
+  m3hip_ctx::ParDev* pp = par_slot(h, slot, "par_result");
+  if (!pp) return M3HIP_EINVAL;
+  auto& p = *pp;
   if (p.ticket == 0) return fail(h, M3HIP_ESTATE, "par_result before par_launch");
   if (n != p.n) return fail(h, M3HIP_EINVAL, "par_result: n differs from the uploaded matrices");
-  int rc = par_wait(h);
+  int rc = par_wait(h, p);
   if (rc) return rc;
   if (prior) *prior = p.h_out[0];
   if (corr_throw) memcpy(corr_throw, p.h_out + 1, sizeof(double) * n);

@@ -122,21 +122,29 @@ class Engine:
         assert len(blob) % capi.XCH_HANDLE_BYTES == 0
         self._chk(self.lib.m3hip_xch_open(self.h, C.c_char_p(blob)))
 
-    # ---- the parameter handler's prior and correlated throw on the device (m3hip_par_*)
-    def par_upload(self, which: int, matrix):
+    # ---- the parameter handler's prior and correlated throw on the device (m3hip_par_*); one slot per handler
+    def par_create(self) -> int:
+        slot = C.c_int32(-1)
+        self._chk(self.lib.m3hip_par_create(self.h, C.byref(slot)))
+        return slot.value
+
+    def par_destroy(self, slot: int):
+        self._chk(self.lib.m3hip_par_destroy(self.h, slot))
+
+    def par_upload(self, slot: int, which: int, matrix):
         m = np.ascontiguousarray(matrix, np.float64)
         assert m.ndim == 2 and m.shape[0] == m.shape[1]
-        self._chk(self.lib.m3hip_par_upload(self.h, which, m.ctypes.data, m.shape[0]))
+        self._chk(self.lib.m3hip_par_upload(self.h, slot, which, m.ctypes.data, m.shape[0]))
 
-    def par_launch(self, d, z):
+    def par_launch(self, slot: int, d, z):
         d = np.ascontiguousarray(d, np.float64)
         z = np.ascontiguousarray(z, np.float64)
-        self._chk(self.lib.m3hip_par_launch(self.h, d.ctypes.data, z.ctypes.data, len(d)))
+        self._chk(self.lib.m3hip_par_launch(self.h, slot, d.ctypes.data, z.ctypes.data, len(d)))
 
-    def par_result(self, n: int):
+    def par_result(self, slot: int, n: int):
         prior = C.c_double()
         throw = np.empty(n, np.float64)
-        self._chk(self.lib.m3hip_par_result(self.h, C.byref(prior), throw.ctypes.data, n))
+        self._chk(self.lib.m3hip_par_result(self.h, slot, C.byref(prior), throw.ctypes.data, n))
         return prior.value, throw
 
     def xch_set_timeout(self, seconds: float):

@@ -4,6 +4,7 @@
 #include "../../include/mach3_amd/SampleHandlerFD.h"
 #include "../../include/mach3_amd/Fitters.h"
 #include "../../include/mach3_amd/SplineBuilders.h"
+#include "../../include/mach3_amd/Sharding.h"
 
 extern "C" {
 
@@ -238,6 +239,76 @@ int facade_par_device_check(int n, unsigned long long seed, int n_steps, double*
     return 0;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "facade_par_device_check: %s\n", e.what());
+    if (h) m3hip_destroy(h);
+    return 99;
+  }
+}
+
+// M3::ShardRanges (Sharding.h) for the comparison with mach3_amd/dist.py:shard_ranges: cuts[2 * n_ranks] = {first, last} per rank
+int facade_shard_ranges(unsigned long long n_events, int n_ranks, const double* weights, unsigned long long* cuts) {
+  try {
+    std::vector<double> w;
+    if (weights) w.assign(weights, weights + n_events);
+    const auto r = M3::ShardRanges(n_events, n_ranks, w);
+    for (int i = 0; i < n_ranks; ++i) {
+      cuts[2 * i] = r[size_t(i)].first;
+      cuts[2 * i + 1] = r[size_t(i)].second;
+    }
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
+// Two ParameterHandlerBase objects attached to ONE engine (MCMCBase loops over all systematics objects): each owns a slot, so
+// with equal or different numbers of parameters both get their own prior and throw.  out[0] = worst relative difference of a
+// prior against the handler's own host loop, out[1] = steps walked.
+int facade_two_handlers_one_engine(int na, int nb, unsigned long long seed, int n_steps, double* out) {
+  m3hip_handle h = nullptr;
+  try {
+    if (m3hip_create(0, &h) != M3HIP_OK) return 100;
+    std::mt19937_64 g(seed);
+    std::normal_distribution<double> N(0.0, 1.0);
+    auto make = [&](const char* name, int n, double ridge, unsigned long long sd) {
+      std::vector<double> a(size_t(n) * n), c(size_t(n) * n, 0.0);
+      for (auto& v : a) v = N(g);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double s = 0.0;
+          for (int k = 0; k < n; ++k) s += a[size_t(i) * n + k] * a[size_t(j) * n + k];
+          c[size_t(i) * n + j] = c[size_t(j) * n + i] = s / n + (i == j ? ridge : 0.0);
+        }
+      std::vector<double> prefit(static_cast<size_t>(n), 0.0), lo(static_cast<size_t>(n), -1e3), up(static_cast<size_t>(n), 1e3);
+      for (auto& v : prefit) v = N(g);
+      return ParameterHandlerBase(name, prefit, c, lo, up, {}, sd);
+    };
+    ParameterHandlerBase A = make("xsec", na, 0.5, seed + 1), B = make("detector", nb, 0.3, seed + 2);
+    ParameterHandlerBase Ah = A, Bh = B;  // host-only twins: same state, same random streams
+    A.AttachDevice(h);
+    B.AttachDevice(h);
+    double worst = 0.0;
+    for (int s = 0; s < n_steps; ++s) {
+      A.ProposeStep(); B.ProposeStep(); Ah.ProposeStep(); Bh.ProposeStep();
+      for (int i = 0; i < na; ++i)
+        if (std::fabs(A.GetParProp(i) - Ah.GetParProp(i)) > 1e-9 * (1.0 + std::fabs(Ah.GetParProp(i)))) return 2;
+      for (int i = 0; i < nb; ++i)
+        if (std::fabs(B.GetParProp(i) - Bh.GetParProp(i)) > 1e-9 * (1.0 + std::fabs(Bh.GetParProp(i)))) return 3;
+      A.LaunchDeviceStep();
+      B.LaunchDeviceStep();  // both in flight before either is collected (MCMCBase::EvaluateProposal's order)
+      const double pa = A.CollectDeviceStep(), pb = B.CollectDeviceStep();
+      const double ha = Ah.GetLikelihood(), hb = Bh.GetLikelihood();
+      worst = std::max(worst, std::fabs(pa - ha) / std::max(std::fabs(ha), 1e-300));
+      worst = std::max(worst, std::fabs(pb - hb) / std::max(std::fabs(hb), 1e-300));
+      A.AcceptStep(); B.AcceptStep(); Ah.AcceptStep(); Bh.AcceptStep();
+    }
+    A.DetachDevice();
+    B.DetachDevice();
+    out[0] = worst;
+    out[1] = n_steps;
+    m3hip_destroy(h);
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "facade_two_handlers_one_engine: %s\n", e.what());
     if (h) m3hip_destroy(h);
     return 99;
   }

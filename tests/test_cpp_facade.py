@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "build", "mr2t2_dragrace")
 
 def test_facade_headers_compile():
     """Syntax-check the facade headers on their own (no GPU, no link)."""
-    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h", "SplineBuilders.h", "Fitters.h"):
+    for h in ("Core.h", "SplineStructs.h", "SplineMonolith.h", "SampleHandlerFD.h", "BinnedSplineHandler.h", "SplineBuilders.h", "Fitters.h", "Sharding.h"):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                             "-x", "c++", os.path.join(ROOT, "include", "mach3_amd", h)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
@@ -155,3 +155,132 @@ def test_device_prior_and_throw_equal_the_host_loops():
         rc = lib.facade_par_device_check(n, 20260318 + n, steps, out.ctypes.data)
         assert rc == 0, (n, rc)
         assert out[2] == steps and out[0] <= 1e-12 and out[1] <= 1e-12, (n, out)
+
+
+def _facade_lib():
+    import ctypes as C
+    subprocess.run(["make", "-C", ROOT, "build/libm3facade_test.so"], check=True, stdout=subprocess.DEVNULL)
+    return C.CDLL(os.path.join(ROOT, "build", "libm3facade_test.so"))
+
+
+def test_cpp_shard_ranges_equal_the_python_harness():
+    """M3::ShardRanges (include/mach3_amd/Sharding.h) -- the rule a C++ host uses to give every rank its block of events --
+    makes the cuts mach3_amd/dist.py:shard_ranges makes (the harness of bench.py and the tests): 20 random weight vectors
+    (responses per event of sparse samples, incl. long stretches of empty events and ties on a rounding boundary), even splits,
+    more ranks than 1024-event groups."""
+    import ctypes as C
+    import numpy as np
+    from mach3_amd import dist
+    lib = _facade_lib()
+    lib.facade_shard_ranges.argtypes = [C.c_ulonglong, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(20260405)
+
+    def cpp(n, ranks, w):
+        cuts = np.zeros(2 * ranks, np.uint64)
+        wp = None if w is None else np.ascontiguousarray(w, np.float64).ctypes.data
+        assert lib.facade_shard_ranges(n, ranks, wp, cuts.ctypes.data) == 0
+        return [(int(cuts[2 * r]), int(cuts[2 * r + 1])) for r in range(ranks)]
+
+    for trial in range(20):
+        n = int(rng.integers(1, 60)) * 1024 + int(rng.integers(0, 1024))
+        ranks = int(rng.choice([1, 2, 3, 4, 8]))
+        kind = trial % 4
+        if kind == 0:
+            w = rng.poisson(32, n).astype(np.float32)                       # config 3's shape
+        elif kind == 1:
+            w = (rng.random(n) < 0.3) * rng.integers(1, 40, n).astype(np.float32)   # most events empty
+        elif kind == 2:
+            w = np.repeat(rng.integers(0, 50, -(-n // 1024)), 1024)[:n].astype(np.float32)  # block averages, as bench.py counts them
+        else:
+            w = np.ones(n, np.float32)                                        # ties: targets fall exactly on events
+        assert cpp(n, ranks, w) == dist.shard_ranges(n, ranks, weights=w), (trial, n, ranks)
+        assert cpp(n, ranks, None) == dist.shard_ranges(n, ranks), (trial, n, ranks)
+    for n, ranks in ((1, 4), (1024, 8), (5000, 8), (10_000_000, 8)):
+        assert cpp(n, ranks, None) == dist.shard_ranges(n, ranks)
+    assert lib.facade_shard_ranges(10, 0, None, np.zeros(2, np.uint64).ctypes.data) == -1
+
+
+@pytest.mark.gpu
+def test_two_parameter_handlers_attached_to_one_engine():
+    """AttachDevice kept its state in the engine's single par block, so a second handler overwrote the first.
+    Every attached handler now owns a slot (m3hip_par_create): two handlers with equal and with different numbers of
+    parameters, both launches in flight together, priors equal to each handler's own host loop (1e-12) and the proposals
+    (device throw) equal to the host-only twins' over 12 steps."""
+    import ctypes as C
+    import numpy as np
+    lib = _facade_lib()
+    lib.facade_two_handlers_one_engine.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_void_p]
+    for na, nb in ((40, 40), (40, 131), (300, 17)):
+        out = np.zeros(2)
+        rc = lib.facade_two_handlers_one_engine(na, nb, 77 + na, 12, out.ctypes.data)
+        assert rc == 0, (na, nb, rc)
+        assert out[1] == 12 and out[0] <= 1e-12, (na, nb, out)
+
+
+def _run_sharded(tmp, n_ranks, exchange, events=60000, params=48, steps=150, timeout=300):
+    exe = os.path.join(ROOT, "build", "mr2t2_sharded")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(r), str(n_ranks), tmp, exchange, str(events), str(params), str(steps), "0"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n_ranks)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"{n_ranks}-rank sharded chain timed out")
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = []
+    for r in range(n_ranks):
+        line = open(os.path.join(tmp, f"result_{r}.txt")).read().strip()
+        kv = dict(tok.split("=", 1) for tok in line.split()[1:])
+        res.append(kv)
+    return res
+
+
+@pytest.mark.gpu
+def test_sharded_chain_through_the_facade_takes_the_same_decisions_on_every_rank():
+    """examples/mr2t2_sharded.cpp: the multi-GPU seam from the C++ side -- M3::ShardRanges, SMonolith + SampleHandlerFD over a
+    rank's own events, SampleHandlerFD::CreateExchange / OpenExchange (handles through files), the same seeded MR2T2 on every
+    rank.  Two processes on the one card of the test box (the one-shot exchange; RCCL refuses two ranks on a device): the
+    accept / reject sequence, the final likelihood and the final bins are IDENTICAL on both ranks (bit for bit: the exchange
+    sums in rank order), and equal to the one-process chain over the whole sample -- same decisions, likelihood to 1e-9, bins to
+    1e-12.  Reference: none (Manager/gpuUtils.cu:71, one device); caller loop Fitters/MR2T2.cpp:25-115."""
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+        one = _run_sharded(t1, 1, "none")[0]
+        two = _run_sharded(t2, 2, "oneshot")
+        b1 = np.fromfile(os.path.join(t1, "bins_0.bin"))
+        b20, b21 = np.fromfile(os.path.join(t2, "bins_0.bin")), np.fromfile(os.path.join(t2, "bins_1.bin"))
+    a, b = two
+    assert a["events"] != b["events"] and a["events"].startswith("[0,") and b["events"].endswith(",60000)")
+    assert a["acc"] == b["acc"] and a["logl"] == b["logl"] and a["accepted"] == b["accepted"]       # identical on both ranks
+    assert np.array_equal(b20, b21)
+    assert a["acc"] == one["acc"] and len(one["acc"]) == 150                                            # ... and the one-process chain's
+    assert 5 < int(one["accepted"]) < 145
+    assert float(a["logl"]) == pytest.approx(float(one["logl"]), rel=1e-9)
+    assert np.allclose(b20, b1, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_two_live_sample_handlers_in_one_fitter():
+    """examples/two_samples_one_fitter.cpp: the reference's step is `for samples: Reweight(); for samples: GetLikelihood()`
+    (Fitters/MR2T2.cpp:66-76).  Two live handlers -- an SMonolith brick sample (float) and a BinnedSplineHandlerT<double> sample,
+    each on its own engine handle and stream -- in ONE MR2T2 over one ParameterHandlerBase: every step's per-handler likelihood
+    equals the handler stepped alone at the same parameters (1e-9), the chain accepts and rejects, and the interleaved pair
+    takes less wall time per step than the two handlers one after the other (the launches and waits overlap)."""
+    exe = os.path.join(ROOT, "build", "two_samples_one_fitter")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    r = subprocess.run([exe, "150000", "200000", "200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("PAIR")][0]
+    kv = dict(tok.split("=") for tok in line.split()[1:])
+    assert int(kv["in_bounds"]) >= 150 and 0 < int(kv["accepted"]) < 200
+    assert float(kv["worst_rel"]) <= 1e-9
+    assert float(kv["us_pair"]) < float(kv["us_A_alone"]) + float(kv["us_B_alone"])
+    assert r.stdout.strip().endswith("OK")

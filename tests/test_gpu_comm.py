@@ -57,11 +57,15 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import numpy as np
 from mach3_amd import synth, dist as m3dist
 from mach3_amd.engine import build_from_synth
-rank, world, tmp, mode, update_w2 = int(sys.argv[1]), int(sys.argv[5]), sys.argv[2], sys.argv[3], sys.argv[4] == "1"
-spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
-e0, e1 = m3dist.shard_ranges(spec.n_events, world)[rank]
-eng, mono, sh, par = build_from_synth(spec, device_id=0, event_range=(e0, e1))
-sh.SetTestStatistic(spec.test_statistic, update_w2)
+ranks, world, tmp, mode, update_w2, n_events = [int(r) for r in sys.argv[1].split(",")], int(sys.argv[5]), sys.argv[2], sys.argv[3], sys.argv[4] == "1", int(sys.argv[6])
+spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
+cuts = m3dist.shard_ranges(spec.n_events, world)
+# one engine per rank this process drives (several: "one process, several engines"; the exchange wires such peers up directly)
+local = []
+for rank in ranks:
+    eng, mono, sh, par = build_from_synth(spec, device_id=0, event_range=cuts[rank])
+    sh.SetTestStatistic(spec.test_statistic, update_w2)
+    local.append((rank, eng, sh, par))
 
 def publish(name, blob):
     f = os.path.join(tmp, name)
@@ -71,45 +75,71 @@ def fetch(name):
     f, t0 = os.path.join(tmp, name), time.time()
     while not os.path.exists(f):
         time.sleep(0.05)
-        assert time.time() - t0 < 60
+        assert time.time() - t0 < 90
     return open(f, "rb").read()
 
 try:
     if mode == "rccl":
+        rank, eng, sh, par = local[0]
         if rank == 0:
             publish("uid", eng.comm_unique_id())
         eng.comm_init(fetch("uid"), rank, world)
         eng.comm_set_validate(True)
     else:  # one-shot exchange: the 64-byte IPC handles travel through files here (any transport will do)
-        publish(f"handle{{rank}}", eng.xch_create(rank, world))
-        eng.xch_open([fetch(f"handle{{r}}") for r in range(world)])
+        for rank, eng, sh, par in local:
+            publish(f"handle{{rank}}", eng.xch_create(rank, world))
+        handles = [fetch(f"handle{{r}}") for r in range(world)]
+        for rank, eng, sh, par in local:
+            eng.xch_open(handles)
+            eng.xch_set_timeout(20.0)       # the processes of a test box start seconds apart
 except Exception as e:
-    open(os.path.join(tmp, f"refused{{rank}}"), "w").write(str(e))
+    open(os.path.join(tmp, f"refused{{ranks[0]}}"), "w").write(str(e))
     sys.exit(0)
-out = []
-sh.Reweight(); data = sh.GetMCArray().copy(); w2_first = sh.GetW2Array().copy(); sh.AddData(data)
+
+def step_all():
+    # a step is a collective: every rank of this process launches before any of them waits
+    for rank, eng, sh, par in local:
+        sh.Reweight()
+    return [sh.GetLikelihood() for rank, eng, sh, par in local]
+
+out = {{rank: [] for rank in ranks}}
+step_all()
+first = {{}}
+for rank, eng, sh, par in local:
+    first[rank] = (sh.GetMCArray().copy(), sh.GetW2Array().copy())
+    sh.AddData(first[rank][0])
 for lap in (1, 2, 3, 4, 5):
-    par[:] = synth.params(spec, lap)
-    llh = sh.Step()
-    out.append((llh, sh.GetMCArray().copy(), sh.GetW2Array().copy()))
-rel, n = eng.comm_last_validation() if mode == "rccl" else (0.0, 99)
-np.savez(os.path.join(tmp, f"rank{{rank}}.npz"), llh=[o[0] for o in out], mc=np.stack([o[1] for o in out]), w2=np.stack([o[2] for o in out]),
-         data=data, w2_first=w2_first, rel=rel, n=n)
-eng.close()
+    for rank, eng, sh, par in local:
+        par[:] = synth.params(spec, lap)
+    llhs = step_all()
+    for (rank, eng, sh, par), llh in zip(local, llhs):
+        out[rank].append((llh, sh.GetMCArray().copy(), sh.GetW2Array().copy()))
+for rank, eng, sh, par in local:
+    rel, n = eng.comm_last_validation() if mode == "rccl" else (0.0, 99)
+    o = out[rank]
+    np.savez(os.path.join(tmp, f"rank{{rank}}.npz"), llh=[x[0] for x in o], mc=np.stack([x[1] for x in o]), w2=np.stack([x[2] for x in o]),
+             data=first[rank][0], w2_first=first[rank][1], rel=rel, n=n)
+# leave together: nobody frees a buffer a peer may still be pushing into
+publish(f"done{{ranks[0]}}", b"x")
+for r in range(0, world, len(ranks)):
+    fetch(f"done{{r}}")
+for rank, eng, sh, par in local:
+    eng.close()
 """
 
 
-def _two_ranks(mode, update_w2, world=2):
+def _two_ranks(mode, update_w2, world=2, per_process=1, n_events=7000):
     with tempfile.TemporaryDirectory() as tmp:
         script = os.path.join(tmp, "worker.py")
         open(script, "w").write(_WORKER.format(root=ROOT))
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs = [subprocess.Popen([sys.executable, script, str(r), tmp, mode, "1" if update_w2 else "0", str(world)], env=env,
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        groups = [",".join(str(r) for r in range(g, g + per_process)) for g in range(0, world, per_process)]
+        procs = [subprocess.Popen([sys.executable, script, g, tmp, mode, "1" if update_w2 else "0", str(world), str(n_events)], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for g in groups]
         outs = []
         for p in procs:
             try:
-                outs.append(p.communicate(timeout=240)[0].decode())
+                outs.append(p.communicate(timeout=300)[0].decode())
             except subprocess.TimeoutExpired:
                 for q in procs:
                     q.kill()
@@ -129,7 +159,7 @@ def _two_ranks(mode, update_w2, world=2):
             assert np.array_equal(r0["data"], r1["data"]) and np.array_equal(r0["w2_first"], r1["w2_first"])
         assert r0["rel"] <= 1e-15 and r0["n"] >= 4
         # ... equal to one engine over the whole sample
-        spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
+        spec = synth.CONFIGS["c3"].scaled(n_events, n_params=64)
         eng, mono, sh, par = build_from_synth(spec, device_id=0)
         sh.SetTestStatistic(spec.test_statistic, update_w2)
         sh.Reweight()
@@ -160,6 +190,21 @@ def test_four_ranks_one_shot_exchange_matches_unsharded():
     """four processes on one card: slot [parity][rank] of every rank's buffer, four push blocks per step, a pull over four
     slots -- the indexing two ranks cannot get wrong"""
     _two_ranks("oneshot", False, world=4)
+
+
+@pytest.mark.parametrize("update_w2", [False, True])
+def test_eight_ranks_one_shot_exchange_matches_unsharded(update_w2):
+    """N = 8 -- what the driver's node runs -- rehearsed on one card: eight slots per parity in every rank's buffer, eight push
+    blocks and a pull over eight slots per step, both parities, the first_w2 transition (the message shrinks from [mc | w2] to
+    mc), with and without UpdateW2.  The pool allows six processes on a card, so the eight ranks are four processes driving
+    two engines each: ranks of one process are recognised by their handles and wired up directly (m3hip_xch_open), ranks of
+    different processes through IPC -- both kinds of peer in one exchange."""
+    _two_ranks("oneshot", update_w2, world=8, per_process=2, n_events=8 * 2048 + 500)
+
+
+def test_two_ranks_in_one_process_one_shot_exchange():
+    """one process driving two engines (ranks 0 and 1 of two): no IPC mapping at all, the peers' buffers as they are"""
+    _two_ranks("oneshot", False, world=2, per_process=2)
 
 
 _SILENT_PEER = r"""
@@ -215,8 +260,9 @@ def test_one_shot_exchange_reports_a_missing_peer(fresh_engine):
 
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_bench_ranks_on_one_card_with_check(n_ranks):
-    """bench.py's N > 1 path end to end on the one card of the test box, with the configuration it picks for that N
-    (configs[2] for two ranks, configs[3] -- four samples -- for four) at a reduced size: torch.distributed over gloo for the
+    """bench.py's N > 1 path end to end on the one card of the test box at a reduced size: ONE workload for the whole --gpus
+    series (configs[2], the N = 1 line's: `value` over N is a strong-scaling curve), and from four ranks on configs[3] -- four
+    samples, 800 bins -- under `extra` with its own step time, roofline and work rate.  torch.distributed over gloo for the
     rendez-vous, the engine's one-shot exchange for the bins (RCCL refuses several ranks on one device), events sharded by
     responses with the cuts counted on rank 0 and broadcast, a time-bounded spin-up whose step count rank 0 decides for
     everybody (every step is a collective), `--check`: the sharded likelihood of three laps equals the one-rank likelihood
@@ -228,14 +274,22 @@ def test_bench_ranks_on_one_card_with_check(n_ranks):
     n_events = 150_000 * n_ranks
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--events", str(n_events),
-                        "--steps", "10", "--warmup", "2", "--spinup-seconds", "0.5", "--check"], env=env, capture_output=True, text=True, timeout=500)
+                        "--steps", "10", "--warmup", "2", "--spinup-seconds", "0.5", "--check", "--strict"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == n_ranks and "one-shot" in line["config"]["comm"]
     assert line["config"]["ranks_seen"] == n_ranks
-    assert ("configs[2]" if n_ranks == 2 else "configs[3]") in line["config"]["workload"]
+    assert "configs[2]" in line["config"]["workload"] and line["config"]["total_events"] == n_events      # the same workload for every N
     assert line["check"]["ok"] and line["check"]["max_rel_diff"] <= 1e-9
     assert line["config"]["events_per_gpu"] < n_events and line["roofline"]["avg_kernel_ms_by_rank"]["min"] > 0
+    assert "extra_failed" not in line
+    if n_ranks >= 4:
+        c4 = line["extra"]["configs[3]"]
+        assert "configs[3]" in c4["workload"] and "4 samples" in c4["workload"] and "800 bins" in c4["workload"]
+        assert c4["ms_per_step"] > 0 and c4["event_steps_per_s"] > 0 and c4["roofline"]["avg_kernel_ms"] > 0 and c4["roofline"]["frac"] > 0
+        assert c4["events_per_gpu"] < 4 * n_events and "one-shot" in c4["comm"]
+    else:
+        assert "configs[3]" not in line.get("extra", {})
 
 
 def test_bench_starts_its_own_ranks_without_a_launcher():

@@ -1642,18 +1642,21 @@ def test_parameter_handler_kernels_through_the_c_abi(fresh_engine):
     replaced between launches, and the error paths."""
     eng = fresh_engine
     rng = np.random.default_rng(11)
+    with pytest.raises(capi.M3HipError, match="no such parameter-handler slot"):
+        eng.par_launch(0, np.zeros(4), np.zeros(4))
+    sl = eng.par_create()
     with pytest.raises(capi.M3HipError, match="before both matrices"):
-        eng.par_launch(np.zeros(4), np.zeros(4))
+        eng.par_launch(sl, np.zeros(4), np.zeros(4))
     with pytest.raises(capi.M3HipError, match="before par_launch"):
-        eng.par_result(4)
+        eng.par_result(sl, 4)
     for n in (1, 5, 64, 65, 513, 1040):
         a = rng.standard_normal((n, n))
         cov = a @ a.T / n + 0.3 * np.eye(n)
         inv = np.linalg.inv(cov)
         inv = 0.5 * (inv + inv.T)
         L = np.linalg.cholesky(cov)
-        eng.par_upload(0, inv)
-        eng.par_upload(1, L)
+        eng.par_upload(sl, 0, inv)
+        eng.par_upload(sl, 1, L)
         for rep in range(3):
             d, z = rng.standard_normal(n), rng.standard_normal(n)
             if rep == 1:
@@ -1661,22 +1664,63 @@ def test_parameter_handler_kernels_through_the_c_abi(fresh_engine):
                 z[1::4] = 0.0     # fixed parameters
             if rep == 2:          # a new throw matrix between two launches
                 L = np.linalg.cholesky(cov + 0.1 * np.eye(n))
-                eng.par_upload(1, L)
-            eng.par_launch(d, z)
-            prior, thr = eng.par_result(n)
+                eng.par_upload(sl, 1, L)
+            eng.par_launch(sl, d, z)
+            prior, thr = eng.par_result(sl, n)
             dl, il, Ll, zl = d.astype(np.longdouble), inv.astype(np.longdouble), L.astype(np.longdouble), z.astype(np.longdouble)
             ref_prior = float(sum(dl[i] * (il[i, :i] @ dl[:i] + 0.5 * il[i, i] * dl[i]) for i in range(n)))
             ref_thr = np.array([float(Ll[i, :i + 1] @ zl[:i + 1]) for i in range(n)])
             assert abs(prior - ref_prior) <= 1e-12 * max(abs(ref_prior), 1.0), (n, rep)
             assert np.allclose(thr, ref_thr, rtol=1e-12, atol=1e-13 * np.abs(ref_thr).max()), (n, rep)
             # bit-reproducible: the same launch again gives the same bits
-            eng.par_launch(d, z)
-            prior2, thr2 = eng.par_result(n)
+            eng.par_launch(sl, d, z)
+            prior2, thr2 = eng.par_result(sl, n)
             assert prior2 == prior and np.array_equal(thr2, thr)
     with pytest.raises(capi.M3HipError, match="n differs"):
-        eng.par_launch(np.zeros(3), np.zeros(3))
+        eng.par_launch(sl, np.zeros(3), np.zeros(3))
     with pytest.raises(capi.M3HipError, match="which is 0"):
-        eng.par_upload(2, np.eye(3))
+        eng.par_upload(sl, 2, np.eye(3))
+    eng.par_destroy(sl)
+    with pytest.raises(capi.M3HipError, match="no such parameter-handler slot"):
+        eng.par_result(sl, 3)
+
+
+@pytest.mark.gpu
+def test_two_parameter_handlers_share_one_engine(fresh_engine):
+    """MCMCBase loops over ALL systematics objects (Fitters/MCMCBase.cpp:32-77): two handlers attached to one engine each get a
+    slot of their own -- matrices, results and tickets do not mix, whether the two have the same number of parameters or not,
+    and both launches may be in flight before either result is read (the order MCMCBase::EvaluateProposal produces)."""
+    eng = fresh_engine
+    rng = np.random.default_rng(5)
+
+    def handler(n, shift):
+        a = rng.standard_normal((n, n))
+        cov = a @ a.T / n + shift * np.eye(n)
+        inv = np.linalg.inv(cov)
+        return 0.5 * (inv + inv.T), np.linalg.cholesky(cov)
+
+    def ref(inv, L, d, z):
+        n = len(d)
+        return sum(d[i] * (inv[i, :i] @ d[:i] + 0.5 * inv[i, i] * d[i]) for i in range(n)), np.array([L[i, :i + 1] @ z[:i + 1] for i in range(n)])
+
+    for na, nb in ((40, 40), (40, 73)):
+        sa, sb = eng.par_create(), eng.par_create()
+        assert sa != sb
+        (inv_a, L_a), (inv_b, L_b) = handler(na, 0.3), handler(nb, 0.7)
+        eng.par_upload(sa, 0, inv_a); eng.par_upload(sa, 1, L_a)
+        eng.par_upload(sb, 0, inv_b); eng.par_upload(sb, 1, L_b)       # equal n: must not overwrite slot a's matrices
+        for step in range(4):
+            da, za, db, zb = rng.standard_normal(na), rng.standard_normal(na), rng.standard_normal(nb), rng.standard_normal(nb)
+            eng.par_launch(sa, da, za)
+            eng.par_launch(sb, db, zb)                                   # before slot a's result was read
+            pa, ta = eng.par_result(sa, na)
+            pb, tb = eng.par_result(sb, nb)
+            ra, rta = ref(inv_a, L_a, da, za)
+            rb, rtb = ref(inv_b, L_b, db, zb)
+            assert abs(pa - ra) <= 1e-12 * max(abs(ra), 1) and abs(pb - rb) <= 1e-12 * max(abs(rb), 1), (na, nb, step)
+            assert np.allclose(ta, rta, rtol=1e-12, atol=1e-13) and np.allclose(tb, rtb, rtol=1e-12, atol=1e-13)
+        eng.par_destroy(sa)
+        eng.par_destroy(sb)
 
 
 @pytest.mark.gpu

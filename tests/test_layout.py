@@ -448,6 +448,9 @@ def test_short_bricks_near_the_end_of_a_launch(monkeypatch, groups, n_events, sh
     (1_250_000, 131072, 1, 1221),           # 4.8 rounds: too few (measured 2 % worse with short bricks)
     (5120 * 1024, 131072, 1, 5120),         # a multiple already
     (100_000_000, 131072, 1, 97657),        # 381 bricks per unit
+    (2100 * 4096, 129 * 1024, 4, 2304),     # chunks that are no multiple of the brick (129 x 1024 events at G = 4): every chunk ends in a
+                                            # 1024-event brick of its own (66 chunks x 33 = 2 148 bricks), the stretch starts on chunk-local boundaries
+    (5150 * 2048, 131 * 1024, 2, 5376),     # ... at G = 2 (78 chunks x 66 bricks + 41 = 5 189)
 ])
 def test_brick_count_is_a_multiple_of_the_compute_units(events, chunk, groups, bricks):
     """the rule itself, walked chunk by chunk on the host (ShortBrickPlan through m3hip_debug_short_brick_plan)"""
@@ -457,7 +460,8 @@ def test_brick_count_is_a_multiple_of_the_compute_units(events, chunk, groups, b
     nb, ns = C.c_uint64(0), C.c_uint64(0)
     assert lib.m3hip_debug_short_brick_plan(events, chunk, groups, 256, C.byref(nb), C.byref(ns)) == 0
     assert nb.value == bricks
-    full = -(-events // (1024 * groups))
+    B = 1024 * groups
+    full = events // chunk * -(-chunk // B) + -(-(events % chunk) // B) if chunk < events else -(-events // B)   # bricks are cut chunk by chunk
     assert ns.value == 4 * (bricks - full)              # a conversion of three full bricks into four short ones gains one
     if bricks != full:
         assert bricks % 256 == 0
