@@ -99,7 +99,7 @@ build/two_samples_one_fitter: examples/two_samples_one_fitter.cpp include/mach3_
 .PHONY: examples
 
 # calibration programs behind the ceilings quoted in DESIGN.md / profiles/README.md (run on an MI355X)
-TOOLS = build/sector_fetch build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths build/hbm_width_bw build/mall_probe
+TOOLS = build/sector_fetch build/hbm_read_bw build/hbm_chunk_bw build/hbm_run_bw build/hbm_group_bw build/fetch_size_widths build/hbm_width_bw build/mall_probe build/step_floor
 tools: $(TOOLS)
 build/%: tools/%.hip
 	@mkdir -p build

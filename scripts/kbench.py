@@ -8,6 +8,8 @@
     python scripts/kbench.py modes  [--events 1000000]                    engine-side grouping of shuffled interaction modes
     python scripts/kbench.py mix    [--events 2000000]                    brick kernel: short / long runs x with / without TF1 responses
     python scripts/kbench.py det    [--config c2,c3]                      cost of the deterministic fill
+    python scripts/kbench.py tilebrick [--events 1000000]                 a sample of uniform tiles AND bricks (mode-sorted events + a ragged
+                                                                          remainder): the two launches of a step against each half alone
 
 Two builds are compared by running the script twice in ONE gpurun call with M3HIP_LIB=<path to the other libm3hip.so>
 (boxes of the pool differ by 2-3 %).  Debug knobs of the uniform kernel: --unroll 8|16, --no-nt, --lds-pad BYTES."""
@@ -25,7 +27,7 @@ from mach3_amd import capi, synth
 from mach3_amd.engine import Engine, SMonolith, SampleHandlerFD, build_from_synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("what", choices=["shard", "occ", "step", "pad", "modes", "det", "mix"])
+ap.add_argument("what", choices=["shard", "occ", "step", "pad", "modes", "det", "mix", "tilebrick"])
 ap.add_argument("--config", default=None)
 ap.add_argument("--events", type=int, default=None)
 ap.add_argument("--unroll", type=int, default=8)
@@ -156,3 +158,46 @@ elif args.what == "det":
             k, st = kernel_us(eng, sh, par, laps, n=200)
             print(f"[{LIB}] {cfg} E={spec.n_events} deterministic={det}: step {st:.1f} us (kernel {k:.1f} us)", flush=True)
         eng.close()
+elif args.what == "tilebrick":
+    # What real MC looks like once it is mode-sorted: most events in uniform tiles (four interaction modes, 96 of 128 parameters
+    # each), a ragged remainder (every parameter with probability 0.3) in bricks.  A step launches k_reweight_uniform and then
+    # k_reweight_brick on one stream: is the sum of the two launches the sum of the halves alone?
+    E, P, K, L = args.events or 1_000_000, 128, 7, 96
+    rng = np.random.default_rng(7)
+    modes = [np.sort(rng.choice(P, L, replace=False)).astype(np.int16) for _ in range(4)]
+
+    def chunk(lists):
+        cnt = np.array([len(l) for l in lists], np.uint32)
+        pn = np.concatenate(lists).astype(np.int16) if len(lists) else np.zeros(0, np.int16)
+        S = len(pn)
+        start = np.concatenate([[0], np.cumsum(cnt[:-1], dtype=np.uint64)]).astype(np.uint32)
+        return dict(n_events=len(lists), n_splines=S, n_tf1=0, total_nknots=S * K, coeff_many=(1 + 0.01 * rng.standard_normal(S * K * 4)).astype(np.float32),
+                    nknots_arr=(np.arange(S, dtype=np.uint64) * K).astype(np.uint32), param_no=pn, coeff_tf1=np.zeros(0, np.float32),
+                    param_no_tf1=np.zeros(0, np.int16), npe_tf1=np.zeros(2 * len(lists), np.uint32), npe=np.stack([cnt, start], axis=1).reshape(-1))
+
+    def lists_of(n_tile, n_ragged):
+        which = np.sort(rng.integers(0, 4, n_tile))
+        out = [modes[m] for m in which]
+        for _ in range(n_ragged):
+            out.append(np.flatnonzero(rng.random(P) < 0.3).astype(np.int16))
+        return out
+    cx, npts = np.tile(np.arange(-3.0, 4.0, dtype=np.float32), P), np.full(P, K, np.int16)
+    n_t = int(0.8 * E) // 1024 * 1024
+    res = {}
+    for label, nt_, nr_ in (("tiles + bricks", n_t, E - n_t), ("the tiles alone", n_t, 0), ("the bricks alone", 0, E - n_t)):
+        ev = lists_of(nt_, nr_)
+        eng = Engine(0)
+        mono = SMonolith(eng, P, K, cx, npts, [chunk(ev[i:i + 131072]) for i in range(0, len(ev), 131072)])
+        par = np.zeros(P)
+        mono.setSplinePointers(par)
+        sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kPoisson)
+        sh.SetupEvents(0, rng.integers(0, 200, len(ev)).astype(np.int32), None, None, None)
+        sh.Reweight(); sh.AddData(sh.GetMCArray())
+        laps = [rng.normal(0, 0.3, P) for _ in range(16)]
+        k, st = kernel_us(eng, sh, par, laps, n=200)
+        res[label] = (k, st)
+        line(label, eng.info(), k, st)
+        eng.close()
+    both, a, b = res["tiles + bricks"], res["the tiles alone"], res["the bricks alone"]
+    print(f"[{LIB}] the two launches together {both[0]:.1f} us (first dispatch's start -> second's end) against {a[0]:.1f} + {b[0]:.1f} = {a[0] + b[0]:.1f} us alone "
+          f"({100 * (both[0] / (a[0] + b[0]) - 1):+.1f} %); step {both[1]:.1f} us against {a[1]:.1f} / {b[1]:.1f} us", flush=True)
