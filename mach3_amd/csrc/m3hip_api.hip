@@ -44,6 +44,7 @@ using namespace m3hip;
 namespace {
 
 constexpr int kRing = 4;  // parameter staging slots in flight
+constexpr int kOscStaticSteps = 2;        // reweights an oscillation table must have been left alone before it counts as pre-staged
 constexpr int kInlineResolveMax = 8192;  // unique slots resolved inside k_prep; beyond that k_resolve runs
 
 struct Chunk {
@@ -165,6 +166,7 @@ struct m3hip_ctx {
   uint64_t* d_evw = nullptr;      // packed {bin, osc, norm indices} per event (ReweightArgs::evw)
   bool evw_dirty = true;          // d_bin / d_osc / d_nidx changed since d_evw was packed
   bool evw_ok = false;            // the sample fits the packed word's fields
+  bool evw_weight = false;        // d_evw as packed: the words carry the oscillation WEIGHT (ReweightArgs::evw_weight), not the index
   char sw_packed = '1', sw_rebin = 'p';  // M3HIP_PACKED_EVENTS / M3HIP_REBIN as they stood at monolith_begin (experiments, tests): the step path reads no environment
   bool bins_in_word = false;      // the last re-binning pass wrote the words' bin field only: d_bin is stale (bins_from_word)
   uint32_t evw_norm_slots = 0;    // norm slots the word carries: M3_EVW_NORM_SLOTS, or 0 when the sample's norm indices do not fit its codes
@@ -506,6 +508,7 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_evw); h->d_evw = nullptr;
   h->evw_dirty = true;
   h->evw_ok = false;
+  h->evw_weight = false;
   h->bins_in_word = false;
   h->min_norm_idx = INT64_MAX;
   h->max_norm_idx_evw = -1;
@@ -595,7 +598,7 @@ int bins_from_word(m3hip_handle h) {
   if (!h->bins_in_word) return M3HIP_OK;
   h->bins_in_word = false;
   if (!h->d_evw || !h->d_bin) return M3HIP_OK;
-  launch_unpack_bins(h->d_evw, h->d_bin, h->E, h->stream);
+  launch_unpack_bins(h->d_evw, h->d_bin, h->E, h->evw_weight ? kEvwBinMaskWeight : kEvwBinMask, h->stream);
   HIPCHK(h, hipGetLastError());
   return M3HIP_OK;
 }
@@ -1918,6 +1921,7 @@ int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) try {
   h->osc_valid_f64 = false;
   h->oscw_valid = false;
   h->osc_static_steps = 0;
+  if (h->evw_weight) h->evw_dirty = true;  // the packed words carry weights of the table that was just replaced
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -1932,6 +1936,7 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) try
   h->osc_valid_f32 = false;
   h->oscw_valid = false;
   h->osc_static_steps = 0;
+  if (h->evw_weight) h->evw_dirty = true;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -2177,16 +2182,31 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   // The brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields:
   // (re)built here when one of the three arrays changed (set-up time).
   const bool packed_fit = evw_fits(h);
+  // A pre-staged oscillation table that has been left alone for a few steps -- a fit that moves oscillation parameters re-uploads
+  // it every step and never gets here -- is folded INTO the packed words: they then carry the event's weight instead of its index
+  // (ReweightArgs::evw_weight; needs a bin space below 2^14), the brick kernel looks nothing up, and a table too large to stay in
+  // L2 (BASELINE configs[4]: 204 000 entries) needs no 4-byte column beside the word.  Table or indices touched again: back to
+  // the index form at the next reweight (one packing pass each way).  M3HIP_OSC_COLUMN = 0 never, 1 at once.
+  const bool osc_static_counts = !h->f64 && !h->h_bricks.empty() && h->n_osc && h->d_osc && h->oscw_mode != 0;
+  if (osc_static_counts) ++h->osc_static_steps;
+  const bool osc_is_static = osc_static_counts && h->osc_valid_f32 && (h->oscw_mode == 1 || h->osc_static_steps > kOscStaticSteps);
+  // (tables that stay in L1 / L2 keep the index form: config 3's 16 KB table measured level either way, 700.4 / 701.9 us)
+  const bool osc_large = sizeof(float) * h->n_osc > 64 * 1024;
+  const bool want_weight = osc_is_static && (osc_large || h->oscw_mode == 1) && packed_fit && h->n_bins < (1 << 14) - 2 && h->max_bin_idx < (1 << 14) - 2;
+  if (want_weight != h->evw_weight) h->evw_dirty = true;
   if (!h->f64 && !h->h_bricks.empty() && h->evw_dirty) {
     h->evw_ok = packed_fit;
     // norm parameters spread over more than 62 indices do not fit the word's 6-bit codes: the word then carries bin and
     // oscillation index only, and the kernel's tail reads every norm slot from the index planes
     h->evw_norm_slots = (h->max_norm_idx_evw < 0 || h->max_norm_idx_evw - h->min_norm_idx <= 62) ? uint32_t(M3_EVW_NORM_SLOTS) : 0u;
     if (h->sw_packed == 'b') h->evw_norm_slots = 0;  // M3HIP_PACKED_EVENTS=b: bin and oscillation index only (tests)
+    if (int rc_b = bins_from_word(h)) return rc_b;  // (bins that live in the words only -- in the form they were packed in -- into d_bin before the words are rebuilt)
+    h->evw_weight = false;
     if (h->evw_ok) {
       if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
       launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
-                         int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+                         int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, want_weight ? h->d_osc_table : nullptr, h->stream);
+      h->evw_weight = want_weight;
     }
     h->evw_dirty = false;
   }
@@ -2211,6 +2231,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (dyn_pass) {
     BinArgs b = make_bin_args(h);
     b.compute_nominal = 0;
+    b.word_bin_mask = h->evw_weight ? kEvwBinMaskWeight : kEvwBinMask;
     if (word_valid && h->h_tiles.empty()) {  // bricks only: nothing but the words needs the bins
       if (use_lds) {
         launch_rebin_lds(b, h->d_evw, int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), h->stream);
@@ -2223,7 +2244,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       else launch_find_bins(b, h->stream);
       if (word_valid)  // (mixed tiles and bricks: the words follow the bins; rare)
         launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
-                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->stream);
+                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->evw_weight ? h->d_osc_table : nullptr, h->stream);
     }
   }
   const double t_c = now_s();
@@ -2237,14 +2258,13 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       h->osc_valid_f32 = true;
     }
   }
-  // A large oscillation table does not stay in L2 beside the brick kernel's streams, and every event's gather from it then
-  // goes to memory (one GPU's share of config 5, 204 000 entries: 5.5 % of the kernel).  Once table and indices have been
-  // left alone for two steps -- a pre-staged table; a fit that moves oscillation parameters re-uploads it every step and never
-  // gets here -- the weights are gathered ONCE into a per-event column the kernel streams (4 B per event).
-  if (!h->f64 && !h->h_bricks.empty() && h->n_osc && h->d_osc && h->oscw_mode != 0) {
-    ++h->osc_static_steps;
+  // Engines whose brick kernel reads the UNPACKED sample side (a sample that does not fit the word's fields, or a bin space of
+  // 2^14 and more): a large static table is gathered ONCE into a per-event column the kernel streams (4 B per event) -- it does not
+  // stay in L2 beside the streams, and every event's gather from it then goes to memory (round 4, one GPU's share of config 5:
+  // 5.5 % of the kernel).  With the packed word the weight travels in the word itself (above).
+  if (osc_static_counts && !(word_valid && h->evw_weight)) {
     const bool large = sizeof(float) * h->n_osc > 64 * 1024;
-    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && h->osc_static_steps > 2))) {
+    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && osc_is_static))) {
       if (!h->d_oscw && (rc = dev_alloc(h, &h->d_oscw, size_t(h->E_pad)))) return rc;
       launch_osc_expand(h->d_osc, h->d_osc_table, h->d_oscw, h->E_pad, h->stream);
       h->oscw_valid = true;
@@ -2272,12 +2292,13 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.dyn = make_bin_args(h);
     a.dyn.compute_nominal = 0;
   }
-  if (h->oscw_valid && !h->f64) a.oscw = h->d_oscw;
+  if (h->oscw_valid && !h->f64 && !(word_valid && h->evw_weight)) a.oscw = h->d_oscw;
   a.nt_codes = choose_nt_codes(h, word_valid);
   h->last_nt_codes = a.nt_codes;
   h->last_cached_bytes = h->h_bricks.empty() ? 0 : h->re_tables + (word_valid ? 8 * h->E : 0) + h->re_book + (a.nt_codes ? 0 : h->re_codes);
   if (word_valid) {
     a.evw = h->d_evw;
+    a.evw_weight = h->evw_weight ? 1u : 0u;
     a.evw_norm_base = int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx);
     a.evw_norm_slots = h->evw_norm_slots;
   }

@@ -103,6 +103,8 @@ struct BinArgs {
   int32_t kin_stride;
   int32_t compute_nominal;   // 1: set-up pass, fill nom_bin with upper_bound; 0: per-step pass using nom_bin
   uint64_t n_events;
+  uint64_t word_bin_mask;    // re-binning into the packed words: the bits of a word that hold bin + 1 (0xFFFFF, or 0x3FFF when the words
+                             // carry the oscillation weight: ReweightArgs::evw_weight)
 };
 void launch_find_bins(const BinArgs& a, hipStream_t s);
 // per-step re-binning straight into the bin field of the events' packed sample words (ReweightArgs::evw)
@@ -111,7 +113,7 @@ void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s);
 bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform);
 void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s);
 void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint64_t n, hipStream_t s);
-void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream_t s);
+void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, uint64_t bin_mask, hipStream_t s);
 // whether the brick kernel re-bins in its own tail (launch_reweight_brick with dyn_bins) for this shape of sample
 bool brick_can_rebin(uint32_t brick_groups, bool packed_word);
 
@@ -145,7 +147,13 @@ struct ReweightArgs {
   // The three arrays above as ONE 8-byte word per event (brick kernel; null when a sample does not fit the fields):
   // bin + 1 in bits 0..19, osc + 1 in bits 20..43, up to three norm indices in bits 44..61 as 6-bit codes idx - evw_norm_base + 1
   // (0: none).  14 B -> 8 B per event; rebuilt on the device (k_pack_events) whenever one of the arrays changes.
+  // evw_weight = 1 (round 5): the word carries the event's oscillation WEIGHT instead of its index -- bin + 1 in bits 0..13, the
+  // three norm codes in bits 14..31, the weight's float bits in the high dword (1.0f for an event without an oscillation pointer:
+  // multiplying by it leaves the product's bits alone).  What the engine packs once a pre-staged table has stopped changing
+  // (m3hip_api.hip): no gather from the table per event, and no separate 4-byte column beside the word for a table too large
+  // to stay in L2 (BASELINE configs[4]: 204 000 entries).  Needs a bin space below 2^14.
   const uint64_t* evw;
+  uint32_t evw_weight;
   // brick kernel: 1 = the TF1 codes are loaded non-temporally, around the Infinity Cache -- the engine's choice when the small
   // streams a step re-reads do not all fit its budget there (m3hip_api.hip: choose_nt_codes); the large streams always are
   uint32_t nt_codes;
@@ -272,8 +280,10 @@ struct LlhArgs {
   uint64_t ticket;
 };
 
+// osc_table non-null: the words carry the oscillation weight (ReweightArgs::evw_weight)
 void launch_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots, uint64_t e_pad, int32_t norm_base,
-                        uint64_t* out, hipStream_t s);
+                        uint64_t* out, const float* osc_table, hipStream_t s);
+constexpr uint64_t kEvwBinMask = 0xFFFFFull, kEvwBinMaskWeight = 0x3FFFull;
 void launch_prep(const PrepArgs& a, hipStream_t s);
 void launch_resolve(const PrepArgs& a, int32_t n_res, hipStream_t s);
 // run-time tuning knobs of the reweight kernel (m3hip_debug_set_knobs)

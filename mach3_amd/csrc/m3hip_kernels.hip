@@ -161,12 +161,19 @@ __device__ int d_find_bin(const double* e, int N_Bins, double KinVar, int NomBin
   // Samples/SampleStructs.h:577-613.  The range test is written so that a NaN (a non-finite shift parameter, a bad
   // input) is out of range: in the reference's form `x < lo || x >= hi` a NaN passes, upper_bound then returns the
   // last edge and the event lands in bin N_Bins -- the next sample's first bin, or past the bin vector.
+  // The nominal bin first, with two look-ups: a value inside [e[NomBin], e[NomBin + 1]) is inside the axis (the edges ascend), so
+  // the reference's order -- range test, then nominal bin -- gives the same index; a NaN fails both comparisons and reaches the
+  // range test below.  (The re-binning pass walks these tables in LDS, the bins of a wave's 64 events are all over them, and its
+  // time was that of its LDS reads: six per event before, two for an event that stays where it was.)
+  if (NomBin > -1) {
+    const double lower = e[NomBin], upper = e[NomBin + 1];
+    if (KinVar < upper && KinVar >= lower) return NomBin;
+  }
   if (!(KinVar >= e[0] && KinVar < e[N_Bins])) return -1;
   if (NomBin > -1) {
     const double lower = e[NomBin], upper = e[NomBin + 1];
     const double lower_lower = NomBin == 0 ? e[0] : e[NomBin - 1];                       // :615-646
     const double upper_upper = (NomBin + 2 < N_Bins) ? e[NomBin + 2] : ((NomBin + 1 < N_Bins) ? e[NomBin + 1] : -999999.123456);
-    if (KinVar < upper && KinVar >= lower) return NomBin;
     if (KinVar < lower && KinVar >= lower_lower) return NomBin - 1;
     if (KinVar < upper_upper && KinVar >= upper) return NomBin + 1;
   }
@@ -983,18 +990,27 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   };
   auto tail_issue_val = [&]() {
     const ReweightArgs& a = late_args();
+    bool have_w = false;  // (kernel-uniform)
     if ((MODE & (kModeFill | kModeEventW)) && PACK) {
       const uint32_t lo = (uint32_t)t_pack, hi = (uint32_t)(t_pack >> 32);
-      t_bin = (int32_t)(lo & 0xFFFFFu) - 1;
-      t_osc = (int32_t)(((lo >> 20) | (hi << 12)) & 0xFFFFFFu) - 1;
-      t_codes = hi >> 12;  // three 6-bit norm codes: resolved against lds_nv in the tail
+      if (a.evw_weight) {  // the word carries the oscillation weight itself: nothing to look up
+        t_bin = (int32_t)(lo & 0x3FFFu) - 1;
+        t_codes = lo >> 14;
+        t_oscw = __uint_as_float(hi);
+        t_osc = 0;  // (1.0f stands for "no oscillation pointer")
+        have_w = true;
+      } else {
+        t_bin = (int32_t)(lo & 0xFFFFFu) - 1;
+        t_osc = (int32_t)(((lo >> 20) | (hi << 12)) & 0xFFFFFFu) - 1;
+        t_codes = hi >> 12;  // three 6-bit norm codes: resolved against lds_nv in the tail
+      }
     }
     if (MODE & (kModeFill | kModeEventW)) {
       // a sample without oscillated events has no table, one without norm parameters no index array: absent entries
       // read (and drop) the first bytes of the brick descriptors instead -- again no branch around the loads
       const float* ot = a.osc_table ? a.osc_table : (const float*)a.bricks;
       const double* pp = a.params ? a.params : (const double*)a.bricks;
-      if (!a.oscw) t_oscw = ot[t_osc >= 0 ? t_osc : 0];
+      if (!a.oscw && !have_w) t_oscw = ot[t_osc >= 0 ? t_osc : 0];
       if (!PACK) {
 #pragma unroll
         for (int m = 0; m < kTailNorm; ++m) t_nv[m] = pp[t_ni[m] >= 0 ? t_ni[m] : 0];
@@ -1373,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_rebin_pack(BinArgs a, uint64_t* evw) {
   const uint64_t w = evw[ev];  // requested before the binning cascade's dependent look-ups
   const int b = d_event_bin(a, ev);
   a.bin[ev] = b;
-  evw[ev] = (w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+  evw[ev] = (w & ~a.word_bin_mask) | (uint64_t)(uint32_t)(b + 1);
 }
 // The same with the binning tables in LDS (samples, axes, edges, shifts with their parameter values, cuts): the cascade of an
 // event is a chain of dependent look-ups into tables of a few KB, and from L2 that chain -- not the 24-36 B of HBM traffic per
@@ -1431,10 +1447,10 @@ __device__ __forceinline__ int d_event_bin_x(const BinArgs& a, int sid, const do
   }
   return out ? -1 : global + sm.global_offset;  // (uniform samples only: rebin_tables_fit_lds)
 }
-// STRIDE = kin_stride when it is 1 or 2: the workgroups are persistent (the tables come in once), a lane's next event is
-// requested while its current one walks the tables; 0: any stride, one event after the other
+// STRIDE = kin_stride when it is 1 or 2: the workgroups are persistent (the tables come in once), a lane works on U events per
+// round whose loads all go out before the first is looked at; 0: any stride, one event after the other
 template <bool WORD, int STRIDE>
-__global__ __launch_bounds__(1024) void k_rebin_lds(BinArgs a, uint64_t* __restrict__ evw, int n_samples, int n_axes, int n_edges) {
+__global__ __launch_bounds__(1024, 8) void k_rebin_lds(BinArgs a, uint64_t* __restrict__ evw, int n_samples, int n_axes, int n_edges) {
   __shared__ BinSample s_samples[RebinLimits::kSamples];
   __shared__ BinAxis s_axes[RebinLimits::kAxes];
   __shared__ double s_edges[RebinLimits::kEdges];
@@ -1475,38 +1491,69 @@ __global__ __launch_bounds__(1024) void k_rebin_lds(BinArgs a, uint64_t* __restr
       uint64_t w = 0;
       if (WORD) w = evw[ev];
       const int b = d_event_bin(al, ev);
-      if (WORD) evw[ev] = (w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
+      if (WORD) evw[ev] = (w & ~a.word_bin_mask) | (uint64_t)(uint32_t)(b + 1);
       else a.bin[ev] = b;
     }
   } else {
+    // U events per lane and round, and two rounds in flight: round r + 1's loads go out before round r is looked at.  The pass
+    // is a stream of 8 B of kinematics per axis + the 8-byte word per event, and what bounds a stream is the bytes a compute
+    // unit keeps in flight.  Round 4's form -- ONE event per lane, the next one requested ahead -- kept 16 B per lane in flight
+    // (56 us per 1e7 events = 2.8 TB/s of its own bytes); a round of U without look-ahead leaves the memory idle while the
+    // workgroup's waves, all in the same phase, walk the tables.  The wait in front of the conditional stores (a join with a
+    // store on one side: the wait-count pass gives up its count) now comes AFTER the round's table walks, when the look-ahead
+    // has had their time to arrive.
+    constexpr int U = 2;
     const double* __restrict__ kin = a.kin;
     const int32_t* __restrict__ sidp = al.sample_id;
-    struct In { double x[STRIDE]; uint64_t w; int sid; };
-    auto fetch = [&](uint64_t ev, In& in) {
-      const uint64_t e = ev < a.n_events ? ev : a.n_events - 1;  // (past the end: a valid event, dropped)
-      in.sid = sidp ? sidp[e] : 0;
-      // events of samples no shift touches are neither read nor written (one sample: no test, one round trip)
-      const bool moves = sidp ? s_moves[in.sid] != 0 : true;
+    // every workgroup owns ONE contiguous share of the events, in slabs of 1024: the shares differ by a slab at most (dealt round
+    // by round, 1e7 events on 512 workgroups are 3.2 rounds of 6 slabs -- four rounds for some, three for others)
+    const uint64_t n = a.n_events, slabs = (n + 1023u) / 1024u, per = (slabs + gridDim.x - 1) / gridDim.x;
+    const uint64_t s0 = (uint64_t)blockIdx.x * per, s1 = s0 + per < slabs ? s0 + per : slabs;
+    if (s0 >= s1) return;
+    const uint64_t lim = s1 * 1024u < n ? s1 * 1024u : n;  // the share's end
+    const uint64_t bin_mask = a.word_bin_mask;
+    struct Round { double x[U][STRIDE]; uint64_t w[U]; int sid[U]; };
+    auto issue = [&](uint64_t sl, Round& r) {  // loads only (past the share's end: a valid event, dropped)
+      const uint64_t base = sl * 1024u;
 #pragma unroll
-      for (int c = 0; c < STRIDE; ++c) in.x[c] = moves ? kin[e * STRIDE + c] : 0.0;
-      in.w = WORD && moves ? evw[e] : 0;
-      if (!moves) in.sid = -1;
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ev = base + (uint64_t)u * 1024u + t;
+        const uint64_t e = ev < lim ? ev : lim - 1;
+        r.sid[u] = 0;
+        bool moves = true;
+        if (sidp) {  // (kernel-uniform) several samples: only what a registered shift touches is read and written
+          r.sid[u] = sidp[e];
+          moves = s_moves[r.sid[u]] != 0;
+          if (!moves) r.sid[u] = -1;
+        }
+#pragma unroll
+        for (int c = 0; c < STRIDE; ++c) r.x[u][c] = moves ? kin[e * STRIDE + c] : 0.0;
+        r.w[u] = WORD && moves ? evw[e] : 0;
+      }
     };
-    uint64_t ev = (uint64_t)blockIdx.x * 1024u + t;
-    In cur, nxt;
-    fetch(ev, cur);
-    for (; ev < a.n_events; ev += step) {
-      fetch(ev + step, nxt);
-      if (cur.sid >= 0) {
-        const int b = d_event_bin_x<STRIDE>(al, cur.sid, cur.x, WORD ? (int)((uint32_t)cur.w & 0xFFFFFu) - 1 : -1);
-        if (WORD) {  // only events that changed bin are written back
-          const uint64_t w = (cur.w & ~0xFFFFFull) | (uint64_t)(uint32_t)(b + 1);
-          if (w != cur.w) evw[ev] = w;
-        } else {
-          a.bin[ev] = b;
+    auto finish = [&](uint64_t sl, const Round& r) {
+      const uint64_t base = sl * 1024u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ev = base + (uint64_t)u * 1024u + t;
+        if (ev < lim && r.sid[u] >= 0) {
+          const int b = d_event_bin_x<STRIDE>(al, r.sid[u], r.x[u], WORD ? (int)(uint32_t)(r.w[u] & bin_mask) - 1 : -1);
+          if (WORD) {  // only events that changed bin are written back
+            const uint64_t wn = (r.w[u] & ~bin_mask) | (uint64_t)(uint32_t)(b + 1);
+            if (wn != r.w[u]) evw[ev] = wn;
+          } else {
+            a.bin[ev] = b;
+          }
         }
       }
-      cur = nxt;
+    };
+    Round ra, rb;
+    issue(s0, ra);
+    for (uint64_t sl = s0; sl < s1; sl += 2 * U) {
+      issue(sl + U, rb);
+      finish(sl, ra);
+      issue(sl + 2 * U, ra);
+      finish(sl + U, rb);
     }
   }
 }
@@ -1549,13 +1596,13 @@ void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint6
   hipLaunchKernelGGL(k_osc_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, osc, table, out, n);
 }
 // the bin field of the packed words back into `bin` (m3hip_get_event_bins after steps that re-binned into the words only)
-__global__ __launch_bounds__(256) void k_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n) {
+__global__ __launch_bounds__(256) void k_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, uint64_t bin_mask) {
   const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (ev < n) bin[ev] = (int32_t)((uint32_t)evw[ev] & 0xFFFFFu) - 1;
+  if (ev < n) bin[ev] = (int32_t)(uint32_t)(evw[ev] & bin_mask) - 1;
 }
-void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream_t s) {
+void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, uint64_t bin_mask, hipStream_t s) {
   if (n == 0) return;
-  hipLaunchKernelGGL(k_unpack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, evw, bin, n);
+  hipLaunchKernelGGL(k_unpack_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, evw, bin, n, bin_mask);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1563,20 +1610,26 @@ void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, hipStream
 // (ReweightArgs::evw).  Set-up time: runs when one of the three arrays has changed.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots,
-                                                     uint64_t e_pad, int32_t norm_base, uint64_t* out) {
+                                                     uint64_t e_pad, int32_t norm_base, uint64_t* out, const float* osc_table) {
   const uint64_t ev = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (ev >= e_pad) return;
-  uint64_t w = (uint64_t)(uint32_t)(bin[ev] + 1) | ((uint64_t)(uint32_t)(osc[ev] + 1) << 20);
+  uint32_t codes = 0;
   for (uint32_t m = 0; m < n_norm_slots && m < (uint32_t)M3_EVW_NORM_SLOTS; ++m) {
     const int32_t i = nidx[(uint64_t)m * e_pad + ev];
-    w |= (uint64_t)(i >= 0 ? (uint32_t)(i - norm_base + 1) : 0u) << (44 + 6 * m);
+    codes |= (i >= 0 ? (uint32_t)(i - norm_base + 1) : 0u) << (6 * m);
   }
-  out[ev] = w;
+  if (osc_table) {  // the word carries the oscillation weight itself (ReweightArgs::evw_weight); the bin space is below 2^14
+    const int32_t o = osc[ev];
+    const float ow = o >= 0 ? osc_table[o] : 1.0f;
+    out[ev] = (uint64_t)(uint32_t)(bin[ev] + 1) | ((uint64_t)codes << 14) | ((uint64_t)__float_as_uint(ow) << 32);
+    return;
+  }
+  out[ev] = (uint64_t)(uint32_t)(bin[ev] + 1) | ((uint64_t)(uint32_t)(osc[ev] + 1) << 20) | ((uint64_t)codes << 44);
 }
 void launch_pack_events(const int32_t* bin, const int32_t* osc, const int16_t* nidx, uint32_t n_norm_slots, uint64_t e_pad, int32_t norm_base,
-                        uint64_t* out, hipStream_t s) {
+                        uint64_t* out, const float* osc_table, hipStream_t s) {
   if (e_pad == 0) return;
-  hipLaunchKernelGGL(k_pack_events, dim3((unsigned)((e_pad + 255) / 256)), dim3(256), 0, s, bin, osc, nidx, n_norm_slots, e_pad, norm_base, out);
+  hipLaunchKernelGGL(k_pack_events, dim3((unsigned)((e_pad + 255) / 256)), dim3(256), 0, s, bin, osc, nidx, n_norm_slots, e_pad, norm_base, out, osc_table);
 }
 
 // ------------------------------------------------------------------------------------

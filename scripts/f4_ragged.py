@@ -31,14 +31,22 @@ sh.Reweight(); sh.AddData(sh.GetMCArray())
 laps = [synth.params(spec, i + 1) for i in range(16)]
 
 
-def timeit(n=60, spin=20):
+def timeit(n=60, spin=20, walk=0.0):
+    """walk = 0: the scale parameter is drawn afresh every step, N(0, 0.02) -- about half of the events change bin, the pass's worst
+    case; walk > 0: a chain, theta += walk * N(0, 1) (a Metropolis step at ~520 parameters moves each by about a tenth of its width)"""
+    th = 0.0
+
+    def nxt():
+        nonlocal th
+        th = th + walk * rng.standard_normal() if walk else 0.02 * rng.standard_normal()
+        return th
     for i in range(spin):
-        par2[:spec.n_par] = laps[i % 16]; par2[-1] = 0.02 * rng.standard_normal(); sh.Step()
+        par2[:spec.n_par] = laps[i % 16]; par2[-1] = nxt(); sh.Step()
     best = 1e9
     for rep in range(3):
         t = time.perf_counter()
         for i in range(n):
-            par2[:spec.n_par] = laps[i % 16]; par2[-1] = 0.02 * rng.standard_normal(); sh.Step()
+            par2[:spec.n_par] = laps[i % 16]; par2[-1] = nxt(); sh.Step()
         best = min(best, (time.perf_counter() - t) / n * 1e6)
     return best
 
@@ -46,6 +54,8 @@ def timeit(n=60, spin=20):
 a = timeit()
 sh.AddKinShift(-1, 0, 1, spec.n_par)
 b = timeit()
+c = timeit(walk=0.002)
 print(f"[{os.path.basename(os.environ.get('M3HIP_LIB', 'libm3hip.so'))}] f4 on a ragged sample: {cfg} E={n_ev}, bricks {info.n_tiles_brick}, 1-D {spec.total_bins} bins, one scale shift: "
-      f"step {a:.1f} us without, {b:.1f} us with the shift (+{b - a:.1f} us = +{100 * (b - a) / a:.1f} %)", flush=True)
+      f"step {a:.1f} us without, {b:.1f} us with the shift drawn afresh every step (+{b - a:.1f} us = +{100 * (b - a) / a:.1f} %), "
+      f"{c:.1f} us with the shift walking like a chain's (+{c - a:.1f} us = +{100 * (c - a) / a:.1f} %)", flush=True)
 eng.close()

@@ -1475,7 +1475,8 @@ def test_deterministic_fill_needs_the_private_bin_vector(fresh_engine):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_into_word_g2", "lds_pass_into_word_g4", "brick_tail", "global_pass_into_word_g4",
-                                  "lds_pass_no_word", "global_pass_no_word"])
+                                  "lds_pass_no_word", "global_pass_no_word", "lds_pass_weight_words_rule", "lds_pass_weight_words_rule_g4",
+                                  "global_pass_weight_words_forced_g4", "brick_tail_weight_words_forced"])
 def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
     """SURVEY 8f row 4 on a brick sample of a size where the launch has rounds of workgroups (120 000 events of configs[2]'s
     shape): an energy-scale functional parameter re-bins every event every step (ApplyShifts, Samples/SampleHandlerFD.cpp:545-564;
@@ -1494,7 +1495,14 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         monkeypatch.setenv("M3HIP_REBIN", "tail")
     if path.startswith("global"):
         monkeypatch.setenv("M3HIP_REBIN", "global")
-    spec = synth.CONFIGS["c3"].scaled(120_000)
+    if path.startswith("brick_tail"):
+        monkeypatch.setenv("M3HIP_REBIN", "tail")
+    # round 5: a pre-staged oscillation table that rests is folded into the packed words (the weight's float bits instead of the
+    # index, a 14-bit bin field for the passes to write into): by the engine's rule for a LARGE table (200 KB here: index words
+    # for the first laps, weight words from the third reweight on, index words again when the table moves, ...), or forced
+    if "forced" in path:
+        monkeypatch.setenv("M3HIP_OSC_COLUMN", "1")
+    spec = synth.CONFIGS["c3"].scaled(120_000, **({"osc_n": 50_000} if "weight_words_rule" in path else {}))
     E, NP = spec.n_events, spec.n_par
     lib = ob.load("serial")
     cx, npts = synth.knots(spec)
@@ -1531,7 +1539,14 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         osamp.add_data(osamp.mc)
         nominal = osamp.event_bins().copy()
         moved = 0
-        for lap, scale in enumerate([0.0, 0.013, -0.02, 0.2, -0.35, 0.0]):
+        for lap, scale in enumerate([0.0, 0.013, -0.02, 0.2, -0.35, 0.0, 0.05, -0.01, 0.02]):
+            # the oscillation table is left alone for the first laps: from the third reweight on the packed words carry the events'
+            # oscillation WEIGHTS (a 14-bit bin field the pass writes into); at lap 5 the table moves -- back to index words, rebuilt
+            # from the bins the pass had left in the words only -- and then rests again
+            if lap == 5:
+                otbl = osamp.keep[7]
+                otbl[:] = np.random.default_rng(9).random(len(otbl)).astype(np.float32)
+                sh.SetOscillationWeights(otbl)
             par[:NP] = synth.params(spec, 1 + lap)
             par[NP] = scale
             opar[:] = par
@@ -1724,14 +1739,19 @@ def test_two_parameter_handlers_share_one_engine(fresh_engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rule", "always", "never"])
+@pytest.mark.parametrize("mode", ["rule", "always", "never", "rule_unpacked", "always_unpacked"])
 def test_large_static_oscillation_table_becomes_a_per_event_column(mode, monkeypatch):
     """A pre-staged oscillation table of hundreds of KB (BASELINE configs[4]: 204 000 entries) does not stay in L2 beside the
-    brick kernel's streams; once table and indices have been left alone for two steps the engine gathers the weights ONCE into a
-    per-event column the kernel streams.  Same numbers either way: event weights bit-exact against the oracle through the
-    transitions gather -> column -> (table re-uploaded) gather -> column, with events that have no oscillation pointer, zero
-    weights, and a slice of indices re-uploaded.  `M3HIP_OSC_COLUMN` = 1 / 0 forces / forbids the column."""
+    brick kernel's streams; once table and indices have been left alone for two steps the engine folds the weights INTO the events'
+    packed sample words (round 5: the word then carries the weight's float bits instead of the index), or -- samples that do not
+    use the packed word -- gathers them once into a per-event column the kernel streams.  Same numbers either way: event weights
+    bit-exact against the oracle through the transitions gather -> weight words / column -> (table re-uploaded) gather -> ...,
+    with events that have no oscillation pointer, zero weights, and a slice of indices re-uploaded.  `M3HIP_OSC_COLUMN` = 1 / 0
+    forces / forbids it."""
     from mach3_amd.engine import Engine
+    if mode.endswith("_unpacked"):
+        monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
+        mode = mode[:-len("_unpacked")]
     if mode != "rule":
         monkeypatch.setenv("M3HIP_OSC_COLUMN", "1" if mode == "always" else "0")
     # 200 KB of weights: "large" by the engine's rule.  Poisson: the oracle sample is re-created half way (new indices), and a
