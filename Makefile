@@ -13,10 +13,20 @@ HIPFLAGS = --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -munsaf
 
 all: $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so oracle
 
-$(LIBDIR)/libm3hip.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp \
-                       $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+# the engine: one object per translation unit (make -j builds them side by side; the kernels take the longest), one link
+ENGINE_TUS = m3hip_api m3hip_upload m3hip_sample m3hip_step m3hip_comm m3hip_par m3hip_kernels
+ENGINE_SRC = $(ENGINE_TUS:%=$(CSRC)/%.hip) $(CSRC)/m3hip_layout.cpp
+ENGINE_HDR = $(CSRC)/m3hip_ctx.h $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+ENGINE_OBJ = $(ENGINE_TUS:%=build/obj/%.o) build/obj/m3hip_layout.o
+build/obj/%.o: $(CSRC)/%.hip $(ENGINE_HDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+build/obj/m3hip_layout.o: $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_layout.h
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
+$(LIBDIR)/libm3hip.so: $(ENGINE_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINE_OBJ) -ldl -lpthread
 
 $(LIBDIR)/libm3synth.so: mach3_amd/synth/m3synth.c mach3_amd/synth/m3synth.h
 	@mkdir -p $(LIBDIR)
@@ -27,20 +37,20 @@ oracle:
 
 # diagnostic build of the engine with phase stamps in the brick kernel (scripts/brick_stamps.py)
 stamps: build/libm3hip_stamps.so
-build/libm3hip_stamps.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+build/libm3hip_stamps.so: $(ENGINE_SRC) $(ENGINE_HDR)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_STAMPS -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_STAMPS -shared -o $@ $(ENGINE_SRC) -ldl -lpthread
 
 # diagnostic build: the brick kernel without arithmetic and LDS traffic (loads, waits and barriers only) -- the memory side's share
 hollow: build/libm3hip_hollow.so
-build/libm3hip_hollow.so: $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp $(CSRC)/m3hip_kernels.h $(CSRC)/m3hip_layout.h include/m3hip.h
+build/libm3hip_hollow.so: $(ENGINE_SRC) $(ENGINE_HDR)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW=$(or $(HOLLOW),1) -shared -o $@ $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+	$(HIPCC) $(HIPFLAGS) -DM3_BRICK_HOLLOW=$(or $(HOLLOW),1) -shared -o $@ $(ENGINE_SRC) -ldl -lpthread
 
 # experiment build: make variant NAME=foo XDEF="-DM3X_FOO" -> build/libm3hip_foo.so (load with M3HIP_LIB; scripts/gexp.py)
 variant:
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) $(XDEF) -shared -o build/libm3hip_$(NAME).so $(CSRC)/m3hip_api.hip $(CSRC)/m3hip_kernels.hip $(CSRC)/m3hip_layout.cpp -ldl -lpthread
+	$(HIPCC) $(HIPFLAGS) $(XDEF) -shared -o build/libm3hip_$(NAME).so $(ENGINE_SRC) -ldl -lpthread
 
 isa: $(CSRC)/m3hip_kernels.hip
 	@mkdir -p build

@@ -454,7 +454,7 @@ int m3hip_debug_host_times(m3hip_handle h, double* out6);
  * clock at k_prep start, at k_llh end, host clock at the k_prep launch, at completion seen}. */
 int m3hip_debug_device_span(m3hip_handle h, int enable, double* last_us);
 
-/* Host-only probe of the rule that evens out a brick launch (m3hip_api.hip, ShortBrickPlan): the bricks an all-ragged
+/* Host-only probe of the rule that evens out a brick launch (m3hip_upload.hip, ShortBrickPlan): the bricks an all-ragged
  * sample of expect_events events ends up in when it arrives in chunks of chunk_events events on a device of n_cu compute
  * units, bricks of brick_groups x 1024 events; n_short: how many of them are three-quarter bricks.  Used by the CPU tests. */
 int m3hip_debug_short_brick_plan(uint64_t expect_events, uint64_t chunk_events, int brick_groups, int n_cu,

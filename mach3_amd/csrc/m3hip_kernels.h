@@ -150,12 +150,12 @@ struct ReweightArgs {
   // evw_weight = 1 (round 5): the word carries the event's oscillation WEIGHT instead of its index -- bin + 1 in bits 0..13, the
   // three norm codes in bits 14..31, the weight's float bits in the high dword (1.0f for an event without an oscillation pointer:
   // multiplying by it leaves the product's bits alone).  What the engine packs once a pre-staged table has stopped changing
-  // (m3hip_api.hip): no gather from the table per event, and no separate 4-byte column beside the word for a table too large
+  // (m3hip_step.hip): no gather from the table per event, and no separate 4-byte column beside the word for a table too large
   // to stay in L2 (BASELINE configs[4]: 204 000 entries).  Needs a bin space below 2^14.
   const uint64_t* evw;
   uint32_t evw_weight;
   // brick kernel: 1 = the TF1 codes are loaded non-temporally, around the Infinity Cache -- the engine's choice when the small
-  // streams a step re-reads do not all fit its budget there (m3hip_api.hip: choose_nt_codes); the large streams always are
+  // streams a step re-reads do not all fit its budget there (m3hip_step.hip: choose_nt_codes); the large streams always are
   uint32_t nt_codes;
   int32_t evw_norm_base;
   uint32_t evw_norm_slots;  // norm slots held in the word (M3_EVW_NORM_SLOTS or 0); an event's further slots are read from nidx

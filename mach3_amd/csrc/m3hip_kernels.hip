@@ -563,7 +563,7 @@ constexpr size_t kBrickStaticLds = sizeof(float) * (M3_STAGE_CAP + kBrickEllSlac
                                    4 * 64 + 4 * ((size_t)kBrickThreads + 32) + 2 * 512 * (size_t)M3_BRICK_MAX_GROUPS;
 static_assert(kBrickStaticLds + M3_HIST_LDS_MAX_BYTES <= 80 * 1024, "two brick workgroups per CU: static LDS + the largest LDS bin vector must fit 80 KB");
 // Idle lanes do not branch around their loads (see the note in the kernel): they read a few KB past the list they index.
-// m3hip_api.hip allocates every chunk's stores with this much room behind them.
+// m3hip_upload.hip allocates every chunk's stores with this much room behind them.
 static_assert(M3_STORE_SLACK_BYTES >= 2 * M3_STAGE_CAP + 8 * kBrickThreads, "room behind the stores for idle lanes' reads");
 
 // Diagnostic build only (-DM3_BRICK_STAMPS, `make stamps`): lane 0 of every brick records the 100 MHz wall clock at the
@@ -612,7 +612,7 @@ __device__ __forceinline__ const M3_GLOBAL T* uniform_base(const M3_GLOBAL T* p)
 // evicts it (tools/mall_probe.hip), so the two large streams a step reads once besides the coefficients -- the TF1 rows (1.28 GB
 // per step of config 3) and the response words (350 MB) -- are loaded non-temporally like the coefficients, and the small ones a
 // step re-reads -- the stages' tables, the sample words, the TF1 bookkeeping, and the TF1 codes when they still fit the engine's
-// budget (template parameter NTC = they do not: m3hip_api.hip choose_nt_codes) -- then stay there from step to step and come back
+// budget (template parameter NTC = they do not: m3hip_step.hip choose_nt_codes) -- then stay there from step to step and come back
 // in 545 instead of 900+ cycles, which is what a compute unit's outstanding misses turn into bandwidth (round 4, config 3:
 // 712 -> 682-690 us).  NTC is a template parameter: as a kernel argument with a branch per load it cost 1 %.
 struct RRun {      // per-step resolved run: quad address = base + r, dx of the run's parameter
@@ -1338,7 +1338,7 @@ static void launch_brick_g(const ReweightArgs& a, dim3 g, size_t lds, const Rewe
   constexpr bool kSampleSide = (MODE & (kModeFill | kModeEventW)) != 0;  // only these read the packed word
   if constexpr (DYN) {
     // the events' bins from their shifted kinematics in the slab's tail (d_event_bin): only G = 1 with the packed word fits the
-    // registers (no scratch; G = 4: 53 spilled); every other shape is re-binned by a pass of its own (m3hip_api.hip)
+    // registers (no scratch; G = 4: 53 spilled); every other shape is re-binned by a pass of its own (m3hip_step.hip)
     static_assert(G == 1 && kSampleSide, "the fused re-binning exists for bricks of 1024 events with the packed sample word");
     if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, true, 1, true>), g, b, lds, s, k, a);
     else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true, true>), g, b, lds, s, k, a);

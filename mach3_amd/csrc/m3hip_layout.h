@@ -154,7 +154,7 @@ extern int g_pad_runs;  // runs padded to whole lines in the stages' response li
 // holds falls back to a smaller G.
 // [short_from, short_to): chunk-local events (multiples of M3_TE) whose bricks are cut at three quarters of the size -- four short
 // bricks where three full ones would be -- and whose ends no brick spans: the engine's way of handing every compute unit the same
-// number of bricks (m3hip_api.hip: ShortBrickPlan)
+// number of bricks (m3hip_upload.hip: ShortBrickPlan)
 bool plan_chunk(int n_params, int max_knots, const int16_t* npts, const ChunkInput& in, ChunkPlan* plan,
                 std::string* err, int brick_groups = 1, uint64_t short_from = ~0ull, uint64_t short_to = ~0ull);
 

@@ -133,7 +133,7 @@ def test_config3_full_size_properties():
     assert info.brick_groups == 1 and info.n_tiles_brick == (E + 1023) // 1024 and info.n_tiles_uniform == 0
     assert info.n_splines * spec.n_knots * 4 > 2 ** 32
     # the small streams a step re-reads: stage tables + sample words + TF1 bookkeeping stay in the Infinity Cache (about 165 MB),
-    # the TF1 codes (176 MB more) do not fit beside them and go around it (m3hip_api.hip choose_nt_codes)
+    # the TF1 codes (176 MB more) do not fit beside them and go around it (m3hip_step.hip choose_nt_codes)
     assert info.tf1_codes_around == 1 and 150e6 < info.cached_stream_bytes < 200e6
 
 
@@ -168,7 +168,7 @@ def test_more_than_1024_parameters_at_mid_size():
 
 def test_short_bricks_even_out_a_launch_at_mid_size(monkeypatch):
     """250 bricks' worth of config-3 events on 256 compute units, the engine's rule for an even launch forced on (it asks for eight
-    rounds otherwise): told the size, the engine converts 18 full bricks near the end into 24 of 768 events (m3hip_api.hip
+    rounds otherwise): told the size, the engine converts 18 full bricks near the end into 24 of 768 events (m3hip_upload.hip
     ShortBrickPlan) -- one brick per unit; the short bricks' events (the last windows) bit for bit against the serial oracle,
     conservation, W2 freeze as for every other sample.  config 4's share of one GPU in eight (5e6 events) gets the rule by itself:
     test_config4_shard_properties."""

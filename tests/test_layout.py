@@ -425,7 +425,7 @@ def test_bricks_of_several_event_groups(monkeypatch, groups, n_events, cfg):
 def test_short_bricks_near_the_end_of_a_launch(monkeypatch, groups, n_events, short_from, short_to, sizes):
     """Between two given events the planner cuts bricks at three quarters of their size, four where three full ones would be (the
     engine asks for that when it knows the sample's size, so that every compute unit gets the same number of bricks:
-    m3hip_api.hip ShortBrickPlan); no brick spans the stretch's ends, and the short bricks replay event by event like the full ones."""
+    m3hip_upload.hip ShortBrickPlan); no brick spans the stretch's ends, and the short bricks replay event by event like the full ones."""
     monkeypatch.setenv("M3HIP_BRICK_GROUPS", str(groups))
     monkeypatch.setenv("M3HIP_DEBUG_SHORT_FROM", str(short_from))
     monkeypatch.setenv("M3HIP_DEBUG_SHORT_TO", str(short_to))
