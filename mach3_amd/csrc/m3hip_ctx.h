@@ -248,7 +248,7 @@ struct m3hip_ctx {
   uint64_t re_tables = 0, re_book = 0, re_codes = 0;  // bytes of the bricks' small re-read streams (stage tables, TF1 bookkeeping, TF1 codes)
   uint64_t last_cached_bytes = 0, last_nt_codes = 0;  // what the last fused reweight planned (m3hip_get_info)
   int nt_force = -1;              // M3HIP_NT_MASK = 0 | 4: the TF1 codes cached / around the Infinity Cache instead of the engine's choice (experiments)
-  double cached_mb = 200.0;       // M3HIP_CACHED_MB: what the engine plans to keep in the Infinity Cache from step to step
+  double cached_mb = 200.0;       // what the engine plans to keep in the Infinity Cache from step to step (of its 256 MB)
   uint64_t n_grouped_chunks = 0;
 
   // device-side binning (optional): axes, nominal kinematics, shifts

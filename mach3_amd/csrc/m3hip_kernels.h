@@ -114,8 +114,6 @@ bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, 
 void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s);
 void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint64_t n, hipStream_t s);
 void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, uint64_t bin_mask, hipStream_t s);
-// whether the brick kernel re-bins in its own tail (launch_reweight_brick with dyn_bins) for this shape of sample
-bool brick_can_rebin(uint32_t brick_groups, bool packed_word);
 
 // One experiment weight beyond oscillation and splines (SampleHandlerFD::AddAdditionalWeightPointers appends such pointers to
 // total_weight_pointers, Samples/SampleHandlerFD.cpp:196; CalcWeightFunc refreshes what they point at, SampleHandlerFD.h:289):
@@ -299,7 +297,7 @@ struct ReweightKnobs {
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
 // float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
-void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 // dynamic LDS of a fill launch and whether the bin vector is privatised there (see ReweightArgs::hist_lds)
 constexpr int M3_HIST_LDS_MAX_BYTES = 20 * 1024;
 void launch_llh(const LlhArgs& a, hipStream_t s);

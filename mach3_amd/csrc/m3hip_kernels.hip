@@ -654,7 +654,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // separate instantiation, because a run-time branch around those loads would cost the common case its counted waits
 // PACK: the event's bin, oscillation index and norm indices come as one 8-byte word (ReweightArgs::evw) instead of from three
 // arrays; a template parameter, because both forms in one kernel cost the slabs' tails more registers than there are
-template <int MODE, bool NT, bool DYN = false, bool BIGP = false, int G = 1, bool PACK = false, bool NTC = false>
+template <int MODE, bool NT, bool BIGP = false, int G = 1, bool PACK = false, bool NTC = false>
 __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArgs a) {
   __shared__ __attribute__((aligned(16))) float ell[M3_STAGE_CAP + kBrickEllSlack];  // compact scatter array: one slot per response of the stage
   __shared__ RRun lds_runs[2 * kBrickRunSlots];   // resolved run tables of two stages
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         t_ni[m] = has ? (int32_t)v : -1;
       }
     }
-    if ((MODE & kModeFill) && !DYN) t_bin = a.bin[ev_own];
+    if (MODE & kModeFill) t_bin = a.bin[ev_own];
   };
   auto tail_issue_val = [&]() {
     const ReweightArgs& a = late_args();
@@ -1262,13 +1262,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
         if (a.n_extra) tw = mul_extra_weights(tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
         if (MODE & kModeEventW) a.event_w[ev] = tw;
         if (MODE & kModeFill) {
-          int b;
-          if (DYN) {
-            b = d_event_bin(a.dyn, ev);
-            a.dyn.bin[ev] = b;
-          } else {
-            b = bin_h;
-          }
+          const int b = bin_h;
           if (a.partial) {  // deterministic mode: filled below, wave after wave
             det_fill = !(tw <= 0.f) && b >= 0;
             det_b = b;
@@ -1332,53 +1326,42 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   M3_STAMP(11);
 }
 
-template <int MODE, bool DYN, int G>
+template <int MODE, int G>
 static void launch_brick_g(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
   const dim3 b(kBrickThreads);
   constexpr bool kSampleSide = (MODE & (kModeFill | kModeEventW)) != 0;  // only these read the packed word
-  if constexpr (DYN) {
-    // the events' bins from their shifted kinematics in the slab's tail (d_event_bin): only G = 1 with the packed word fits the
-    // registers (no scratch; G = 4: 53 spilled); every other shape is re-binned by a pass of its own (m3hip_step.hip)
-    static_assert(G == 1 && kSampleSide, "the fused re-binning exists for bricks of 1024 events with the packed sample word");
-    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, true, 1, true>), g, b, lds, s, k, a);
-    else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true, true>), g, b, lds, s, k, a);
-    else M3_LAUNCH((k_reweight_brick<MODE, true, true, false, 1, true>), g, b, lds, s, k, a);
-  } else {
-    if (kSampleSide && a.evw) {
-      if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, false, true, G, kSampleSide>), g, b, lds, s, k, a);
-      else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G, kSampleSide, true>), g, b, lds, s, k, a);
-      else M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G, kSampleSide>), g, b, lds, s, k, a);
-      return;
-    }
-    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, false, true, G>), g, b, lds, s, k, a);
-    else if (k.nt || G != 1) M3_LAUNCH((k_reweight_brick<MODE, true, false, false, G>), g, b, lds, s, k, a);
-    else M3_LAUNCH((k_reweight_brick<MODE, false, false, false, 1>), g, b, lds, s, k, a);
+  if (kSampleSide && a.evw) {
+    if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, G, kSampleSide>), g, b, lds, s, k, a);
+    else if (a.nt_codes) M3_LAUNCH((k_reweight_brick<MODE, true, false, G, kSampleSide, true>), g, b, lds, s, k, a);
+    else M3_LAUNCH((k_reweight_brick<MODE, true, false, G, kSampleSide>), g, b, lds, s, k, a);
+    return;
   }
+  if (a.n_params > kBrickLdsParams) M3_LAUNCH((k_reweight_brick<MODE, true, true, G>), g, b, lds, s, k, a);
+  else if (k.nt || G != 1) M3_LAUNCH((k_reweight_brick<MODE, true, false, G>), g, b, lds, s, k, a);
+  else M3_LAUNCH((k_reweight_brick<MODE, false, false, 1>), g, b, lds, s, k, a);
 }
 
-template <int MODE, bool DYN>
+template <int MODE>
 static void launch_brick_mode(const ReweightArgs& a, dim3 g, size_t lds, const ReweightKnobs& k, hipStream_t s) {
-  if (a.brick_groups == 4) launch_brick_g<MODE, DYN, 4>(a, g, lds, k, s);
-  else if (a.brick_groups == 2) launch_brick_g<MODE, DYN, 2>(a, g, lds, k, s);
-  else launch_brick_g<MODE, DYN, 1>(a, g, lds, k, s);
+  if (a.brick_groups == 4) launch_brick_g<MODE, 4>(a, g, lds, k, s);
+  else if (a.brick_groups == 2) launch_brick_g<MODE, 2>(a, g, lds, k, s);
+  else launch_brick_g<MODE, 1>(a, g, lds, k, s);
 }
 
-void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins) {
+// (Samples with bricks and functional shifts are re-binned by a pass of its own in front of this kernel -- k_rebin_lds, k_rebin_pack,
+// k_find_bins below.  Rounds 3-4 could also re-bin in this kernel's tail -- G = 1 with the packed word, no scratch -- and measured it
+// at +159 us per step on config 3 against +60 for the pass: the cascade's look-ups come from L2 there.  Removed in round 5.)
+void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s) {
   if (n_bricks == 0) return;
   size_t lds = ((mode & kModeFill) && a.hist_lds) ? sizeof(double) * (a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
   if (k.lds_pad > 0 && lds < (size_t)k.lds_pad) lds = (size_t)k.lds_pad;  // occupancy throttle (experiments)
   const dim3 g(n_bricks);
-  if (dyn_bins && (mode & kModeFill)) {  // brick_can_rebin() held: the caller ran no pass of its own
-    if (mode == kModeFill) launch_brick_g<kModeFill, true, 1>(a, g, lds, k, s);
-    else launch_brick_g<kModeFill | kModeEval | kModeEventW, true, 1>(a, g, lds, k, s);
-    return;
-  }
-  if (mode == kModeEval) launch_brick_mode<kModeEval, false>(a, g, lds, k, s);
-  else if (mode == kModeFill) launch_brick_mode<kModeFill, false>(a, g, lds, k, s);
-  else launch_brick_mode<kModeFill | kModeEval | kModeEventW, false>(a, g, lds, k, s);
+  if (mode == kModeEval) launch_brick_mode<kModeEval>(a, g, lds, k, s);
+  else if (mode == kModeFill) launch_brick_mode<kModeFill>(a, g, lds, k, s);
+  else launch_brick_mode<kModeFill | kModeEval | kModeEventW>(a, g, lds, k, s);
 }
-bool brick_can_rebin(uint32_t brick_groups, bool packed_word) { return brick_groups <= 1 && packed_word; }
 
+// ------------------------------------------------------------------------------------
 // k_rebin_pack: the per-step re-binning of samples whose brick kernel cannot do it in its tail (G > 1): the event's bin from
 // its shifted kinematics (d_event_bin) straight into the bin field of its packed sample word -- one pass, 8 B read + 8 B
 // written per event beside the kinematics, instead of k_find_bins followed by a full k_pack_events (which re-read the

@@ -144,7 +144,7 @@ struct ChunkPlan {
 constexpr double kPadMinFillDefault = 0.88;
 extern double g_pad_min_fill;
 // TF1 lane-slots by descending code count: 0 never, 1 always, 2 (default) when an event of the brick has more than 16 codes
-// (M3HIP_TF1_SORT; experiments)
+// (the planner's rule; the other two values are for the CPU tests of the layout)
 extern int g_tf1_sort;
 extern int g_pad_runs;  // runs padded to whole lines in the stages' response lists: 0 never, 1 always, 2 where it costs <= 8 % more entries (env M3HIP_PAD_RUNS)
 

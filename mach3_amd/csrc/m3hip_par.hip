@@ -82,10 +82,7 @@ int m3hip_par_upload(m3hip_handle h, int slot, int which, const double* m, int n
   int rc;
   if (p.n != n) {  // (re)size everything
     par_free(h, p);
-    if (!h->par_stream) {
-      const char* f = getenv("M3HIP_PAR_STREAM");
-      if (!(f && f[0] == '0')) HIPCHK(h, hipStreamCreateWithFlags(&h->par_stream, hipStreamNonBlocking));
-    }
+    if (!h->par_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->par_stream, hipStreamNonBlocking));
     if ((rc = dev_alloc(h, &p.d_inv, size_t(n) * n))) return rc;
     if ((rc = dev_alloc(h, &p.d_chol, size_t(n) * n))) return rc;
     if ((rc = dev_alloc(h, &p.d_rows, size_t(2) * n))) return rc;

@@ -33,7 +33,7 @@ int xch_check(m3hip_handle h) {
 // 1e7 events -- tables + sample words + bookkeeping cached (160 MB), codes (176 MB) around: 690.5 us; codes cached alone 695.0;
 // sample words + bookkeeping only 701; everything cached, large streams included (round 3's way) 712; everything around 721.5.
 // 5e6 events -- all four cached (168 MB): 341.0; codes alone 354.4; round 3's way 362.9.
-// M3HIP_NT_MASK = 0 | 4 forces the choice (experiments), M3HIP_CACHED_MB the budget.
+// M3HIP_NT_MASK = 0 | 4 forces the choice (tests).
 static uint32_t choose_nt_codes(m3hip_handle h, bool word_valid) {
   if (h->nt_force >= 0) return (uint32_t(h->nt_force) & 4u) ? 1u : 0u;
   const double budget = h->cached_mb * 1e6;
@@ -342,19 +342,15 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   // their kernel's epilogue.  Samples with bricks (and the float_t = double variant) by a pass of its own in front of the
   // reweight kernel: with the binning tables in LDS when they fit (uniform samples, <= 2048 edges) and, when the packed words
   // exist, straight into their bin field -- 8 B of kinematics + the word, read and written, per event; k_rebin_pack /
-  // k_find_bins from global tables otherwise.  Bricks of 1024 events with the packed word can also re-bin in the brick
-  // kernel's own tail (no scratch since round 3's register work): measured slower than the LDS pass (the cascade's look-ups
-  // come from L2 there), so only M3HIP_REBIN=tail selects it.
+  // k_find_bins from global tables otherwise (M3HIP_REBIN=global forces those: tests).
   const bool dyn_any = !h->h_shifts.empty();
   bool nonuniform = false;
   for (const BinSample& bs : h->bb_samples) nonuniform = nonuniform || !bs.uniform;
   const bool lds_ok = rebin_tables_fit_lds(int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), int(h->h_shifts.size()),
                                            int(h->h_cuts.size()), nonuniform);
-  const bool want_tail = h->sw_rebin == 't';  // M3HIP_REBIN = tail | pass | global (experiments / tests)
   const bool use_lds = lds_ok && h->sw_rebin != 'g';
-  const bool brick_tail = want_tail && brick_can_rebin(uint32_t(h->brick_groups), word_valid);
-  const bool dyn_pass = dyn_any && (h->f64 || (!h->h_bricks.empty() && !brick_tail));
-  const bool dyn_bins = dyn_any && !dyn_pass;  // fused
+  const bool dyn_pass = dyn_any && (h->f64 || !h->h_bricks.empty());
+  const bool dyn_bins = dyn_any && !dyn_pass;  // fused into the uniform-tile kernel's epilogue
   if (dyn_pass) {
     BinArgs b = make_bin_args(h);
     b.compute_nominal = 0;
@@ -462,7 +458,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
     launch_reweight_uniform(a, n_tiles, mode, ku, h->stream, dyn_bins);
-    launch_reweight_brick(a, n_bricks, mode, kb, h->stream, dyn_bins);
+    launch_reweight_brick(a, n_bricks, mode, kb, h->stream);
   }
   if (h->deterministic && (n_tiles || n_bricks)) {  // ordered sum of the workgroups' rows -> replica 0
     launch_fold_partials(h->d_partial, int(n_tiles + n_bricks), h->n_bins, a.fill_w2, h->d_partial_l1, h->d_hist, h->hist_rep, h->stream);

@@ -115,7 +115,6 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
   h->short_bricks = ShortBrickPlan();
   { const char* f = getenv("M3HIP_NT_MASK"); h->nt_force = f && f[0] ? atoi(f) : -1; }
-  { const char* f = getenv("M3HIP_CACHED_MB"); h->cached_mb = f && f[0] ? atof(f) : 200.0; }
   h->expect_events = 0;
   h->P = n_params;
   h->K = max_knots;
@@ -249,7 +248,6 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
-  { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
   // G of the bricks, fixed by the first chunk (all bricks of an engine share one kernel instantiation)
   if (h->brick_groups == 0) h->brick_groups = choose_brick_groups(in, h->upload_expect);
@@ -702,7 +700,6 @@ int m3hip_debug_layout(int n_params, int max_knots, const int16_t* npts, uint64_
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }
-  { const char* f = getenv("M3HIP_TF1_SORT"); g_tf1_sort = f ? atoi(f) : 2; }
   { const char* f = getenv("M3HIP_PAD_RUNS"); g_pad_runs = f ? atoi(f) : 2; }
   // M3HIP_DEBUG_SHORT_FROM / _TO: the stretch of events whose bricks are cut short (tests/test_layout.py; an engine gets them from its ShortBrickPlan)
   uint64_t short_from = ~0ull, short_to = ~0ull;

@@ -1474,16 +1474,15 @@ def test_deterministic_fill_needs_the_private_bin_vector(fresh_engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_into_word_g2", "lds_pass_into_word_g4", "brick_tail", "global_pass_into_word_g4",
+@pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_into_word_g2", "lds_pass_into_word_g4", "global_pass_into_word", "global_pass_into_word_g4",
                                   "lds_pass_no_word", "global_pass_no_word", "lds_pass_weight_words_rule", "lds_pass_weight_words_rule_g4",
-                                  "global_pass_weight_words_forced_g4", "brick_tail_weight_words_forced"])
+                                  "global_pass_weight_words_forced_g4", "lds_pass_weight_words_forced"])
 def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
     """SURVEY 8f row 4 on a brick sample of a size where the launch has rounds of workgroups (120 000 events of configs[2]'s
     shape): an energy-scale functional parameter re-bins every event every step (ApplyShifts, Samples/SampleHandlerFD.cpp:545-564;
     FindBin with the cached nominal bin, Samples/SampleStructs.h:577-613).  Every device form against the oracle: the pass with
     the binning tables in LDS that rewrites the packed words' bin field (the default; bricks of 1024, 2048 and 4096 events), the
-    brick kernel's own tail (M3HIP_REBIN=tail), the passes over global tables (k_rebin_pack, k_find_bins), samples without the
-    packed word.  Bins integer-exact, event weights bit-exact, bin contents 1e-12, LLH 1e-9."""
+    passes over global tables (k_rebin_pack, k_find_bins), samples without the packed word.  Bins integer-exact, event weights bit-exact, bin contents 1e-12, LLH 1e-9."""
     from mach3_amd.engine import Engine
     if path.endswith("_g2"):
         monkeypatch.setenv("M3HIP_BRICK_GROUPS", "2")
@@ -1491,12 +1490,8 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         monkeypatch.setenv("M3HIP_BRICK_GROUPS", "4")
     if "no_word" in path:
         monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
-    if path == "brick_tail":
-        monkeypatch.setenv("M3HIP_REBIN", "tail")
     if path.startswith("global"):
         monkeypatch.setenv("M3HIP_REBIN", "global")
-    if path.startswith("brick_tail"):
-        monkeypatch.setenv("M3HIP_REBIN", "tail")
     # round 5: a pre-staged oscillation table that rests is folded into the packed words (the weight's float bits instead of the
     # index, a 14-bit bin field for the passes to write into): by the engine's rule for a LARGE table (200 KB here: index words
     # for the first laps, weight words from the third reweight on, index words again when the table moves, ...), or forced
@@ -1580,8 +1575,6 @@ def test_functional_shifts_on_a_ragged_two_sample_2d_space(path, monkeypatch):
     from mach3_amd.engine import Engine
     if "no_word" in path:
         monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
-    if path == "brick_tail":
-        monkeypatch.setenv("M3HIP_REBIN", "tail")
     if path.startswith("global"):
         monkeypatch.setenv("M3HIP_REBIN", "global")
     spec = synth.CONFIGS["c3"].scaled(60_000)
