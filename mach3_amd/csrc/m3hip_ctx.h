@@ -212,15 +212,17 @@ struct m3hip_ctx {
 
   // binned spline handler (optional)
   int b_M = 0, b_U = 0, b_C = 0;
-  int32_t* d_b_cidx = nullptr;
-  int32_t* d_b_usv = nullptr;
-  int32_t* d_b_uniq = nullptr;
-  float* d_b_xcoeff = nullptr;
+  // the handler's tables in the engine's layout (BinnedArgs, m3hip_kernels.h): non-flat bin-splines in blocks, sorted by parameter
+  // inside a block, coefficients and knots segment-major per block
+  int b_block = 0, b_nseg = 0;
+  int16_t* d_b_par = nullptr;
+  int32_t* d_b_target = nullptr;
+  float* d_b_xk = nullptr;
   float4* d_b_many = nullptr;
   float* d_b_w = nullptr;
   // M3::float_t = double build of the sample side (m3hip_binned_upload_f64)
   bool f64 = false;
-  double* d_b_xcoeff_d = nullptr;
+  double* d_b_xk_d = nullptr;
   double* d_b_many_d = nullptr;
   double* d_b_w_d = nullptr;
   double* d_coeff_x_d = nullptr;

@@ -235,23 +235,31 @@ struct PrepArgs {
 };
 
 // ---- binned splines (ref: Splines/BinnedSplineHandler.cpp:295-341)
+// BinnedSplineHandler::CalcSplineWeights on the engine's own layout of the handler's tables (m3hip_upload.hip: binned_planes).
+// The reference keeps one AoS record {y,b,c,d}[knot] per bin-spline and a step reads ONE quad of it -- a 128-byte line for 16 bytes;
+// read as it is (rounds 2-4) the pass moved 121 B per non-flat bin-spline.  Here the non-flat bin-splines are cut into blocks of
+// `block` (a multiple of 256), sorted by parameter inside a block, and stored segment-major per block:
+//     many[(b * n_seg + k) * block + j]    quad of segment k of the j-th bin-spline of block b (float4, or four doubles)
+//     xk  [(b * n_seg + k) * block + j]    its knot x
+// so the lanes of a wave -- a run of one parameter, i.e. of one segment -- read 1 KB of contiguous quads, and a bin-spline costs
+// 2 (parameter) + 4 (target) + 16 + 4 B read and its weight written: 30 B (54 B in the double build).  The weight vector keeps
+// the handler's order (the events' pointer lists index it): a block's targets lie in a window of a few KB that L2 merges.
 struct BinnedArgs {
-  const int32_t* uniquecoeffindices;  // [n_unique]
-  const int32_t* uniquesplinevec;     // [M]
-  const int32_t* coeffindexvec;       // [M]
-  const float* xcoeff;                // [C]
-  const float4* manycoeff;            // [C] {y,b,c,d}
+  const int16_t* par;        // [n_unique] unique spline parameter of the bin-spline at sorted position q
+  const int32_t* target;     // [n_unique] its index in weightvec_Monolith
+  const float4* many;        // float build: segment-major quads
+  const float* xk;
+  const double* many_d;      // double build: [..][4]
+  const double* xk_d;
   const PTab* ptab;
   const float* pval;
-  float* weightvec;                   // [M]
-  int32_t n_unique;
-  // float_t = double build: the same tables in double; xvar is the parameter's double value itself
-  // (BinnedSplineHandler.cpp:327), read through par_map from the device parameter vector
-  const double* xcoeff_d;
-  const double* manycoeff_d;          // [C][4]
+  float* weightvec;          // [M]
   double* weightvec_d;
-  const double* params;
-  const int32_t* par_map;
+  const double* params;      // double build: xvar is the parameter's own double value (BinnedSplineHandler.cpp:327),
+  const int32_t* par_map;    // read through par_map from the device parameter vector
+  int32_t n_unique;
+  int32_t block;             // bin-splines per block
+  int32_t n_seg;             // segment planes per block (max_knots - 1)
 };
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s);
 

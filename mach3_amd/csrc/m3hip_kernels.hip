@@ -1649,45 +1649,54 @@ void launch_find_bins(const BinArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_binned_weights: BinnedSplineHandler::CalcSplineWeights (Splines/BinnedSplineHandler.cpp:305-341):
-// one lane per non-flat bin-spline; weight = max(0, cubic).  A few 1e5-1e6 splines: small next to
-// the event loop, so the reference's AoS coefficient layout is read as it is (one float4 per lane).
+// k_binned_weights: BinnedSplineHandler::CalcSplineWeights (Splines/BinnedSplineHandler.cpp:305-341): one lane per non-flat
+// bin-spline, weight = max(0, cubic), on the block-sorted segment-major tables described at BinnedArgs.  The workgroups of a
+// block run on ONE XCD (chunk = the XCD's share, not the workgroup number): their scattered 4-byte writes into the block's window
+// of the weight vector then merge in that XCD's L2 instead of leaving eight L2s with partial lines.
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ int binned_chunk(int n_chunks) {
+  // workgroup w lands on XCD w % 8: give XCD x the contiguous chunks [x * per, (x + 1) * per)
+  const int per = (n_chunks + 7) / 8;
+  return (int)(blockIdx.x % 8u) * per + (int)(blockIdx.x / 8u);
+}
 __global__ __launch_bounds__(256) void k_binned_weights(BinnedArgs a) {
-  const int iCoeff = blockIdx.x * 256 + threadIdx.x;
-  if (iCoeff >= a.n_unique) return;
-  const int iSpline = a.uniquecoeffindices[iCoeff];
-  const int uniqueIndex = a.uniquesplinevec[iSpline];
-  const PTab pt = a.ptab[uniqueIndex];
-  const int segCoeff = a.coeffindexvec[iSpline] + pt.seg;
-  const float4 c = a.manycoeff[segCoeff];
-  const float dx = a.pval[uniqueIndex] - a.xcoeff[segCoeff];  // :327-329 (float_t = float)
+  const int n_chunks = (a.n_unique + 255) / 256;
+  const int q = binned_chunk(n_chunks) * 256 + (int)threadIdx.x;
+  if (q >= a.n_unique) return;
+  const int p = a.par[q];
+  const int tgt = a.target[q];
+  const PTab pt = a.ptab[p];
+  const size_t at = ((size_t)(q / a.block) * a.n_seg + pt.seg) * a.block + (q % a.block);
+  const float4 c = a.many[at];
+  const float dx = a.pval[p] - a.xk[at];  // :327-329 (float_t = float)
   float weight = fmaf(dx, fmaf(dx, fmaf(dx, c.w, c.z), c.y), c.x);
   if (weight < 0) weight = 0.f;  // :337
-  a.weightvec[iSpline] = weight;
+  a.weightvec[tgt] = weight;
 }
 
 // float_t = double build: double tables, std::fma, and xvar is the parameter's own double value
 // (BinnedSplineHandler.cpp:320-337 with M3::float_t = double, M3::fmaf_t = std::fma, Core.h:44-51)
 __global__ __launch_bounds__(256) void k_binned_weights_f64(BinnedArgs a) {
-  const int iCoeff = blockIdx.x * 256 + threadIdx.x;
-  if (iCoeff >= a.n_unique) return;
-  const int iSpline = a.uniquecoeffindices[iCoeff];
-  const int uniqueIndex = a.uniquesplinevec[iSpline];
-  const int segCoeff = a.coeffindexvec[iSpline] + a.ptab[uniqueIndex].seg;
-  const double* c = a.manycoeff_d + (size_t)segCoeff * 4;
+  const int n_chunks = (a.n_unique + 255) / 256;
+  const int q = binned_chunk(n_chunks) * 256 + (int)threadIdx.x;
+  if (q >= a.n_unique) return;
+  const int p = a.par[q];
+  const int tgt = a.target[q];
+  const size_t at = ((size_t)(q / a.block) * a.n_seg + a.ptab[p].seg) * a.block + (q % a.block);
+  const double* c = a.many_d + at * 4;
   const double y = c[0], b = c[1], cc = c[2], d = c[3];
-  const double xvar = a.params[a.par_map[uniqueIndex]];
-  const double dx = xvar - a.xcoeff_d[segCoeff];
+  const double xvar = a.params[a.par_map[p]];
+  const double dx = xvar - a.xk_d[at];
   double weight = fma(dx, fma(dx, fma(dx, d, cc), b), y);
   if (weight < 0) weight = 0.;
-  a.weightvec_d[iSpline] = weight;
+  a.weightvec_d[tgt] = weight;
 }
 
 void launch_binned_weights(const BinnedArgs& a, hipStream_t s) {
   if (a.n_unique <= 0) return;
-  if (a.weightvec_d) hipLaunchKernelGGL(k_binned_weights_f64, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_binned_weights, dim3((a.n_unique + 255) / 256), dim3(256), 0, s, a);
+  const unsigned n_wg = (unsigned)(((a.n_unique + 255) / 256 + 7) / 8 * 8);  // a whole number of chunks per XCD (binned_chunk)
+  if (a.weightvec_d) hipLaunchKernelGGL(k_binned_weights_f64, dim3(n_wg), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_binned_weights, dim3(n_wg), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------

@@ -290,20 +290,22 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   if (h->n_res > kInlineResolveMax) launch_resolve(p, h->n_res, h->stream);
   if (h->b_U > 0) {  // BinnedSplineHandler::CalcSplineWeights
     BinnedArgs ba;
-    ba.uniquecoeffindices = h->d_b_uniq;
-    ba.uniquesplinevec = h->d_b_usv;
-    ba.coeffindexvec = h->d_b_cidx;
-    ba.xcoeff = h->d_b_xcoeff;
-    ba.manycoeff = h->d_b_many;
+    memset(&ba, 0, sizeof(ba));
+    ba.par = h->d_b_par;
+    ba.target = h->d_b_target;
+    ba.many = h->d_b_many;
+    ba.xk = h->d_b_xk;
+    ba.many_d = h->d_b_many_d;
+    ba.xk_d = h->d_b_xk_d;
     ba.ptab = h->d_ptab;
     ba.pval = h->d_pval;
     ba.weightvec = h->d_b_w;
-    ba.n_unique = h->b_U;
-    ba.xcoeff_d = h->d_b_xcoeff_d;
-    ba.manycoeff_d = h->d_b_many_d;
     ba.weightvec_d = h->d_b_w_d;
     ba.params = h->d_params;
     ba.par_map = h->d_parmap;
+    ba.n_unique = h->b_U;
+    ba.block = h->b_block;
+    ba.n_seg = h->b_nseg;
     launch_binned_weights(ba, h->stream);
   }
   // The brick kernel reads an event's bin, oscillation index and norm indices as one packed word when they fit its fields:

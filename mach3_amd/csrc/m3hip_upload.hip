@@ -53,13 +53,12 @@ void free_monolith(m3hip_handle h) {
   h->n_extra = 0;
   h->extras_dirty = false;
   dev_free(h->d_spline_w); h->d_spline_w = nullptr;
-  dev_free(h->d_b_cidx); h->d_b_cidx = nullptr;
-  dev_free(h->d_b_usv); h->d_b_usv = nullptr;
-  dev_free(h->d_b_uniq); h->d_b_uniq = nullptr;
-  dev_free(h->d_b_xcoeff); h->d_b_xcoeff = nullptr;
+  dev_free(h->d_b_par); h->d_b_par = nullptr;
+  dev_free(h->d_b_target); h->d_b_target = nullptr;
+  dev_free(h->d_b_xk); h->d_b_xk = nullptr;
   dev_free(h->d_b_many); h->d_b_many = nullptr;
   dev_free(h->d_b_w); h->d_b_w = nullptr;
-  dev_free(h->d_b_xcoeff_d); h->d_b_xcoeff_d = nullptr;
+  dev_free(h->d_b_xk_d); h->d_b_xk_d = nullptr;
   dev_free(h->d_b_many_d); h->d_b_many_d = nullptr;
   dev_free(h->d_b_w_d); h->d_b_w_d = nullptr;
   dev_free(h->d_coeff_x_d); h->d_coeff_x_d = nullptr;
@@ -79,6 +78,7 @@ void free_monolith(m3hip_handle h) {
   h->bl_mode = -1;
   h->bl_map.clear(); h->bl_off.clear(); h->bl_idx.clear();
   h->b_M = h->b_U = h->b_C = 0;
+  h->b_block = h->b_nseg = 0;
   h->Kb = 0;
   dev_free(h->d_sample_id); h->d_sample_id = nullptr;
   dev_free(h->d_kin); h->d_kin = nullptr;
@@ -96,6 +96,64 @@ void free_monolith(m3hip_handle h) {
   h->n_uniform = h->n_brick = h->n_padded = h->pad_responses = 0;
   h->mono_open = h->mono_done = false;
   h->parmap_set = false;
+}
+
+// The handler's tables in the engine's layout (BinnedArgs, m3hip_kernels.h).  T = float / double.
+template <class T>
+static int binned_planes(m3hip_handle h, int n_params, int max_knots, const int16_t* npts, const int32_t* coeffindexvec, const int32_t* uniquesplinevec,
+                         int n_unique, const int32_t* uniquecoeffindices, const T* xcoeff, const T* manycoeff, T** d_xk, void** d_many) {
+  const int n_seg = std::max(1, max_knots - 1);
+  // a block long enough for a parameter's run inside it to span whole waves (the quads of a run are one segment plane: contiguous),
+  // short enough for the block's window of the weight vector to stay in L2 while its workgroups write into it
+  int n_used = 0;
+  {
+    std::vector<char> used(size_t(n_params), 0);
+    for (int u = 0; u < n_unique; ++u) used[size_t(uniquesplinevec[uniquecoeffindices[u]])] = 1;
+    for (char c : used) n_used += c;
+  }
+  int block = std::min(65536, std::max(4096, 128 * std::max(1, n_used)));
+  block = (block + 255) / 256 * 256;
+  if (n_unique < block) block = std::max(256, (n_unique + 255) / 256 * 256);
+  const size_t n_blocks = (size_t(n_unique) + size_t(block) - 1) / size_t(block);
+  const size_t plane_len = n_blocks * size_t(n_seg) * size_t(block);
+  std::vector<int16_t> par(static_cast<size_t>(n_unique));
+  std::vector<int32_t> target(static_cast<size_t>(n_unique));
+  std::vector<T> xk(plane_len, T(0)), many(plane_len * 4, T(0));
+  std::vector<int32_t> ord;
+  for (size_t b = 0; b < n_blocks; ++b) {
+    const int j0 = int(b * size_t(block)), j1 = std::min(n_unique, j0 + block);
+    ord.resize(size_t(j1 - j0));
+    for (int j = j0; j < j1; ++j) ord[size_t(j - j0)] = j;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return uniquesplinevec[uniquecoeffindices[x]] < uniquesplinevec[uniquecoeffindices[y]]; });
+    for (int jj = 0; jj < j1 - j0; ++jj) {
+      const int i = uniquecoeffindices[ord[size_t(jj)]], p = uniquesplinevec[i];
+      const size_t q = size_t(j0) + size_t(jj);
+      par[q] = int16_t(p);
+      target[q] = i;
+      const int segs = npts[p] - 1;  // (checked by the caller: npts >= 2)
+      for (int k = 0; k < n_seg; ++k) {
+        const size_t src = size_t(coeffindexvec[i]) + size_t(std::min(k, segs - 1)), at = (b * size_t(n_seg) + size_t(k)) * size_t(block) + size_t(jj);
+        xk[at] = xcoeff[src];
+        for (int c = 0; c < 4; ++c) many[4 * at + size_t(c)] = manycoeff[4 * src + size_t(c)];
+      }
+    }
+  }
+  int rc;
+  if ((rc = dev_alloc(h, &h->d_b_par, size_t(n_unique)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_b_target, size_t(n_unique)))) return rc;
+  if ((rc = dev_alloc(h, d_xk, plane_len))) return rc;
+  T* dm = nullptr;
+  if ((rc = dev_alloc(h, &dm, plane_len * 4))) return rc;
+  *d_many = dm;
+  if (n_unique) {
+    HIPCHK(h, hipMemcpy(h->d_b_par, par.data(), sizeof(int16_t) * par.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_b_target, target.data(), sizeof(int32_t) * target.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(*d_xk, xk.data(), sizeof(T) * xk.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dm, many.data(), sizeof(T) * many.size(), hipMemcpyHostToDevice));
+  }
+  h->b_block = block;
+  h->b_nseg = n_seg;
+  return M3HIP_OK;
 }
 
 extern "C" {
@@ -516,12 +574,6 @@ static int binned_upload_common(m3hip_handle h, uint64_t n_events, int n_params,
     if (rc) return rc;
   }
   if ((rc = m3hip_monolith_end(h))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_cidx, size_t(monolith_size)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_usv, size_t(monolith_size)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_uniq, size_t(n_unique)))) return rc;
-  HIPCHK(h, hipMemcpy(h->d_b_cidx, coeffindexvec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_b_usv, uniquesplinevec, sizeof(int32_t) * monolith_size, hipMemcpyHostToDevice));
-  if (n_unique) HIPCHK(h, hipMemcpy(h->d_b_uniq, uniquecoeffindices, sizeof(int32_t) * n_unique, hipMemcpyHostToDevice));
   h->b_M = monolith_size;
   h->b_U = n_unique;
   h->b_C = n_coeff;
@@ -535,13 +587,10 @@ int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max
   int rc = binned_upload_common(h, n_events, n_params, max_knots, xpts, npts, monolith_size, coeffindexvec, uniquesplinevec, n_unique,
                                 uniquecoeffindices, n_coeff, xcoeff, manycoeff);
   if (rc) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_xcoeff, size_t(n_coeff)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_many, size_t(n_coeff)))) return rc;
+  if ((rc = binned_planes<float>(h, n_params, max_knots, npts, coeffindexvec, uniquesplinevec, n_unique, uniquecoeffindices, xcoeff, manycoeff, &h->d_b_xk,
+                                 reinterpret_cast<void**>(&h->d_b_many))))
+    return rc;
   if ((rc = dev_alloc(h, &h->d_b_w, size_t(monolith_size)))) return rc;
-  if (n_coeff) {
-    HIPCHK(h, hipMemcpy(h->d_b_xcoeff, xcoeff, sizeof(float) * n_coeff, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->d_b_many, manycoeff, sizeof(float) * 4 * size_t(n_coeff), hipMemcpyHostToDevice));
-  }
   std::vector<float> ones(size_t(monolith_size), 1.0f);  // flat bin-splines keep weight 1 (BinnedSplineHandler.cpp:236)
   HIPCHK(h, hipMemcpy(h->d_b_w, ones.data(), sizeof(float) * monolith_size, hipMemcpyHostToDevice));
   return M3HIP_OK;
@@ -559,14 +608,11 @@ int m3hip_binned_upload_f64(m3hip_handle h, uint64_t n_events, int n_params, int
                                 uniquecoeffindices, n_coeff, xcoeff, manycoeff);
   if (rc) return rc;
   if ((rc = dev_alloc(h, &h->d_coeff_x_d, xf.size()))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_xcoeff_d, size_t(n_coeff)))) return rc;
-  if ((rc = dev_alloc(h, &h->d_b_many_d, 4 * size_t(n_coeff)))) return rc;
+  if ((rc = binned_planes<double>(h, n_params, max_knots, npts, coeffindexvec, uniquesplinevec, n_unique, uniquecoeffindices, xcoeff, manycoeff, &h->d_b_xk_d,
+                                  reinterpret_cast<void**>(&h->d_b_many_d))))
+    return rc;
   if ((rc = dev_alloc(h, &h->d_b_w_d, size_t(monolith_size)))) return rc;
   HIPCHK(h, hipMemcpy(h->d_coeff_x_d, xpts, sizeof(double) * xf.size(), hipMemcpyHostToDevice));
-  if (n_coeff) {
-    HIPCHK(h, hipMemcpy(h->d_b_xcoeff_d, xcoeff, sizeof(double) * n_coeff, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->d_b_many_d, manycoeff, sizeof(double) * 4 * size_t(n_coeff), hipMemcpyHostToDevice));
-  }
   std::vector<double> ones(size_t(monolith_size), 1.0);
   HIPCHK(h, hipMemcpy(h->d_b_w_d, ones.data(), sizeof(double) * monolith_size, hipMemcpyHostToDevice));
   h->f64 = true;
