@@ -80,9 +80,12 @@ int m3hip_set_binning(m3hip_handle h, int n_samples, const int32_t* sample_bin_o
   // 132 us step at 7 200 bins with 32 replicas): keep the number of addresses, not the number of replicas.
   // Twice the replicas pay for samples of thousands of workgroups only (config 2: -1 % kernel and step); a small sample's step
   // is reset + fold (1e5 events: 28 -> 31 us with 64).  Allocated for the larger number, settled at the first reweight.
+  // Round 5: a brick flushes EVERY bin of a several-sample space (its events belong to all samples), so with more bins the big
+  // samples want more addresses, not the same number: config 4's share of one GPU (5 120 bricks, 800 bins), 8 / 16 / 32 / 64
+  // replicas: kernel 358.5 / 355.3 / 348.6 / 348.8 us, step 389.7 / 390.1 / 383.9 / 392.1 -> 25 600 addresses for them (32 at 800 bins).
   if (!h->hist_rep_forced) {
     h->hist_rep = std::max(1, std::min(std::min(h->hist_rep_cfg, 32), 6400 / nb));
-    h->hist_rep_big = std::max(h->hist_rep, std::min(h->hist_rep_cfg, 12800 / nb));
+    h->hist_rep_big = std::max(h->hist_rep, std::min(h->hist_rep_cfg, 25600 / nb));
   } else {
     h->hist_rep_big = h->hist_rep;
   }
