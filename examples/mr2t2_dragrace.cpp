@@ -225,6 +225,37 @@ int main(int argc, char** argv) {
     std::printf("DelayedMR2T2: %d steps, %.0f steps/s, acceptance %.3f (%d accepted at a delayed stage)\n", NSteps / 2, (NSteps / 2) / el,
                 double(delayed.GetAccCount()) / delayed.GetStepCount(), delayed.GetDelayedAcceptCount());
 
+    // ---- likelihood scans (ref: FitterBase::RunLLHScan, Fitters/FitterBase.cpp:622-830): every parameter but the first three
+    // skipped; each point against a step made by hand, the per-sample split against the total, the scanned parameter put back
+    {
+      for (int i = 0; i < nPar; ++i) setpar(i, nominal[i]);
+      std::vector<std::pair<int, int>> skip;
+      for (int i = 3; i < nPar; ++i) skip.emplace_back(0, i);
+      const auto scans = fitter.RunLLHScan(9, 1.0, /*BySample=*/true, skip);
+      if (scans.size() != 3) throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan: expected three scans");
+      for (const auto& sc : scans) {
+        if (ph.GetParProp(sc.iParam) != sc.CentralValue) throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan left a parameter moved");
+        for (size_t j = 0; j < sc.x.size(); ++j) {
+          ph.SetParProp(sc.iParam, sc.x[j]);
+          sample.Reweight();
+          const double l = sample.GetLikelihood(), pr = ph.GetLikelihood();
+          const double s0 = sample.GetSampleLikelihood(0), s1 = sample.GetSampleLikelihood(1);
+          auto close = [](double a, double b) { return std::fabs(a - b) <= 1e-9 * std::max(1.0, std::fabs(b)); };
+          if (!close(sc.sam[j], 2 * l) || !close(sc.cov[0][j], 2 * pr) || !close(sc.full[j], 2 * (l + pr)) || !close(sc.sample[0][j], 2 * l) ||
+              !close(sc.split[0][j], 2 * s0) || !close(sc.split[1][j], 2 * s1) || !close(sc.split[0][j] + sc.split[1][j], sc.sam[j]))
+            throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan: a scan point differs from the step made by hand");
+        }
+        ph.SetParProp(sc.iParam, sc.CentralValue);
+        // Asimov data at nominal: the sample term has its minimum (zero) at the central value, in the middle of the scan
+        const size_t mid = sc.x.size() / 2;
+        if (!(sc.sam[mid] < 1e-6) || !(sc.sam.front() > sc.sam[mid]) || !(sc.sam.back() > sc.sam[mid]))
+          throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan: the Asimov scan has no minimum at the central value");
+      }
+      sample.Reweight();
+      std::printf("LLH scan: 3 parameters x 9 points equal steps made by hand; per-sample split adds up; Asimov minimum at the central value (2LLH at -1 sigma: %.3f)\n",
+                  scans[0].full.front());
+    }
+
     // ---- functional parameter: E_rec *= 1 + theta, events re-binned on the device every step
     sample.EnableDeviceBinning();  // also checks device FindGlobalBin == host FindGlobalBin for every event
     sample.RegisterFunctionalParameter(-1, 0, 1, iEScale);

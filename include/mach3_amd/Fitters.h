@@ -9,6 +9,7 @@
 //   MCMCBase / MR2T2       Fitters/MCMCBase.cpp:32-216, Fitters/MR2T2.cpp:11-115
 //   DelayedMR2T2           Fitters/DelayedMR2T2.cpp:95-235 (delayed rejection, DRAM acceptance)
 //
+// FitterBase::RunLLHScan (Fitters/FitterBase.cpp:559-830) as MCMCBase::RunLLHScan: the scans returned as vectors.
 // Also here: the two special proposals (circular bounds and parameter flips, EnableCircularBounds / EnableFlip), fixed
 // parameters, flat priors, simulated annealing.
 // Not here: YAML configuration, ROOT output trees (steps are kept in memory), PCA, tunes, Robbins-Monro scaling,
@@ -59,6 +60,11 @@ class ParameterHandlerBase {
   const std::vector<double>& GetParCurrVec() const { return _fCurrVal; }
   const std::vector<double>& GetParPropVec() const { return _fPropVal; }
   double GetParProp(int i) const { return _fPropVal[size_t(i)]; }
+  double GetParInit(int i) const { return _fPreFitValue[size_t(i)]; }
+  void SetParProp(const int i, const double val) { _fPropVal[size_t(i)] = val; }
+  double GetDiagonalError(const int i) const { return std::sqrt(covMatrix[size_t(i) * size_t(_fNumPar) + size_t(i)]); }
+  double GetLowerBound(const int i) const { return _fLowBound[size_t(i)]; }
+  double GetUpperBound(const int i) const { return _fUpBound[size_t(i)]; }
   double GetParCurr(int i) const { return _fCurrVal[size_t(i)]; }
   void SetParCurrProp(const int parNo, const double parVal) { _fPropVal[size_t(parNo)] = _fCurrVal[size_t(parNo)] = parVal; }
   void SetStepScale(const double scale, bool = false) { _fGlobalStepScale = scale; }
@@ -533,6 +539,74 @@ class MCMCBase {
   const std::vector<double>& GetSystLikelihoods() const { return syst_llh; }
   double GetLogLProp() const { return logLProp; }
   const std::vector<double>& GetStepTimes() const { return stepTime; }
+
+  /// One parameter's likelihood scan (ref: FitterBase::RunLLHScan, Fitters/FitterBase.cpp:622-830; what the reference writes into
+  /// TH1Ds is returned here): n_points bin centres between CentralValue -+ nSigma * prior error, clipped to the parameter's
+  /// bounds (GetParameterScanRange, :559-617); every entry is 2 x the negative log-likelihood at that point.
+  struct LLHScanResult {
+    int iHandler = 0, iParam = 0;
+    double CentralValue = 0, lower = 0, upper = 0;
+    std::vector<double> x;                        ///< the scan points (TH1D bin centres)
+    std::vector<double> full, sam;                ///< hScan: samples + all systematics objects; hScanSam: the samples
+    std::vector<std::vector<double>> sample;      ///< hScanSample: [sample handler][point]
+    std::vector<std::vector<double>> cov;         ///< hScanCov: [systematics object][point]
+    std::vector<std::vector<double>> split;       ///< hScanSamSplit (LLHScanBySample): [sub-sample over all handlers][point]
+  };
+  /// Scans every parameter of every systematics object (Skip: {handler, parameter} pairs left out, the reference's
+  /// LLHScanSkipVector); all other parameters stay at their proposed values, the scanned one is put back afterwards.
+  /// As in the reference the samples are reweighted for every point, all of them before the first likelihood is asked for.
+  std::vector<LLHScanResult> RunLLHScan(const int n_points = 100, const double nSigma = 1.0, const bool BySample = false,
+                                        const std::vector<std::pair<int, int>>& Skip = {}) {
+    if (n_points < 1) throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan: no points");
+    std::vector<LLHScanResult> out;
+    for (size_t ic = 0; ic < systematics.size(); ++ic) {
+      ParameterHandlerBase* cov = systematics[ic];
+      for (int i = 0; i < cov->GetNumParams(); ++i) {
+        if (std::find(Skip.begin(), Skip.end(), std::make_pair(int(ic), i)) != Skip.end()) continue;
+        LLHScanResult r;
+        r.iHandler = int(ic);
+        r.iParam = i;
+        r.CentralValue = cov->GetParProp(i);
+        r.lower = std::max(r.CentralValue - nSigma * cov->GetDiagonalError(i), cov->GetLowerBound(i));
+        r.upper = std::min(r.CentralValue + nSigma * cov->GetDiagonalError(i), cov->GetUpperBound(i));
+        r.sample.assign(samples.size(), {});
+        r.cov.assign(systematics.size(), {});
+        size_t n_split = 0;
+        if (BySample)
+          for (auto* smp : samples) n_split += size_t(smp->GetNsamples());
+        r.split.assign(n_split, {});
+        for (int j = 0; j < n_points; ++j) {
+          const double x = r.lower + (double(j) + 0.5) * (r.upper - r.lower) / double(n_points);  // TH1D::GetBinCenter(j + 1)
+          cov->SetParProp(i, x);
+          for (auto* smp : samples) smp->Reweight();
+          double samplellh = 0.0, totalllh = 0.0;
+          for (size_t ivs = 0; ivs < samples.size(); ++ivs) {
+            const double l = samples[ivs]->GetLikelihood();
+            r.sample[ivs].push_back(2 * l);
+            samplellh += l;
+          }
+          for (size_t ivc = 0; ivc < systematics.size(); ++ivc) {
+            const double l = systematics[ivc]->GetLikelihood();
+            r.cov[ivc].push_back(2 * l);
+            totalllh += l;
+          }
+          totalllh += samplellh;
+          if (BySample) {
+            size_t it = 0;
+            for (auto* smp : samples)
+              for (int is = 0; is < smp->GetNsamples(); ++is) r.split[it++].push_back(2 * smp->GetSampleLikelihood(is));
+          }
+          r.x.push_back(x);
+          r.sam.push_back(2 * samplellh);
+          r.full.push_back(2 * totalllh);
+        }
+        cov->SetParProp(i, r.CentralValue);
+        out.push_back(std::move(r));
+      }
+    }
+    for (auto* smp : samples) smp->Reweight();  // the samples back at the point the scan started from
+    return out;
+  }
 
   /// ref: Fitters/FitterBase.cpp:461-520
   void DragRace(int NLaps, double* reweight_s_per_lap, double* llh_s_per_lap) {

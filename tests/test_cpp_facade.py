@@ -31,6 +31,7 @@ def test_cpp_driver_runs_a_chain():
     assert "MCMC + adaptive proposal" in out and "DelayedMR2T2" in out and "functional parameter" in out
     assert "reloaded monolith are bit-identical" in out
     assert "experiment weight slots" in out
+    assert "LLH scan: 3 parameters x 9 points equal steps made by hand" in out
 
 
 @pytest.mark.gpu
