@@ -15,7 +15,7 @@ def pytest_configure(config):
     need = [os.path.join(ROOT, "mach3_amd", "lib", "libm3hip.so"), os.path.join(ROOT, "mach3_amd", "lib", "libm3synth.so"),
             os.path.join(ROOT, "oracle", "libm3oracle_serial.so"), os.path.join(ROOT, "oracle", "libm3oracle_omp.so")]
     if not all(os.path.exists(p) for p in need):
-        subprocess.run(["make", "-C", ROOT, "all"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-j8", "-C", ROOT, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
