@@ -399,6 +399,11 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     if (sort_slots) std::stable_sort(idx.begin(), idx.end(), [&](uint16_t x, uint16_t y) { return key(x) > key(y); });
     std::copy(idx.begin(), idx.end(), sigma.begin() + size_t(h) * M3_GROUP);
   }
+  if (sort_slots) {  // events that come in that order already (MC registered so, or few distinct counts): nothing to permute
+    bool identity = true;
+    for (size_t k = 0; k < sigma.size() && identity; ++k) identity = sigma[k] == uint16_t(k % size_t(M3_GROUP));
+    if (identity) sort_slots = false;
+  }
   auto slot_codes = [&](uint32_t k) -> const std::vector<uint8_t>* { const uint32_t le = slot_event(k); return le < ne ? &codes[le] : nullptr; };
   const uint32_t off_tf1 = uint32_t(w.size());
   w[1] = off_tf1;
