@@ -194,8 +194,8 @@ struct ReweightArgs {
                              // and the LDS would cost occupancy)
   uint32_t tile_base;        // index of the first tile handled by this launch
   uint32_t brick_groups;     // G of the engine's bricks (1, 2 or 4): events per brick = G x 1024
-  BinArgs dyn;               // DYN variants only: the event's bin is recomputed from its shifted kinematics in the
-                             // epilogue (functional parameters), instead of being read from `bin`
+  BinArgs dyn;               // DYN variants of the uniform-tile kernel only: the event's bin is recomputed from its shifted
+                             // kinematics in the epilogue (functional parameters), instead of being read from `bin`
 };
 
 enum ReweightMode : int { kModeEval = 1, kModeFill = 2, kModeEventW = 4 };
