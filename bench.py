@@ -361,11 +361,16 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback, 
             go = float(flag.item()) > 0
         return go
 
+    # the kernel's time over the UNTIMED steps as well (thousands of launches: what a profiler averages over), beside the figure of
+    # the timed region's few: `roofline.untimed_steps`
+    eng.timing_enable(EVENT_EVERY)
+    eng.timing_reset()
     while keep_spinning():
         step(n_spin)
         n_spin += 1
     for i in range(max(args.warmup, 2 if in_library else 0)):
         step(i)
+    k_ms_untimed, k_n_untimed = eng.timing_read(0)
     comm_val = None
     if in_library:
         rel, n_val = eng.comm_last_validation()
@@ -422,7 +427,7 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback, 
     after = None
     if oneshot and in_library and os.environ.get("M3_BENCH_ONESHOT", "1") != "0":
         after = lambda: oneshot_leg(eng, step, rank, n_ranks, dist, torch, args)  # noqa: E731
-    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=None,
+    out = dict(el=el, llh=llh, k_ms=k_ms, k_n=int(k_n), k_ms_untimed=k_ms_untimed, k_n_untimed=int(k_n_untimed), info=info, comm=comm_mode, e0=e0, e1=e1, check=check, comm_val=comm_val, oneshot=None,
                comm_us=1e3 * gap_ms if gap_n else None, k_all=k_all, after=after, close=eng.close)
     if after is None:
         eng.close()
@@ -547,6 +552,9 @@ def roofline(base_name, m, per_gpu):
         "alg_bytes_per_launch": int(info.alg_bytes_fused),
         "avg_kernel_ms": k_ms,
         "launches_timed": m["k_n"],
+        # the same events over the untimed spin-up and warm-up steps of this process: many more launches, the average a profiler reports
+        "untimed_steps": ({"avg_kernel_ms": m["k_ms_untimed"], "launches": m["k_n_untimed"],
+                           "frac": info.alg_bytes_fused / (m["k_ms_untimed"] * 1e-3) / 1e9 / HBM_PEAK_GBS} if m.get("k_n_untimed") else None),
         "event_sampling": f"every {EVENT_EVERY}th launch of the timed region carries a hipEvent pair stamped with the dispatch's own start/end (hipExtLaunchKernelGGL); rank 0's shard",
     }
 
