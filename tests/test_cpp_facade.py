@@ -257,6 +257,11 @@ def test_sharded_chain_through_the_facade_takes_the_same_decisions_on_every_rank
         two = _run_sharded(t2, 2, "oneshot")
         b1 = np.fromfile(os.path.join(t1, "bins_0.bin"))
         b20, b21 = np.fromfile(os.path.join(t2, "bins_0.bin")), np.fromfile(os.path.join(t2, "bins_1.bin"))
+    # ... and SampleHandlerFD::InitComm (RCCL, with the validator on) with the one rank a single card allows: the same chain again
+    with tempfile.TemporaryDirectory() as t3:
+        rccl = _run_sharded(t3, 1, "rccl")[0]
+        b3 = np.fromfile(os.path.join(t3, "bins_0.bin"))
+    assert rccl["acc"] == one["acc"] and float(rccl["logl"]) == pytest.approx(float(one["logl"]), rel=1e-12) and np.allclose(b3, b1, rtol=1e-12, atol=0)
     a, b = two
     assert a["events"] != b["events"] and a["events"].startswith("[0,") and b["events"].endswith(",60000)")
     assert a["acc"] == b["acc"] and a["logl"] == b["logl"] and a["accepted"] == b["accepted"]       # identical on both ranks
