@@ -195,8 +195,59 @@ class BinningHandler {
   int TotalBins = 0;
 };
 
+/// A normalisation parameter's applicability (ref: Parameters/ParameterStructs.h:111-131).  The reference names kinematic
+/// variables by strings resolved through the experiment's ReturnKinematicParameter; here they are columns of the event's KinVars.
+struct NormParameter {
+  std::string name;
+  int index = 0;                       ///< position in the parameter vector (what becomes a norm_pointer)
+  std::vector<int> modes, pdgs, preoscpdgs, targets;  ///< empty: applies to all (SampleHandlerBase::MatchCondition)
+  bool hasKinBounds = false;
+  std::vector<int> KinematicColumn;    ///< per bounded variable: column of KinVars (KinematicVarStr in the reference)
+  std::vector<std::vector<std::vector<double>>> Selection;  ///< [variable][alternative] = {lo, hi}: lo < x <= hi, any alternative
+};
+/// What the applicability test reads of an event (ref: Samples/FarDetectorCoreInfoStruct.h: mode, Target, nupdg, nupdgUnosc, isNC)
+struct EventTruth {
+  int mode = 0, target = 0, nupdg = 0, nupdgUnosc = 0;
+  bool isNC = false;
+};
+
 class SampleHandlerFD : public SampleHandlerBase {
  public:
+  /// SampleHandlerFD::CalcNormsBins for one event (ref: Samples/SampleHandlerFD.cpp:667-731, PassesSelection :2101-2130,
+  /// MatchCondition Samples/SampleHandlerBase.h:196-202): the indices of the normalisation parameters that apply, in the order of
+  /// the parameter list -- what AddEvent takes as NormParams.  Oscillated NC events get none (:678-681); target, flavour,
+  /// unoscillated flavour and mode must each be listed (an empty list admits all); every bounded kinematic variable must lie in
+  /// one of its (lo, hi] ranges.
+  static std::vector<int16_t> CalcNormsBins(const std::vector<NormParameter>& norm_parameters, const EventTruth& ev, const std::vector<double>& KinVars) {
+    std::vector<int16_t> NormBins;
+    if (ev.isNC && ev.nupdg != ev.nupdgUnosc) return NormBins;
+    auto MatchCondition = [](const std::vector<int>& allowed, int value) {
+      return allowed.empty() || std::find(allowed.begin(), allowed.end(), value) != allowed.end();
+    };
+    for (const NormParameter& par : norm_parameters) {
+      if (!MatchCondition(par.targets, ev.target)) continue;
+      if (!MatchCondition(par.pdgs, ev.nupdg)) continue;
+      if (!MatchCondition(par.preoscpdgs, ev.nupdgUnosc)) continue;
+      if (!MatchCondition(par.modes, ev.mode)) continue;
+      bool IsSelected = true;
+      if (par.hasKinBounds) {
+        if (par.KinematicColumn.size() != par.Selection.size()) throw MaCh3Exception(__FILE__, __LINE__, "NormParameter " + par.name + ": one Selection entry per bounded variable");
+        for (size_t iKinPar = 0; iKinPar < par.KinematicColumn.size() && IsSelected; ++iKinPar) {
+          const size_t col = size_t(par.KinematicColumn[iKinPar]);
+          if (col >= KinVars.size()) throw MaCh3Exception(__FILE__, __LINE__, "NormParameter " + par.name + ": kinematic column beyond the event's variables");
+          const double kinVal = KinVars[col];
+          bool passedAnyBound = false;
+          for (const auto& bounds : par.Selection[iKinPar])
+            if (kinVal > bounds[0] && kinVal <= bounds[1]) { passedAnyBound = true; break; }
+          if (!passedAnyBound) IsSelected = false;
+        }
+      }
+      if (!IsSelected) continue;
+      NormBins.push_back(int16_t(par.index));
+    }
+    return NormBins;
+  }
+
   /// `Splines` keeps ownership of the device handle; `ParameterValues` plays
   /// ParameterHandlerBase::_fPropVal (read at every Reweight, like the reference's pointers).
   SampleHandlerFD(std::string Name, std::unique_ptr<SplineBase> Splines, std::unique_ptr<BinningHandler> Bins,

@@ -244,6 +244,38 @@ int facade_par_device_check(int n, unsigned long long seed, int n_steps, double*
   }
 }
 
+// SampleHandlerFD::CalcNormsBins for one event against a list of parameters given as flat arrays: per parameter index, the four
+// match lists as CSR (off[4 * n_par + 1], values), one optional bounded variable {column, n_ranges, ranges...} per parameter as CSR of
+// doubles (kin_off[n_par + 1], kin: {column, lo0, hi0, lo1, hi1, ...}; empty = no bounds).  Returns the number of indices written.
+int facade_calc_norms_bins(int n_par, const int* index, const int* off, const int* values, const int* kin_off, const double* kin, int mode, int target,
+                           int nupdg, int nupdg_unosc, int is_nc, int n_kin, const double* kinvars, short* out) {
+  try {
+    std::vector<NormParameter> pars(static_cast<size_t>(n_par));
+    for (int p = 0; p < n_par; ++p) {
+      NormParameter& np = pars[size_t(p)];
+      np.name = "p" + std::to_string(p);
+      np.index = index[p];
+      std::vector<int>* lists[4] = {&np.modes, &np.pdgs, &np.preoscpdgs, &np.targets};
+      for (int l = 0; l < 4; ++l) lists[l]->assign(values + off[4 * p + l], values + off[4 * p + l + 1]);
+      const int k0 = kin_off[p], k1 = kin_off[p + 1];
+      if (k1 > k0) {
+        np.hasKinBounds = true;
+        np.KinematicColumn.push_back(int(kin[k0]));
+        std::vector<std::vector<double>> ranges;
+        for (int k = k0 + 1; k + 1 < k1; k += 2) ranges.push_back({kin[k], kin[k + 1]});
+        np.Selection.push_back(ranges);
+      }
+    }
+    EventTruth ev;
+    ev.mode = mode; ev.target = target; ev.nupdg = nupdg; ev.nupdgUnosc = nupdg_unosc; ev.isNC = is_nc != 0;
+    const auto bins = SampleHandlerFD::CalcNormsBins(pars, ev, std::vector<double>(kinvars, kinvars + n_kin));
+    for (size_t i = 0; i < bins.size(); ++i) out[i] = bins[i];
+    return int(bins.size());
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 // M3::ShardRanges (Sharding.h) for the comparison with mach3_amd/dist.py:shard_ranges: cuts[2 * n_ranks] = {first, last} per rank
 int facade_shard_ranges(unsigned long long n_events, int n_ranks, const double* weights, unsigned long long* cuts) {
   try {
