@@ -251,9 +251,28 @@ int main(int argc, char** argv) {
         if (!(sc.sam[mid] < 1e-6) || !(sc.sam.front() > sc.sam[mid]) || !(sc.sam.back() > sc.sam[mid]))
           throw MaCh3Exception(__FILE__, __LINE__, "RunLLHScan: the Asimov scan has no minimum at the central value");
       }
+      // ... and in two dimensions (ref: FitterBase::Run2DLLHScan, :936-1035): parameters 0 and 2, 5 x 5 points, the diagonal
+      // entry of the grid's centre is the Asimov minimum, every entry a step made by hand
+      std::vector<std::pair<int, int>> skip2;
+      for (int i = 0; i < nPar; ++i)
+        if (i != 0 && i != 2) skip2.emplace_back(0, i);
+      const auto scans2 = fitter.Run2DLLHScan(5, 1.0, skip2);
+      if (scans2.size() != 1 || scans2[0].iParamX != 2 || scans2[0].iParamY != 0 || scans2[0].sam.size() != 25)
+        throw MaCh3Exception(__FILE__, __LINE__, "Run2DLLHScan: expected one 5 x 5 scan of parameters (2, 0)");
+      for (int x = 0; x < 5; ++x)
+        for (int y = 0; y < 5; ++y) {
+          ph.SetParProp(2, scans2[0].x[size_t(x)]);
+          ph.SetParProp(0, scans2[0].y[size_t(y)]);
+          sample.Reweight();
+          const double l = 2 * sample.GetLikelihood();
+          if (std::fabs(l - scans2[0].sam[size_t(x) * 5 + size_t(y)]) > 1e-9 * std::max(1.0, l)) throw MaCh3Exception(__FILE__, __LINE__, "Run2DLLHScan: a grid point differs from the step made by hand");
+        }
+      ph.SetParProp(2, nominal[2]);
+      ph.SetParProp(0, nominal[0]);
+      if (!(scans2[0].sam[12] < 1e-6) || !(scans2[0].sam[0] > scans2[0].sam[12])) throw MaCh3Exception(__FILE__, __LINE__, "Run2DLLHScan: no Asimov minimum at the grid's centre");
       sample.Reweight();
-      std::printf("LLH scan: 3 parameters x 9 points equal steps made by hand; per-sample split adds up; Asimov minimum at the central value (2LLH at -1 sigma: %.3f)\n",
-                  scans[0].full.front());
+      std::printf("LLH scan: 3 parameters x 9 points equal steps made by hand; per-sample split adds up; Asimov minimum at the central value (2LLH at -1 sigma: %.3f); 2-D scan 5 x 5 equal (corner %.3f)\n",
+                  scans[0].full.front(), scans2[0].sam[0]);
     }
 
     // ---- functional parameter: E_rec *= 1 + theta, events re-binned on the device every step

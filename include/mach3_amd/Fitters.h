@@ -9,7 +9,7 @@
 //   MCMCBase / MR2T2       Fitters/MCMCBase.cpp:32-216, Fitters/MR2T2.cpp:11-115
 //   DelayedMR2T2           Fitters/DelayedMR2T2.cpp:95-235 (delayed rejection, DRAM acceptance)
 //
-// FitterBase::RunLLHScan (Fitters/FitterBase.cpp:559-830) as MCMCBase::RunLLHScan: the scans returned as vectors.
+// FitterBase::RunLLHScan / Run2DLLHScan (Fitters/FitterBase.cpp:559-830, 936-1035) as MCMCBase methods: the scans returned as vectors.
 // Also here: the two special proposals (circular bounds and parameter flips, EnableCircularBounds / EnableFlip), fixed
 // parameters, flat priors, simulated annealing.
 // Not here: YAML configuration, ROOT output trees (steps are kept in memory), PCA, tunes, Robbins-Monro scaling,
@@ -605,6 +605,59 @@ class MCMCBase {
       }
     }
     for (auto* smp : samples) smp->Reweight();  // the samples back at the point the scan started from
+    return out;
+  }
+
+  /// Two parameters' scan of the samples' likelihood (ref: FitterBase::Run2DLLHScan, Fitters/FitterBase.cpp:936-1035; the TH2D's
+  /// contents returned row-major, sam[x * n_points + y] = 2 x the samples' -log L): parameter pairs (i, j < i) of one systematics
+  /// object, both ranges as in RunLLHScan.
+  struct LLHScan2DResult {
+    int iHandler = 0, iParamX = 0, iParamY = 0;
+    double lowerX = 0, upperX = 0, lowerY = 0, upperY = 0;
+    std::vector<double> x, y, sam;
+  };
+  std::vector<LLHScan2DResult> Run2DLLHScan(const int n_points = 20, const double nSigma = 1.0, const std::vector<std::pair<int, int>>& Skip = {}) {
+    if (n_points < 1) throw MaCh3Exception(__FILE__, __LINE__, "Run2DLLHScan: no points");
+    auto skipped = [&](size_t ic, int i) { return std::find(Skip.begin(), Skip.end(), std::make_pair(int(ic), i)) != Skip.end(); };
+    auto range = [&](ParameterHandlerBase* cov, int i, double& lo, double& up) {
+      const double cv = cov->GetParProp(i);
+      lo = std::max(cv - nSigma * cov->GetDiagonalError(i), cov->GetLowerBound(i));
+      up = std::min(cv + nSigma * cov->GetDiagonalError(i), cov->GetUpperBound(i));
+      return cv;
+    };
+    std::vector<LLHScan2DResult> out;
+    for (size_t ic = 0; ic < systematics.size(); ++ic) {
+      ParameterHandlerBase* cov = systematics[ic];
+      for (int i = 0; i < cov->GetNumParams(); ++i) {
+        if (skipped(ic, i)) continue;
+        for (int j = 0; j < i; ++j) {
+          if (skipped(ic, j)) continue;
+          LLHScan2DResult r;
+          r.iHandler = int(ic);
+          r.iParamX = i;
+          r.iParamY = j;
+          const double central_x = range(cov, i, r.lowerX, r.upperX), central_y = range(cov, j, r.lowerY, r.upperY);
+          for (int k = 0; k < n_points; ++k) {
+            r.x.push_back(r.lowerX + (double(k) + 0.5) * (r.upperX - r.lowerX) / double(n_points));
+            r.y.push_back(r.lowerY + (double(k) + 0.5) * (r.upperY - r.lowerY) / double(n_points));
+          }
+          r.sam.reserve(size_t(n_points) * size_t(n_points));
+          for (int x = 0; x < n_points; ++x)
+            for (int y = 0; y < n_points; ++y) {
+              cov->SetParProp(i, r.x[size_t(x)]);
+              cov->SetParProp(j, r.y[size_t(y)]);
+              for (auto* smp : samples) smp->Reweight();
+              double samplellh = 0.0;
+              for (auto* smp : samples) samplellh += smp->GetLikelihood();
+              r.sam.push_back(2 * samplellh);
+            }
+          cov->SetParProp(i, central_x);
+          cov->SetParProp(j, central_y);
+          out.push_back(std::move(r));
+        }
+      }
+    }
+    for (auto* smp : samples) smp->Reweight();
     return out;
   }
 
