@@ -12,6 +12,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <limits>
 #include <type_traits>
 #include <vector>
@@ -86,3 +87,54 @@ class BinnedSplineHandlerT : public SplineBase {
 };
 
 using BinnedSplineHandler = BinnedSplineHandlerT<float>;
+
+/// Which bin-splines an event points at: the handler's spline bookkeeping of ONE (sample, oscillation channel) and the look-up
+/// SampleHandlerFD::SetSplinePointers makes per event (ref: BinnedSplineHandler::GetEventSplines, Splines/BinnedSplineHandler.cpp:832-884;
+/// the fan-out to total_weight_pointers, Samples/SampleHandlerFD.cpp:1196-1243).  The reference keeps a seven-dimensional
+/// indexvec[sample][channel][syst][mode][b1][b2][b3] filled from ROOT files; here the caller registers, per systematic, its spline
+/// modes and the index in weightvec_Monolith of every (mode, bin1, bin2, bin3), and gets the event's CSR row for SetEventSplines.
+class BinnedSplineIndex {
+ public:
+  /// the three spline axes (true energy, first and second kinematic variable; a 1-D sample's third axis is one bin around 0):
+  /// ascending edges, bins [lo, hi) as TAxis::FindBin counts them
+  BinnedSplineIndex(std::vector<double> Axis1, std::vector<double> Axis2, std::vector<double> Axis3) : Axis{std::move(Axis1), std::move(Axis2), std::move(Axis3)} {
+    for (const auto& a : Axis)
+      if (a.size() < 2 || !std::is_sorted(a.begin(), a.end())) throw MaCh3Exception(__FILE__, __LINE__, "BinnedSplineIndex: axis edges must ascend");
+  }
+  int GetNBins(int axis) const { return int(Axis[size_t(axis)].size()) - 1; }
+  /// a systematic of this (sample, channel): the spline modes it has splines for (SplineModeVecs) and, mode-major, the
+  /// weightvec_Monolith index of every bin -- SplineID[((iMode * n1 + b1) * n2 + b2) * n3 + b3]
+  int AddSystematic(std::vector<int> SplineModes, std::vector<int32_t> SplineID) {
+    const size_t cells = size_t(GetNBins(0)) * size_t(GetNBins(1)) * size_t(GetNBins(2));
+    if (SplineID.size() != SplineModes.size() * cells) throw MaCh3Exception(__FILE__, __LINE__, "BinnedSplineIndex: one spline index per (mode, bin1, bin2, bin3)");
+    Modes.push_back(std::move(SplineModes));
+    Index.push_back(std::move(SplineID));
+    return int(Modes.size()) - 1;
+  }
+  /// TAxis::FindBin(v) - 1: -1 below the first edge, GetNBins at or above the last
+  int FindBin(int axis, double v) const {
+    const auto& e = Axis[size_t(axis)];
+    return int(std::upper_bound(e.begin(), e.end(), v) - e.begin()) - 1;
+  }
+  /// The event's bin-splines, systematic after systematic (the order total_weight_pointers gets them in): for every systematic
+  /// whose spline modes contain `SplineMode`, the spline of the event's (bin1, bin2, bin3), unless it is flat.  An event outside
+  /// any of the three axes gets none (:851-864).  `isflatarray` is the handler's, indexed like weightvec_Monolith (may be null).
+  std::vector<int32_t> GetEventSplines(int SplineMode, double Var1Val, double Var2Val, double Var3Val, const std::vector<char>* isflatarray = nullptr) const {
+    std::vector<int32_t> out;
+    if (SplineMode < 0) return out;
+    const int b1 = FindBin(0, Var1Val), b2 = FindBin(1, Var2Val), b3 = FindBin(2, Var3Val);
+    if (b1 < 0 || b1 >= GetNBins(0) || b2 < 0 || b2 >= GetNBins(1) || b3 < 0 || b3 >= GetNBins(2)) return out;
+    for (size_t iSyst = 0; iSyst < Modes.size(); ++iSyst)
+      for (size_t iMode = 0; iMode < Modes[iSyst].size(); ++iMode)
+        if (Modes[iSyst][iMode] == SplineMode) {
+          const int32_t id = Index[iSyst][((iMode * size_t(GetNBins(0)) + size_t(b1)) * size_t(GetNBins(1)) + size_t(b2)) * size_t(GetNBins(2)) + size_t(b3)];
+          if (!(isflatarray && (*isflatarray)[size_t(id)])) out.push_back(id);
+        }
+    return out;
+  }
+
+ private:
+  std::array<std::vector<double>, 3> Axis;
+  std::vector<std::vector<int>> Modes;     // [syst] spline modes
+  std::vector<std::vector<int32_t>> Index;  // [syst][mode][b1][b2][b3]
+};

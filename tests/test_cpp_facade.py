@@ -356,3 +356,59 @@ def test_calc_norms_bins_matches_a_plain_restatement():
         assert n == len(exp) and out[:n].tolist() == exp, (e, ev, kv, out[:n].tolist(), exp)
         hits += n
     assert hits > 100          # (the rule admitted parameters in a fair share of the cases)
+
+
+def test_binned_spline_index_event_fan_out():
+    """BinnedSplineIndex::GetEventSplines (the facade's twin of BinnedSplineHandler::GetEventSplines, ref
+    Splines/BinnedSplineHandler.cpp:832-884, and of the fan-out in SampleHandlerFD::SetSplinePointers, Samples/SampleHandlerFD.cpp:1196-1243)
+    against the look-up written out in python: three spline axes with TAxis::FindBin's [lo, hi) bins, events outside any axis get
+    nothing, a systematic contributes the spline of the event's bins when its mode list holds the event's spline mode and the spline is
+    not flat, systematics in order; values on edges included."""
+    import ctypes as C
+    import numpy as np
+    lib = _facade_lib()
+    lib.facade_event_splines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(7)
+    axes = [np.array([0.0, 0.5, 1.0, 2.0, 5.0]), np.array([-1.0, 0.0, 0.3, 1.0]), np.array([-1e9, 1e9])]   # a "1-D" sample: one bin on the third axis
+    nb = [len(a) - 1 for a in axes]
+    cells = nb[0] * nb[1] * nb[2]
+    systs, next_id = [], 0
+    for s in range(7):
+        modes = sorted(rng.choice(5, int(rng.integers(1, 4)), replace=False).tolist())
+        ids = np.arange(next_id, next_id + len(modes) * cells, dtype=np.int32)
+        next_id += len(ids)
+        systs.append((modes, ids))
+    isflat = (rng.random(next_id) < 0.2).astype(np.int8)
+    n_ev = 600
+    ev_mode = rng.integers(-1, 6, n_ev).astype(np.int32)
+    ev_vars = np.stack([rng.uniform(-0.5, 5.5, n_ev), rng.uniform(-1.3, 1.3, n_ev), np.zeros(n_ev)], axis=1)
+    ev_vars[::37, 0] = rng.choice(axes[0], len(ev_vars[::37]))       # exactly on edges
+    ev_vars[5::41, 1] = rng.choice(axes[1], len(ev_vars[5::41]))
+
+    def find(a, v):
+        return int(np.searchsorted(a, v, side="right")) - 1
+
+    exp_off, exp_idx = [0], []
+    for i in range(n_ev):
+        b = [find(axes[k], ev_vars[i, k]) for k in range(3)]
+        if ev_mode[i] >= 0 and all(0 <= b[k] < nb[k] for k in range(3)):
+            for modes, ids in systs:
+                for im, m in enumerate(modes):
+                    if m == ev_mode[i]:
+                        sid = int(ids[((im * nb[0] + b[0]) * nb[1] + b[1]) * nb[2] + b[2]])
+                        if not isflat[sid]:
+                            exp_idx.append(sid)
+        exp_off.append(len(exp_idx))
+    n_edges = np.array([len(a) for a in axes], np.int32)
+    edges = np.concatenate(axes)
+    mode_off = np.cumsum([0] + [len(m) for m, _ in systs]).astype(np.int32)
+    modes = np.concatenate([m for m, _ in systs]).astype(np.int32)
+    id_off = np.cumsum([0] + [len(i) for _, i in systs]).astype(np.int32)
+    ids = np.concatenate([i for _, i in systs]).astype(np.int32)
+    out_off, out_idx = np.zeros(n_ev + 1, np.int32), np.zeros(len(exp_idx) + 8, np.int32)
+    n = lib.facade_event_splines(n_edges.ctypes.data, edges.ctypes.data, len(systs), mode_off.ctypes.data, modes.ctypes.data, id_off.ctypes.data, ids.ctypes.data,
+                                 len(isflat), isflat.ctypes.data, n_ev, ev_mode.ctypes.data, np.ascontiguousarray(ev_vars).ctypes.data, out_off.ctypes.data,
+                                 out_idx.ctypes.data, len(out_idx))
+    assert n == len(exp_idx) and out_off.tolist() == exp_off and out_idx[:n].tolist() == exp_idx
+    assert len(exp_idx) > 300 and exp_off.count(0) < n_ev
