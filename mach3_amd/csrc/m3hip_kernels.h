@@ -54,7 +54,7 @@ struct BrickDev {
   uint32_t st1[4];            // the header block
   uint32_t n_dict;
   uint32_t spl_last_off;      // byte offset of the spline store's last quad (idle lanes' offsets are clamped to it)
-  uint32_t pad_[2];           // [0] G of the brick's format, [1] 1: the TF1 lane-slots are sorted by code count (sigma in use)
+  uint32_t pad_[2];           // [0] G of the brick's format, [1] bit 0: the TF1 lane-slots are sorted by code count (sigma in use), bit 1: the slots' code counts are bits 10..15 of their sigma words
 };
 
 // ---- device-side binning (uniform N-D), ref: Samples/SampleStructs.h:577-613, BinningHandler.cpp:257-307

@@ -622,6 +622,7 @@ struct RRun {      // per-step resolved run: quad address = base + r, dx of the 
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef u32x3_t u32x3_u __attribute__((aligned(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // k_reweight_brick: one 1024-lane workgroup per brick (<= G x 1024 events with ragged parameter lists); lane l owns the
@@ -703,13 +704,14 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     // lines per stage through the memory system
     const uint32_t n_resp = hd.h0 & 0xFFFFu, n_runs = (hd.h0 >> 16) & 0x3FFu;
     {
-      // the lane's response words: ONE load of three dwords from its record of nd = 1, 2 or 3 (m3hip_layout.h); what lies behind a
-      // shorter record belongs to the next lane and is never looked at as a response (scatter and ballots check the count).
+      // the lane's response words: ONE load of three dwords from its record of 1 .. 5 uint16 (m3hip_layout.cpp) -- every other
+      // record of an odd length starts on a 2-byte boundary: the load is declared so and stays one global_load_dwordx3.  What lies
+      // behind a shorter record belongs to the next lane and is never looked at as a response (scatter and ballots check the count).
       // Lanes without a response re-read the last record.
-      const uint32_t nd = ((n_resp + 1023u) / 1024u + 1u) / 2u;  // scalar
+      const uint32_t rec = 2u * ((n_resp + 1023u) / 1024u);  // bytes, scalar
       const uint32_t lanes = n_resp < (uint32_t)kBrickThreads ? (n_resp ? n_resp : 1u) : (uint32_t)kBrickThreads;
       const uint32_t l = lane < lanes - 1u ? lane : lanes - 1u;
-      const u32x3_t v = __builtin_nontemporal_load((const M3_GLOBAL u32x3_t*)(uniform_base(wbytes + 4u * hd.off_resp) + 4u * nd * l));
+      const u32x3_t v = __builtin_nontemporal_load((const M3_GLOBAL u32x3_u*)(uniform_base(wbytes + 4u * hd.off_resp) + rec * l));
       static_assert(kWordRegs == 3, "a lane's response words of a stage travel as three dwords");
       m.w[0] = v.x;
       m.w[1] = v.y;
@@ -756,13 +758,31 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   // cnt: code count of the lane-slot | the slot's event (relative to the slab) << 16.  The slots of a slab take its events in
   // order of descending count (m3hip_layout.cpp), so that the events of a wave have about equal counts
   struct Tf1Book { uint32_t cnt, cbase, dbase; };
+  // Where no event of the brick has more than 63 codes (bd.pad_[1] bit 1) the count sits in the sigma word's bits 10..15 and the
+  // byte array is not in the stream: a byte per event less to read.  Brick-uniform, but neither a branch (see the note at
+  // fetch_meta) nor a select (the instantiations without the packed sample word have no register for its mask): the byte load of
+  // such a brick reads, in every lane, a byte of the stream's header that is zero, and the count is the sum of the two fields.
+  // (Not for bricks of 2048 events, m3hip_layout.h kTf1CntInSigmaG2: those instantiations without the packed sample word are the
+  // ones the two scalars below push into scratch.)
+  auto book_word = [&](const M3_GLOBAL char* cb, uint32_t k) -> uint32_t {
+    if (G == 2 && !kTf1CntInSigmaG2) {
+      const uint32_t c8 = *(const M3_GLOBAL uint8_t*)(cb + k);
+      const uint32_t s16 = *(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * k);
+      return c8 | s16 << 16;
+    }
+    const uint32_t in_sigma = (bd.pad_[1] >> 1) & 1u;  // scalar
+    const uint32_t c8 = *(const M3_GLOBAL uint8_t*)(uniform_base(in_sigma ? wbytes + 4u * 6u : cb) + k * (1u - in_sigma));
+    const uint32_t s16 = *(const M3_GLOBAL uint16_t*)(uniform_base(cb + (in_sigma ? 0u : 1024u * G)) + 2u * k);
+    return c8 | s16 << 16;  // count in bits 0..7 or in bits 26..31 (the other field 0) | the slot's event in bits 16..25
+  };
+  auto book_count = [](uint32_t bw) -> uint32_t { return (bw & 0xFFu) + (bw >> 26); };
+  auto book_event = [](uint32_t bw) -> uint32_t { return (bw >> 16) & 1023u; };
   auto tf1_book = [&](uint32_t h) -> Tf1Book {
     Tf1Book b;
     uint32_t le = lane;
     asm volatile("" : "+v"(le));  // as in tail_issue_idx: no hoisting of G slabs' addresses
     const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));  // SGPR base + 32-bit offsets
-    b.cnt = *(const M3_GLOBAL uint8_t*)(cb + (1024u * h + le));
-    b.cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * (1024u * h + le))) << 16;
+    b.cnt = book_word(cb, 1024u * h + le);
     b.cbase = __builtin_amdgcn_readfirstlane(tf1h[16u * h + wave]);
     b.dbase = __builtin_amdgcn_readfirstlane(tf1h[16u * G + 16u * h + wave]);
     return b;
@@ -776,8 +796,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
   uint32_t book0_cnt = 0, book0_w = 0;
   if (kBookLds) {
     const M3_GLOBAL char* cb = uniform_base(wbytes + 4u * (bd.off_tf1 + 32u * G));
-    book0_cnt = *(const M3_GLOBAL uint8_t*)(cb + lane);
-    book0_cnt |= (uint32_t)(*(const M3_GLOBAL uint16_t*)(cb + 1024u * G + 2u * lane)) << 16;
+    book0_cnt = book_word(cb, lane);
     if (lane < 32) book0_w = tf1h[(lane < 16 ? 0u : 16u * G - 16u) + lane];
   } else if (n_stages == 0) {
     book_nxt = tf1_book(0);
@@ -1027,8 +1046,8 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
     return b;
   };
   auto slab_begin = [&]() {  // the slab whose bookkeeping was requested last becomes the current one
-    tf1_cnt = book_nxt.cnt & 0xFFu;
-    ev_slot = book_nxt.cnt >> 16;
+    tf1_cnt = book_count(book_nxt.cnt);
+    ev_slot = book_event(book_nxt.cnt);
     tf1_cbase = book_nxt.cbase;
     tf1_dbase = book_nxt.dbase;
   };
@@ -1169,7 +1188,7 @@ __global__ __launch_bounds__(kBrickThreads, 8) void k_reweight_brick(ReweightArg
 
   // ---- the TSpline3 products change lanes: up to here lane l held event l of every slab, from here on it holds the event of
   // its lane-slot (sigma).  Through the scatter array, which the stages are done with.
-  const bool resorted = bd.pad_[1] != 0;  // brick-uniform; otherwise sigma is the identity and the products stay where they are
+  const bool resorted = (bd.pad_[1] & 1u) != 0;  // brick-uniform; otherwise sigma is the identity and the products stay where they are
   if ((n_stages > 0 || kEvwLin) && resorted) {
     __syncthreads();  // every wave is through its events' products of the last stage
 #pragma unroll

@@ -87,7 +87,8 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 // Brick metadata stream (uint32 words, offsets relative to the brick's first word).  G = the engine's brick_groups: a brick
 // holds up to G x 1024 events, local event le = 1024 h + lane (slab h, lane of the workgroup); wave-block b = 16 h + w.
 //   [0] n_stages (TSpline3)   [1] off_tf1   [2] TF1 slots of the brick (codes, skips included)   [3] G   [4] 1: the TF1 lane-slots
-//   take the slab's events in order of descending code count (sigma below), 0: in their own order   [5..7] 0
+//   take the slab's events in order of descending code count (sigma below), 0: in their own order   [5] 1: no event has more than
+//   63 TF1 codes and the counts travel in the sigma words   [6..7] 0
 //   [8 + 4 s ..]  stage header: n_resp | n_runs << 16 | rows << 26, off_runs, off_pairs, off_resp   (rows = the most
 //             responses one event holds in the stage, <= M3_STAGE_EVENT_MAX)
 //   off_runs  n_runs x {int32 coef_off - start_r, stride | param << 16}.  coef_off: float4 index of the run's first plane
@@ -100,14 +101,17 @@ bool tile_is_uniform(const ChunkInput& in, uint64_t e0, uint64_t e1) {
 //             event l | event l + 1024 << 4; G = 4: uint16 l = events l, l + 1024, l + 2048, l + 3072, a nibble each.
 //   off_resp  one uint16 per response: slot << 2 | last response of its run (bits 2..14 are the byte offset of the
 //             response's slot in the scatter array).  Slots: wave-block after wave-block, inside a block event after event
-//             (lane order), an event's responses in ascending parameter order.  Stored two per
-//             dword, a lane's dwords next to each other (the kernel fetches them with one load): record [l] of lane l = nd
-//             dwords, dword k = word of response l + 2k * 1024 | word of response l + (2k + 1) * 1024 << 16,
-//             nd = stage_word_dwords(n_resp) = 1, 2 or 3; one record for every lane that holds a response
+//             (lane order), an event's responses in ascending parameter order.  A lane's words
+//             lie next to each other (the kernel fetches them with one 12-byte load): record [l] of lane l = nw uint16, word u =
+//             response l + 1024 u, nw = stage_record_words(n_resp) = 1 .. 5 -- records of 2 nw bytes, so with an odd nw every
+//             other one starts on a 2-byte boundary (gfx950 loads from there; rounding the records up to whole dwords cost a
+//             stage of 4097 .. 5120 entries a sixth of these bytes); one record for every lane that holds a response, the
+//             last dword of the list filled up with zeros
 //   off_tf1   [0 .. 16 G)       float2 index (from the brick's TF1 store) of the first slot of wave-block b
 //             [16 G .. 32 G)    word offset (from the brick's first word) of wave-block b's first code dword
-//             [32 G .. 32 G + 256 G)  codes per lane-slot, uint8, four per word (slot k = 1024 h + l: what lane l works on in slab h)
-//             [.. + 512 G)      sigma: the slot's event relative to its slab, uint16, two per word.  Inside a slab the events are
+//             [32 G .. 32 G + 256 G)  codes per lane-slot, uint8, four per word (slot k = 1024 h + l: what lane l works on in slab h);
+//                               NOT THERE when [5] is set: the count is then bits 10..15 of the slot's sigma word
+//             [.. + 512 G)      sigma: the slot's event relative to its slab, uint16 (bits 0..9), two per word.  Inside a slab the events are
 //                               handed to the slots in order of descending code count, so that a wave-block's 64 events have
 //                               about equal counts (a wave executes as many rows as its longest event has codes)
 //             then the code dwords: per wave-block, per four rows 4 q .. 4 q + 3, one dword for every lane with more than 4 q
@@ -330,16 +334,17 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         w.push_back(d);
       }
     }
-    // response words, two per dword, a lane's dwords next to each other (one load fetches them): lane l of the workgroup works on
-    // responses l, l + 1024, l + 2048, ... of the stage; record [l] = nd dwords, dword k = word of response l + 2k * 1024 |
-    // word of response l + (2k + 1) * 1024 << 16, nd = stage_word_dwords(n_resp); records for the lanes that hold a response
+    // response words, a lane's next to each other (one load fetches them): lane l of the workgroup works on responses l, l + 1024,
+    // l + 2048, ... of the stage; record [l] = nw uint16, word u = response l + 1024 u, nw = stage_record_words(n_resp); records
+    // for the lanes that hold a response
     const uint32_t off_resp = uint32_t(w.size());
     {
-      const uint32_t nd = stage_word_dwords(n_resp), lanes = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp);
+      const uint32_t nw = stage_record_words(n_resp), lanes = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp);
+      w.resize(size_t(off_resp) + (size_t(nw) * lanes + 1) / 2, 0u);
       for (uint32_t l = 0; l < lanes; ++l)
-        for (uint32_t k = 0; k < nd; ++k) {
-          const uint32_t lo = 2 * k * uint32_t(M3_GROUP) + l, hi = lo + uint32_t(M3_GROUP);
-          w.push_back((lo < n_resp ? uint32_t(resp[lo]) : 0u) | (hi < n_resp ? uint32_t(resp[hi]) << 16 : 0u));
+        for (uint32_t u = 0; u < nw; ++u) {
+          const uint32_t r = u * uint32_t(M3_GROUP) + l, at = nw * l + u;
+          if (r < n_resp) w[size_t(off_resp) + at / 2] |= uint32_t(resp[r]) << (16 * (at & 1u));
         }
     }
     bh->bytes_tables += 4ull * (off_resp - off_runs);
@@ -409,13 +414,19 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   w[1] = off_tf1;
   const uint32_t n_waves = n_blocks;  // wave-blocks
   const uint32_t n_slots = G * uint32_t(M3_GROUP);
-  w.resize(w.size() + 2 * n_waves + size_t(n_slots) / 4 + size_t(n_slots) / 2, 0u);
+  // the slots' code counts: in the spare six bits of their sigma words where every count fits (a byte per event less to read),
+  // else a byte array in front of the sigma words
+  bool cnt_in_sigma = G != 2 || kTf1CntInSigmaG2;
+  for (uint32_t le = 0; le < ne && cnt_in_sigma; ++le) cnt_in_sigma = codes[le].size() <= 63;
+  const size_t cnt_words = cnt_in_sigma ? 0 : size_t(n_slots) / 4;
+  w.resize(w.size() + 2 * n_waves + cnt_words + size_t(n_slots) / 2, 0u);
   bh->bytes_book = 4ull * (w.size() - off_tf1);
   const size_t codes_from = w.size();
   for (uint32_t k = 0; k < n_slots; ++k) {
     const std::vector<uint8_t>* c = slot_codes(k);
-    w[off_tf1 + 2 * n_waves + k / 4] |= uint32_t(c ? c->size() : 0) << (8 * (k % 4));
-    w[off_tf1 + 2 * n_waves + n_slots / 4 + k / 2] |= uint32_t(sigma[k]) << (16 * (k % 2));
+    const uint32_t n_codes = uint32_t(c ? c->size() : 0);
+    if (!cnt_in_sigma) w[off_tf1 + 2 * n_waves + k / 4] |= n_codes << (8 * (k % 4));
+    w[off_tf1 + 2 * n_waves + cnt_words + k / 2] |= (uint32_t(sigma[k]) | (cnt_in_sigma ? n_codes << 10 : 0u)) << (16 * (k % 2));
   }
   uint64_t tf1_f2 = 0;
   for (uint32_t wv = 0; wv < n_waves; ++wv) {
@@ -442,7 +453,9 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   }
   w[2] = uint32_t(tf1_f2);
   w[4] = sort_slots ? 1u : 0u;
+  w[5] = cnt_in_sigma ? 1u : 0u;
   bh->tf1_sorted = sort_slots;
+  bh->tf1_cnt_in_sigma = cnt_in_sigma;
   bh->n_tf1_f2 = tf1_f2;
   while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);  // the next brick's stream starts on a line
   bh->bytes_codes = 4ull * (w.size() - codes_from);
@@ -479,8 +492,8 @@ void fill_brick(const int16_t* npts, const ChunkInput& in, const BrickHost& bh, 
       // their words point into the scatter array's slack)
       auto word_at = [&](uint32_t i) -> uint32_t {
         const uint32_t u = i / uint32_t(M3_GROUP), l = i % uint32_t(M3_GROUP);
-        const uint32_t d = words[h[3] + stage_word_dwords(n_resp) * l + u / 2];
-        return (u & 1u) ? d >> 16 : d & 0xFFFFu;
+        const uint32_t at = stage_record_words(n_resp) * l + u, d = words[h[3] + at / 2];
+        return (at & 1u) ? d >> 16 : d & 0xFFFFu;
       };
       while (n_run > 0 && ((word_at(start_r + n_run - 1) & 0x7FFCu) >> 2) >= uint32_t(M3_STAGE_CAP)) --n_run;
       const uint32_t n_ext = uint32_t((r + 1 < n_runs ? int64_t(coef_off) + int64_t(stride) * nseg - int64_t(int32_t(runs[2 * (r + 1)])) : int64_t(n_resp)) - int64_t(start_r));

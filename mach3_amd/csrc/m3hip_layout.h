@@ -51,8 +51,8 @@ constexpr int M3_STAGE_CAP = 5120;       // TSpline3 responses per brick stage (
 constexpr int M3_STAGE_MAX_RUNS = 512;   // runs per stage (the resolved run table lives in LDS)
 constexpr int M3_STAGE_EVENT_MAX = 15;   // responses one event may hold in a stage (its count is a nibble)
 constexpr int M3_BRICK_MAX_GROUPS = 4;   // a brick holds up to 4 x M3_GROUP events
-// dwords of response words a lane holds in a stage of n_resp list entries (two 16-bit words per dword)
-constexpr uint32_t stage_word_dwords(uint32_t n_resp) { return ((n_resp + 1023u) / 1024u + 1u) / 2u; }
+// 16-bit response words a lane holds in a stage of n_resp list entries = the length of its record (m3hip_layout.cpp)
+constexpr uint32_t stage_record_words(uint32_t n_resp) { return (n_resp + 1023u) / 1024u; }
 constexpr int M3_STAGE_PAIR_WORDS = M3_STAGE_CAP / 64;  // {run of the group's first response, first slot of wave-block} pairs per stage
 constexpr int M3_BRICK_MAX_STAGES = 250; // stage headers are staged in LDS (one load per lane of the workgroup)
 constexpr int M3_BRICK_HDR0 = 8;         // words in front of the stage headers
@@ -61,6 +61,7 @@ constexpr int M3_RUN_WORDS = 2;          // words per run entry
 constexpr int M3_PLANE_ALIGN = 8;        // quads: segment planes of a run start on 128-B lines
 constexpr int M3_WAVE = 64;              // events per jagged TF1 block
 constexpr int M3_TF1_MAX_CODES = 255;    // TF1 codes (responses + skips) per event
+constexpr bool kTf1CntInSigmaG2 = false;  // bricks of 2048 events keep the TF1 code counts as a byte array (m3hip_kernels.hip: book_word)
 constexpr int M3_TF1_SKIP = 255;         // code: advance 254 dictionary entries, no response
 // idle lanes of the brick kernel read (and drop) what lies behind the list they index: every chunk's stores are allocated
 // with this much room behind them
@@ -102,6 +103,7 @@ struct BrickHost {
   uint32_t n_stages = 0;           // TSpline3 stages
   uint32_t groups = 1;             // G: the brick spans up to G x M3_GROUP events
   bool tf1_sorted = false;         // the TF1 lane-slots take the events in order of descending code count
+  bool tf1_cnt_in_sigma = false;   // no event has more than 63 TF1 codes: the slots' counts travel in their sigma words
 };
 
 struct ChunkInput {

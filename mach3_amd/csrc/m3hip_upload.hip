@@ -468,7 +468,7 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
     bd.n_dict = uint32_t(plan.tf1_dict.size());
     bd.spl_last_off = bh.n_spl_f4 ? uint32_t((bh.n_spl_f4 - 1) * 16) : 0u;
     bd.pad_[0] = bh.groups;
-    bd.pad_[1] = bh.tf1_sorted ? 1u : 0u;
+    bd.pad_[1] = (bh.tf1_sorted ? 1u : 0u) | (bh.tf1_cnt_in_sigma ? 2u : 0u);
     h->h_bricks.push_back(bd);
   }
   h->n_uniform += plan.n_uniform;

@@ -36,15 +36,14 @@ for b in range(nb):
         h0, off_runs, off_grp, off_resp = [int(v) for v in w[HDR0 + 4 * s: HDR0 + 4 * s + 4]]
         n_resp, n_runs = h0 & 0xFFFF, (h0 >> 16) & 0x3FF
         runs = w[off_runs: off_runs + 2 * n_runs].reshape(-1, 2)
-        resp = np.zeros(n_resp, np.uint16)   # per-lane records of nd dwords, two words per dword (m3hip_layout.h: stage_word_dwords)
-        nd, lanes = ((n_resp + 1023) // 1024 + 1) // 2, min(1024, n_resp)
-        rec = w[off_resp: off_resp + nd * lanes].reshape(lanes, nd)
-        for k in range(nd):
-            lo = 2048 * k
-            n_lo = max(0, min(lanes, n_resp - lo))
-            resp[lo: lo + n_lo] = rec[:n_lo, k] & 0xFFFF
-            n_hi = max(0, min(lanes, n_resp - lo - 1024))
-            resp[lo + 1024: lo + 1024 + n_hi] = rec[:n_hi, k] >> 16
+        resp = np.zeros(n_resp, np.uint16)   # per-lane records (m3hip_layout.h: stage_record_words)
+        nrec, lanes = (n_resp + 1023) // 1024, min(1024, n_resp)     # record [l] = nrec uint16: the lane's words next to each other
+        n16 = nrec * lanes
+        rec16 = w[off_resp: off_resp + (n16 + 1) // 2].view(np.uint16)
+        rec = rec16[:n16].reshape(lanes, nrec)
+        for u in range(nrec):
+            n_u = max(0, min(lanes, n_resp - 1024 * u))
+            resp[1024 * u: 1024 * u + n_u] = rec[:n_u, u]
         ends = np.flatnonzero(resp & 1) + 1
         first_r = np.concatenate([[0], ends[:-1]])
         for rn in range(n_runs):
@@ -54,7 +53,7 @@ for b in range(nb):
             tot["quads_used"] += 16 * int(((resp[first_r[rn]: ends[rn]] >> 2) < 5120).sum())
             for L in range((16 * q0) // 128, (16 * (q0 + n) - 1) // 128 + 1):
                 lines.add(L)
-        tot["resp_words"] += 4 * nd * lanes
+        tot["resp_words"] += 4 * ((n16 + 1) // 2)
         tot["run_tab"] += 8 * n_runs
         tot["pair_tab"] += 4 * (5120 // 64)
         tot["stage_counts"] += 512 * G
@@ -65,9 +64,10 @@ for b in range(nb):
     tot["tf1_lines"] += 128 * ((8 * (tf1_off + n_f2) + 127) // 128 - (8 * tf1_off) // 128)
     tot["words"] += 4 * nw
     tot["hdr"] += 4 * (HDR0 + 4 * n_stages)
-    tot["tf1_hdr"] += 4 * (32 * G + 256 * G)            # wave-block bases + one count byte per lane-slot
+    cnt_words = 0 if int(w[5]) else 256 * G             # the count bytes: absent where the counts ride in the sigma words
+    tot["tf1_hdr"] += 4 * (32 * G + cnt_words)          # wave-block bases + one count byte per lane-slot
     tot["tf1_sigma"] += 2 * 1024 * G
-    tot["tf1_codes"] += 4 * (nw - off_tf1 - 32 * G - 256 * G - 512 * G)   # upper bound: to the end of the (128-B padded) stream
+    tot["tf1_codes"] += 4 * (nw - off_tf1 - 32 * G - cnt_words - 512 * G)   # upper bound: to the end of the (128-B padded) stream
 S, T = ch["n_splines"], ch["n_tf1"]
 alg = 16 * S + 8 * T + 8 * ev
 sample_side = ev * 8   # the packed word {bin, osc, <= 3 norm indices}; the three arrays it replaces were 4 + 4 + 2 * slots bytes

@@ -165,16 +165,16 @@ def brick_event_lists(npts, ch, lay, b):
             for h in range(4):
                 cnt[1024 * h: 1024 * (h + 1)] = (hw >> (4 * h)) & 15
         assert not cnt[nev:].any() and cnt.max() == rows <= STAGE_EVENT_MAX
-        resp = np.zeros(n_resp, np.uint16)                # two per dword, a lane's dwords next to each other
-        nd, lanes = ((n_resp + 1023) // 1024 + 1) // 2, min(1024, n_resp)
-        rec = w[off_resp: off_resp + nd * lanes].reshape(lanes, nd)
-        for k in range(nd):
-            lo = 2048 * k
-            n_lo = max(0, min(lanes, n_resp - lo))
-            resp[lo: lo + n_lo] = rec[:n_lo, k] & 0xFFFF
-            n_hi = max(0, min(lanes, n_resp - lo - 1024))
-            resp[lo + 1024: lo + 1024 + n_hi] = rec[:n_hi, k] >> 16
-            assert not (rec[n_hi:, k] >> 16).any() and not (rec[n_lo:, k] & 0xFFFF).any()
+        resp = np.zeros(n_resp, np.uint16)                # per-lane records
+        nw, lanes = (n_resp + 1023) // 1024, min(1024, n_resp)     # record [l] = nw uint16: the lane's words next to each other
+        n16 = nw * lanes
+        rec16 = w[off_resp: off_resp + (n16 + 1) // 2].view(np.uint16)
+        assert not rec16[n16:].any()
+        rec = rec16[:n16].reshape(lanes, nw)
+        for u in range(nw):
+            n_u = max(0, min(lanes, n_resp - 1024 * u))
+            resp[1024 * u: 1024 * u + n_u] = rec[:n_u, u]
+            assert not rec[n_u:, u].any()
         ell = {}
         run = -1
         n_pad = 0
@@ -229,9 +229,15 @@ def brick_event_lists(npts, ch, lay, b):
         assert os.environ.get("M3HIP_PAD_RUNS") == "1" or pads_total * 100 <= 8 * (entries_total - pads_total)
     # TF1: jagged rows per wave-block of 64 lane-slots; slot k = 1024 h + l works on event 1024 h + sigma[k] of the brick
     n_slots = 1024 * G
-    hdr = w[off_tf1: off_tf1 + 32 * G + n_slots // 4 + n_slots // 2]
-    cnts = hdr[32 * G: 32 * G + n_slots // 4].view(np.uint8)
-    sigma = hdr[32 * G + n_slots // 4:].view(np.uint16).astype(np.int64)
+    if int(w[5]):                                       # no event with more than 63 codes: the counts ride in the sigma words
+        hdr = w[off_tf1: off_tf1 + 32 * G + n_slots // 2]
+        s16 = hdr[32 * G:].view(np.uint16).astype(np.int64)
+        cnts, sigma = s16 >> 10, s16 & 1023
+    else:
+        hdr = w[off_tf1: off_tf1 + 32 * G + n_slots // 4 + n_slots // 2]
+        cnts = hdr[32 * G: 32 * G + n_slots // 4].view(np.uint8)
+        sigma = hdr[32 * G + n_slots // 4:].view(np.uint16).astype(np.int64)
+        assert sigma.max() < 1024 and (cnts.max() > 63 or G == 2)   # (bricks of 2048 events keep the byte array)
     ev_of = (np.arange(n_slots) // 1024) * 1024 + sigma
     for h in range(G):                                  # a permutation of every slab, existing events first, longest first
         sl = slice(1024 * h, 1024 * (h + 1))
