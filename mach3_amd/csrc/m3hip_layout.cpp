@@ -337,6 +337,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
     // response words, a lane's next to each other (one load fetches them): lane l of the workgroup works on responses l, l + 1024,
     // l + 2048, ... of the stage; record [l] = nw uint16, word u = response l + 1024 u, nw = stage_record_words(n_resp); records
     // for the lanes that hold a response
+    while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);  // a wave's 64 records of 8 or 10 bytes are then whole lines
     const uint32_t off_resp = uint32_t(w.size());
     {
       const uint32_t nw = stage_record_words(n_resp), lanes = std::min<uint32_t>(uint32_t(M3_GROUP), n_resp);
@@ -430,6 +431,11 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
   }
   uint64_t tf1_f2 = 0;
   for (uint32_t wv = 0; wv < n_waves; ++wv) {
+    // a wave-block's rows and its code dwords start on 128-byte lines: whole rows (64 lanes: four lines of {a,b}, two of codes) then
+    // ARE whole lines.  Laid end to end, nearly every row shared its first and last line with a neighbour -- two non-temporal
+    // requests, often two fetches (config 3 -0.8 %, one GPU's share of config 5 -2 %: profiles/r05_brick_stream_alignment_ab.txt)
+    while (tf1_f2 % (128 / 8)) { bh->tf1_src.push_back(0xFFFFFFFFu); ++tf1_f2; }
+    while (w.size() % size_t(M3_BRICK_ALIGN_WORDS)) w.push_back(0u);
     w[off_tf1 + wv] = uint32_t(tf1_f2);
     w[off_tf1 + n_waves + wv] = uint32_t(w.size());
     const uint32_t k0 = wv * uint32_t(M3_WAVE), k1 = k0 + uint32_t(M3_WAVE);
@@ -451,6 +457,7 @@ bool plan_brick(int n_params, const int16_t* npts, const ChunkInput& in, const s
         }
       }
   }
+  while (tf1_f2 % (128 / 8)) { bh->tf1_src.push_back(0xFFFFFFFFu); ++tf1_f2; }  // (the next brick's store starts on a line as well)
   w[2] = uint32_t(tf1_f2);
   w[4] = sort_slots ? 1u : 0u;
   w[5] = cnt_in_sigma ? 1u : 0u;

@@ -168,6 +168,7 @@ def brick_event_lists(npts, ch, lay, b):
         resp = np.zeros(n_resp, np.uint16)                # per-lane records
         nw, lanes = (n_resp + 1023) // 1024, min(1024, n_resp)     # record [l] = nw uint16: the lane's words next to each other
         n16 = nw * lanes
+        assert off_resp % 32 == 0                                   # a wave's 64 records are whole 128-byte lines
         rec16 = w[off_resp: off_resp + (n16 + 1) // 2].view(np.uint16)
         assert not rec16[n16:].any()
         rec = rec16[:n16].reshape(lanes, nw)
@@ -251,6 +252,11 @@ def brick_event_lists(npts, ch, lay, b):
     slots = 0
     for wv in range(n_blocks):
         cbase, dbase = int(hdr[wv]), int(hdr[16 * G + wv])
+        assert cbase % 16 == 0 and dbase % 32 == 0 and (tf1_off + cbase) % 16 == 0   # a wave-block's rows and code dwords start on 128-byte lines
+        assert cbase - slots < 16                                                    # (behind at most a line's worth of identity slots)
+        for i in range(slots, cbase):
+            assert np.array_equal(tf1[tf1_off + i], np.array([0, 1], np.float32))
+        slots = cbase
         lanes = [k for k in range(64 * wv, 64 * wv + 64) if ev_of[k] < nev]
         kd = {k: -1 for k in lanes}
         rows = max([int(cnts[k]) for k in lanes], default=0)
@@ -272,7 +278,7 @@ def brick_event_lists(npts, ch, lay, b):
                     out[int(ev_of[k])].append((int(tdict[kd[k]]), "tf1", ab))
             cbase += len(act)
             slots += len(act)
-    assert slots == int(w[2]) == n_f2
+    assert -(-slots // 16) * 16 == int(w[2]) == n_f2
     return e0, out
 
 
