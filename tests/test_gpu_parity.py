@@ -730,6 +730,24 @@ def test_many_distinct_uniform_lists(fresh_engine):
     assert info.n_tiles_uniform == T and info.n_tiles_brick == 0 and info.n_tiles_padded == 0
 
 
+@pytest.mark.parametrize("per_event", [0.6, 1.7, 2.8, 3.8, 4.8])
+def test_one_stage_bricks_of_every_record_length(fresh_engine, per_event):
+    """A lane's response words of a stage are a record of 1 .. 5 uint16 read with one 12-byte load (m3hip_layout.cpp: records of
+    2-byte granularity, so with 3 or 5 words every other record starts on a 2-byte boundary): one 1024-event brick whose TSpline3
+    responses fill ONE stage with 1, 2, 3, 4 and 5 words per lane, a second, partly filled brick behind it; weights bit for bit."""
+    rng = np.random.default_rng(int(per_event * 10))
+    X7, X5 = np.arange(-3.0, 4.0), np.array([-2.0, -1, 0, 1, 2])
+    P = 48
+    xs = {p: (X7 if p % 2 else X5) for p in range(P) if p % 6}       # five sixths TSpline3, one sixth TF1
+    events = _ragged_events(rng, 1024 + 300, P, per_event / len(xs), xs)
+    n_spl = sum(1 for e in events[:1024] for r in e if r[1] == "spl")
+    words = -(-n_spl // 1024)
+    assert words == int(per_event) + 1 and n_spl <= 5120              # (run padding may add a few list entries: stays in one stage)
+    cx, npts, ch = make_monolith(P, 7, xs, events)
+    info = _eval_matches(fresh_engine, P, 7, cx, npts, ch, rng, laps=3)
+    assert info.n_tiles_brick == 2 and info.n_tiles_uniform == 0
+
+
 @pytest.mark.parametrize("grouping", ["on", "off"])
 def test_shuffled_modes_are_grouped_by_the_engine(fresh_engine, grouping, monkeypatch):
     """Events of three interaction modes (each with its own parameter list, a tenth of the splines flat and dropped)
