@@ -9,6 +9,8 @@
 //   2  the same three kernels as ONE hipGraphLaunch       (arguments fixed; the step number travels in a device word)
 //   3  two launches: the prep work folded into every workgroup's prologue of the reweight kernel (table in LDS)
 //   4  one launch: as 3, and the workgroup that finishes LAST (atomic counter behind a device-scope fence) runs the likelihood
+//   5  the three launches of step s + 1 ENQUEUED WHILE STEP s RUNS: its prep kernel waits (one lane polls a doorbell word in mapped
+//      host memory, with a time-out) until the host has written the step's parameters -- launch latency leaves the critical path
 // Results are checked against each other (the same sum every scheme).  Build: make tools; run: build/step_floor [steps=3000]
 #include <hip/hip_runtime.h>
 
@@ -39,6 +41,7 @@ struct Args {
   unsigned long long* step;   // device word: the step number (graph scheme), bumped by the prep kernel
   unsigned int* arrived;      // device word: workgroups through (one-launch scheme)
   unsigned long long ticket;  // direct schemes: this step's number
+  const unsigned long long* door;  // mapped pinned: the doorbell of scheme 5 (nullptr: no waiting)
 };
 
 __device__ void prep_table(const Args& a, float* table, int tid, int nt) {
@@ -55,6 +58,13 @@ __device__ void prep_table(const Args& a, float* table, int tid, int nt) {
 }
 
 __global__ __launch_bounds__(kLanes) void k_prep(Args a) {
+  if (a.door) {  // scheme 5: enqueued ahead of its parameters
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();  // 100 MHz
+      while (__hip_atomic_load(a.door, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.ticket && wall_clock64() - t0 < 200000000ull) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
   for (int b = threadIdx.x; b < kRep * kBins; b += kLanes) a.hist[b] = 0.0;
   prep_table(a, a.table, threadIdx.x, kLanes);
   if (a.step && threadIdx.x == 0) *a.step += 1;
@@ -166,6 +176,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&d_arr, 4));
   CK(hipMemset(d_step, 0, 8));
   CK(hipMemset(d_arr, 0, 4));
+  unsigned long long* h_door;
+  CK(hipHostMalloc((void**)&h_door, 64, hipHostMallocMapped));
+  *h_door = 0;
+  const unsigned long long* d_door;
+  CK(hipHostGetDevicePointer((void**)&d_door, h_door, 0));
   volatile unsigned long long* flag = (volatile unsigned long long*)h_out + 1;
   *flag = 0;
   unsigned long long ticket = 0;
@@ -200,12 +215,25 @@ int main(int argc, char** argv) {
     unsigned long long bad = 0;
     double t0 = 0;
     const int warm = 300;
+    auto enqueue_armed = [&](unsigned long long t) {
+      Args x = a;
+      x.ticket = t;
+      x.door = d_door;
+      hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, x);
+      hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+      hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, x);
+    };
+    if (scheme == 5) enqueue_armed(ticket + 1 + (1ull << 40));
     for (int s = 0; s < warm + steps; ++s) {
       if (s == warm) t0 = now_s();
       set_params((unsigned long long)s);
       Args x = a;
       unsigned long long want;
-      if (scheme == 2) {
+      if (scheme == 5) {
+        want = ++ticket + (1ull << 40);
+        __atomic_store_n(h_door, want, __ATOMIC_RELEASE);  // the parameters are in place: go
+        enqueue_armed(want + 1);                           // the next step's launches, behind this step's kernels
+      } else if (scheme == 2) {
         want = ++graph_steps;
         CK(hipGraphLaunch(gexec, st));
       } else {
@@ -229,6 +257,10 @@ int main(int argc, char** argv) {
       if (!have_ref && s == 127) have_ref = true;
     }
     const double el = now_s() - t0;
+    if (scheme == 5) {  // the step that was enqueued last never gets parameters of its own: let it run on the last ones
+      __atomic_store_n(h_door, ++ticket + (1ull << 40), __ATOMIC_RELEASE);
+      wait(ticket + (1ull << 40));
+    }
     std::printf("scheme %d  %-58s %7.2f us/step%s\n", scheme, name, 1e6 * el / steps, bad ? "   (RESULTS DIFFER)" : "");
     std::fflush(stdout);
   };
@@ -251,6 +283,7 @@ int main(int argc, char** argv) {
     run(2, "the three kernels as one hipGraphLaunch");
     run(3, "two launches: prep inside the reweight kernel's prologue");
     run(4, "one launch: ... and the likelihood by the last workgroup");
+    run(5, "three launches enqueued a step ahead, prep waits for a doorbell");
   }
   return 0;
 }
