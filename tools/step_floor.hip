@@ -11,6 +11,7 @@
 //   4  one launch: as 3, and the workgroup that finishes LAST (atomic counter behind a device-scope fence) runs the likelihood
 //   5  the three launches of step s + 1 ENQUEUED WHILE STEP s RUNS: its prep kernel waits (one lane polls a doorbell word in mapped
 //      host memory, with a time-out) until the host has written the step's parameters -- launch latency leaves the critical path
+//   6  3 and 5 together: two launches enqueued ahead, every workgroup of the reweight kernel waits for the doorbell itself
 // Results are checked against each other (the same sum every scheme).  Build: make tools; run: build/step_floor [steps=3000]
 #include <hip/hip_runtime.h>
 
@@ -108,6 +109,13 @@ __global__ __launch_bounds__(kLanes) void k_reweight(Args a) {
   __shared__ float s_table[kPar];
   __shared__ double s_hist[kBins];
   __shared__ bool s_last;
+  if (OWN_PREP && a.door) {  // scheme 6: every workgroup waits for the doorbell itself
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.door, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.ticket && wall_clock64() - t0 < 200000000ull) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+  }
   for (int b = threadIdx.x; b < kBins; b += kLanes) s_hist[b] = 0.0;
   if (OWN_PREP) prep_table(a, s_table, threadIdx.x, kLanes);  // every workgroup fetches the parameters itself (PCIe) and builds its table
   else
@@ -219,17 +227,22 @@ int main(int argc, char** argv) {
       Args x = a;
       x.ticket = t;
       x.door = d_door;
-      hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, x);
-      hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
-      hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, x);
+      if (scheme == 5) {
+        hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, x);
+        hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, x);
+      } else {
+        hipLaunchKernelGGL((k_reweight<true, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        hipLaunchKernelGGL(k_llh<true>, dim3(1), dim3(kLanes), 0, st, x);
+      }
     };
-    if (scheme == 5) enqueue_armed(ticket + 1 + (1ull << 40));
+    if (scheme >= 5) enqueue_armed(ticket + 1 + (1ull << 40));
     for (int s = 0; s < warm + steps; ++s) {
       if (s == warm) t0 = now_s();
       set_params((unsigned long long)s);
       Args x = a;
       unsigned long long want;
-      if (scheme == 5) {
+      if (scheme >= 5) {
         want = ++ticket + (1ull << 40);
         __atomic_store_n(h_door, want, __ATOMIC_RELEASE);  // the parameters are in place: go
         enqueue_armed(want + 1);                           // the next step's launches, behind this step's kernels
@@ -257,7 +270,7 @@ int main(int argc, char** argv) {
       if (!have_ref && s == 127) have_ref = true;
     }
     const double el = now_s() - t0;
-    if (scheme == 5) {  // the step that was enqueued last never gets parameters of its own: let it run on the last ones
+    if (scheme >= 5) {  // the step that was enqueued last never gets parameters of its own: let it run on the last ones
       __atomic_store_n(h_door, ++ticket + (1ull << 40), __ATOMIC_RELEASE);
       wait(ticket + (1ull << 40));
     }
@@ -284,6 +297,7 @@ int main(int argc, char** argv) {
     run(3, "two launches: prep inside the reweight kernel's prologue");
     run(4, "one launch: ... and the likelihood by the last workgroup");
     run(5, "three launches enqueued a step ahead, prep waits for a doorbell");
+    run(6, "two launches enqueued a step ahead, every workgroup waits");
   }
   return 0;
 }
