@@ -75,17 +75,19 @@ def _self_launch():
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] --gpus {want} without a launcher: starting {want} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr is inherited: progress shows as it happens
-    line = None
-    for ln in r.stdout.splitlines():
+    # stderr is inherited: progress shows as it happens.  Rank 0's JSON lines are passed on AS THEY COME (the headline line before
+    # the legs under `extra`, the complete one at the end), so that a caller who stops this process early still has the first
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    seen = 0
+    for ln in p.stdout:
         if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-    if line is not None:
-        print(line, flush=True)
-    elif r.returncode == 0:
+            print(ln.rstrip("\n"), flush=True)
+            seen += 1
+    rc = p.wait()
+    if not seen and rc == 0:
         print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
         raise SystemExit(5)
-    raise SystemExit(r.returncode)
+    raise SystemExit(rc)
 
 
 if __name__ == "__main__":
@@ -331,8 +333,28 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback, 
 
     laps = [synth.params(spec, 1 + i) for i in range(64)]
 
+    # The step of a fit that MOVES oscillation parameters (--table host | device): the weight table is replaced before every
+    # reweight, as OscillationHandler::Evaluate refills it inside every Reweight of the reference (SampleHandlerFD.cpp:323).  Eight
+    # tables of the same values with every entry different from lap to lap; "device": they lie in device memory the engine
+    # does not own (where a GPU calculator leaves them) and are read in place, "host": they come through the pinned staging
+    # copy.  The oscillation calculation itself is not part of the path (BASELINE: probabilities pre-staged).
+    table = getattr(args, "table", "resting")
+    move = None
+    if table != "resting":
+        base_tbl = synth.osc_table(spec)
+        tables = [np.ascontiguousarray(np.roll(base_tbl, 977 * k)) for k in range(8)]
+        if table == "device":
+            d_tables = [torch.from_numpy(t).cuda() for t in tables]
+            torch.cuda.synchronize()
+            ptrs = [t.data_ptr() for t in d_tables]
+            move = lambda i: sh.SetOscillationWeightsDevice(ptrs[i % 8], spec.osc_n)  # noqa: E731
+        else:
+            move = lambda i: sh.SetOscillationWeights(tables[i % 8])  # noqa: E731
+
     def step(i):
         par[:] = laps[i % len(laps)]
+        if move is not None:
+            move(i)
         if not fallback:
             return sh.Step()
         sh.Reweight()  # partial bins of this rank's shard
@@ -533,6 +555,37 @@ def workload_text(base, spec, n_ranks):
             f"{STAT_NAME.get(int(spec.test_statistic), '?')} LLH{shard}")
 
 
+def table_text(args, spec):
+    t = getattr(args, "table", "resting")
+    out = "" if t == "resting" else f"; oscillation table REPLACED EVERY STEP from {t} memory ({spec.osc_n} entries)"
+    return out + ("; MC in oscillation-bin order" if spec.osc_sorted else "")
+
+
+def osc_moves_leg(args, local_rank, torch):
+    """`--osc-moves`: the step of a fit that moves oscillation parameters, beside the pre-staged one.  One GPU's share of configs[4]
+    (1.25e7 events, 1 024 systematics, beam + atmospheric tables = 204 000 entries) and configs[2] (4 000 entries), each with the
+    table resting, replaced every step from host memory and from device memory; configs[4]'s share also with the MC registered in
+    oscillation-bin order (M3::OscillationBinOrder), where a wave's 64 events read one or two lines of the table instead of 64."""
+    from mach3_amd import synth
+    res = {"what": "kernel = fused reweight kernel by dispatch-stamped events; frac = algorithmic bytes / kernel / 8 TB/s; table replaced before every step"}
+    shapes = [("configs[4] one GPU's share of 8", synth.CONFIGS["c5"].scaled(12_500_000), "c5"),
+              ("configs[4] share, MC in oscillation-bin order", synth.CONFIGS["c5"].scaled(12_500_000, osc_sorted=True), "c5"),
+              ("configs[2]", synth.CONFIGS["c3"], "c3")]
+    for name, spec, base_name in shapes:
+        row = {"events": spec.n_events, "osc_entries": spec.osc_n}
+        lines = None
+        for tbl in ("resting", "device", "host"):
+            a = argparse.Namespace(**vars(args))
+            a.check, a.table, a.spinup_seconds, a.warmup = False, tbl, min(args.spinup_seconds, 0.5), max(args.warmup, 8)
+            m = measure(spec, 0, 1, local_rank, a, None, torch, False)
+            row[tbl] = {"ms_per_step": 1e3 * m["el"] / a.steps, "avg_kernel_ms": m["k_ms"], "launches_timed": m["k_n"],
+                        "frac": m["info"].alg_bytes_fused / (m["k_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if m["k_ms"] > 0 else None}
+            lines = round(float(m["info"].osc_lines_per_kevent), 1)
+        row["osc_lines_per_kevent"] = lines
+        res[name] = row
+    return res
+
+
 def roofline(base_name, m, per_gpu):
     info, k_ms = m["info"], m["k_ms"]
     tr = pmc_traffic(base_name, per_gpu)
@@ -576,6 +629,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] line under `extra`")
     ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--table", choices=["resting", "host", "device"], default="resting",
+                    help="the oscillation table of the HEADLINE workload: resting = pre-staged once (BASELINE's configs; the default), host / device = "
+                         "replaced before every step through m3hip_set_osc_table / m3hip_set_osc_table_device (profiling the moving-table step; the workload text says so)")
+    ap.add_argument("--osc-sorted", action="store_true", help="the MC registered in oscillation-bin order (SynthSpec.osc_sorted; the workload text says so)")
+    ap.add_argument("--osc-moves", action="store_true",
+                    help="N = 1: also measure the step of a fit that moves oscillation parameters -- one GPU's share of configs[4] (1.25e7 events, 204 000-entry table) and "
+                         "configs[2], table resting / replaced every step from host memory / from device memory, MC in random and in oscillation-bin order -- under "
+                         "`extra.osc_moves`, never as `value`")
     ap.add_argument("--check", action="store_true",
                     help="N > 1: rank 0 also runs the whole sample on its own GPU and compares the LLH of three laps (<= 1e-9 relative)")
     ap.add_argument("--allow-host-fallback", action="store_true",
@@ -618,6 +679,8 @@ def main():
     cfg = args.config if args.config != "auto" else "c3"  # ONE workload for the whole --gpus series
     base = synth.CONFIGS[cfg]
     spec = base.scaled(args.events) if args.events else base
+    if args.osc_sorted:
+        spec = spec.scaled(spec.n_events, osc_sorted=True)
 
     m = measure(spec, rank, n_gpus, local_rank, args, dist, torch, args.allow_host_fallback)
     ranks_seen = 1
@@ -656,8 +719,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": workload_text(base, spec, n_gpus),
+                "workload": workload_text(base, spec, n_gpus) + table_text(args, spec),
                 "total_events": spec.n_events,
+                # which configuration `value` is of (rounds <= 3 switched to configs[3] at N >= 4; since round 4 every N runs configs[2])
+                "headline": f"configs[{CFG_INDEX.get(base.name, '?')}]",
                 "ranks_seen": ranks_seen,
                 # the job's work rate in events x steps per second (comparable with `extra.configs[3]`, four times the events)
                 "event_steps_per_s": spec.n_events * args.steps / m["el"],
@@ -666,6 +731,8 @@ def main():
                 "comm": m["comm"],
                 "last_llh": m["llh"],
                 "brick_events": 1024 * int(m["info"].brick_groups or 1),
+                # distinct 128-B lines of the oscillation table per 1024 consecutive events (m3hip_info; ~1: MC in oscillation-bin order)
+                "osc_lines_per_kevent": round(float(m["info"].osc_lines_per_kevent), 1),
                 # rank 0's brick kernel: MB of the small streams a step re-reads that the engine keeps cached, to find them in the
                 # 256 MB Infinity Cache again next step, and whether the TF1 codes had to go around it
                 "infinity_cache": {"cached_small_streams_MB": round(int(m["info"].cached_stream_bytes) / 1e6, 1),
@@ -702,16 +769,30 @@ def main():
             except Exception as e:
                 out.setdefault("extra", {})["configs[1]"] = {"failed": str(e)}
                 failed_extras.append("configs[1]")
+        if n_gpus == 1 and args.osc_moves:
+            try:
+                out.setdefault("extra", {})["osc_moves"] = osc_moves_leg(args, local_rank, torch)
+            except Exception as e:
+                out.setdefault("extra", {})["osc_moves"] = {"failed": f"{type(e).__name__}: {e}"}
+                failed_extras.append("osc_moves")
     # ---- legs under `extra` that are collectives (every rank runs them): the one-shot exchange beside RCCL, and from four
     # GPUs on BASELINE configs[3].  The headline numbers are in hand; each leg runs behind a watchdog, and a leg that does not
     # return within its limit is reported as text in its place -- rank 0 prints the line as it stands and every rank leaves.
     import threading
 
     def run_leg(name, limit, fn):
+        # the line as it stands when the leg starts, serialised HERE: the watchdog's thread must not walk a dictionary the main
+        # thread may be filling at that moment
+        snap = None
+        if rank == 0:
+            o = json.loads(json.dumps(out))
+            o.setdefault("extra", {})[name] = {"error": f"did not finish within {limit:.0f} s; abandoned (the line above it stands)"}
+            o["extra_failed"] = failed_extras + [name]
+            snap = json.dumps(o)
+
         def give_up():
             if rank == 0:
-                out.setdefault("extra", {})[name] = {"error": f"did not finish within {limit:.0f} s; abandoned (the line above it stands)"}
-                print(json.dumps(out), file=json_out, flush=True)
+                print(snap, file=json_out, flush=True)
             log(f"[bench] rank {rank}: `extra.{name}` did not return within {limit:.0f} s; leaving without it")
             os._exit(4 if check is not None and not check["ok"] else (6 if args.strict else 0))
         wd = threading.Timer(limit, give_up)
@@ -719,14 +800,22 @@ def main():
         wd.start()
         try:
             res = fn()
-        except BaseException as e:  # (the legs report their own failures as text; this is the belt to those braces)
+        except Exception as e:  # (the legs report their own failures as text; this is the belt to those braces.  SystemExit and KeyboardInterrupt pass)
             res = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
-        wd.cancel()
+        finally:
+            wd.cancel()
         if isinstance(res, dict) and ("error" in res or "failed" in res or res.get("ok") is False):
             failed_extras.append(name)
         if rank == 0:
             out.setdefault("extra", {})[name] = res
         return res
+
+    # N > 1: the headline line goes out BEFORE the collective legs under `extra` (flushed; `"final": false`), and the complete line
+    # once more at the end: whoever stops this process inside a leg -- a driver's time-out on a cold eight-GPU node -- still finds
+    # a parsable line with the headline numbers; a reader that takes the LAST line gets everything.  N = 1 prints one line.
+    will_run_legs = m.get("after") is not None or (n_gpus >= 4 and args.config == "auto" and not args.no_c4_extra)
+    if rank == 0 and n_gpus > 1 and will_run_legs:
+        print(json.dumps(dict(out, final=False)), file=json_out, flush=True)
 
     if m.get("after") is not None:
         run_leg("oneshot_exchange", float(os.environ.get("M3_BENCH_ONESHOT_LIMIT_S", "180")), m["after"])
@@ -736,6 +825,8 @@ def main():
             pass
     if n_gpus >= 4 and args.config == "auto" and not args.no_c4_extra:
         def c4_leg():
+            if os.environ.get("M3_BENCH_TEST_STALL_LEG_S"):  # tests: a leg that is slow but alive (the caller stops the run inside it)
+                time.sleep(float(os.environ["M3_BENCH_TEST_STALL_LEG_S"]))
             a4 = argparse.Namespace(**vars(args))
             a4.check = False
             a4.spinup_seconds = min(args.spinup_seconds, 0.5)

@@ -265,6 +265,20 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
  * event pointers, Samples/OscillationHandler.cpp:81-119).  May be re-uploaded per step. */
 int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n);
 int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n);
+/* The same table where a GPU calculator LEFT it: `d_table` is device memory of the engine's device and is read in place by the
+ * kernels of the following reweights -- no copy, no host round trip.  This is the reference's own arrangement: the events'
+ * oscillation pointers alias the calculator's weight array (Samples/SampleHandlerFD.cpp:1108-1133, NuOscillator's
+ * ReturnWeightPointer, Samples/OscillationHandler.cpp:103-119), which OscillationHandler::Evaluate refills inside every Reweight
+ * (SampleHandlerFD.cpp:323, OscillationHandler.cpp:81-100).  Call it after every refill (cheap: no device work, the pointer is
+ * checked the first time only); the call is what tells the engine that the weights changed.
+ * ORDERING is by the handle's stream: the refill must have completed, or have been enqueued on the handle's stream
+ * (m3hip_set_stream makes the calculator's stream the engine's), before m3hip_reweight / m3hip_step is called; and the array
+ * must not be overwritten before that step has completed (m3hip_get_likelihood / m3hip_step returned, or m3hip_sync) --
+ * unless the writer is enqueued on the same stream behind it.  The array stays the caller's; it must outlive its use here
+ * (until the next m3hip_set_osc_table* call or m3hip_destroy).  Errors: M3HIP_EINVAL for a host pointer or another device's
+ * memory. */
+int m3hip_set_osc_table_device(m3hip_handle h, const float* d_table, uint64_t n);
+int m3hip_set_osc_table_device_f64(m3hip_handle h, const double* d_table, uint64_t n);
 
 /* Experiment weights behind oscillation and splines.  SampleHandlerFD::AddAdditionalWeightPointers
  * (Samples/SampleHandlerFD.cpp:196) lets an experiment append pointers to an event's total_weight_pointers;
@@ -419,6 +433,11 @@ typedef struct {
                                  * cached loads, i.e. that the engine plans to find in the Infinity Cache again next step (stage
                                  * tables, sample words, TF1 bookkeeping, and the TF1 codes unless tf1_codes_around) */
   uint64_t tf1_codes_around;    /* 1: the TF1 codes are loaded non-temporally, around the Infinity Cache (they did not fit beside the others) */
+  double osc_lines_per_kevent;  /* distinct 128-byte lines of the (float) oscillation table that 1024 consecutive events point at, averaged
+                                 * over the uploaded events (0: none uploaded).  Near 1: the MC is registered in oscillation-bin order and a
+                                 * wave's look-ups share a line or two; hundreds: every event reads a line of its own -- free while the table
+                                 * rests (the weights are folded into the events' words), +11 % on BASELINE configs[4]'s kernel when a fit moves
+                                 * oscillation parameters.  SampleHandlerFD::EventOrderByOscillationBin gives the order to register the MC in. */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

@@ -337,6 +337,23 @@ class SampleHandlerFD : public SampleHandlerBase {
   void SetOscillationWeights(const std::vector<float>& w) { M3HIP_CALL(h, m3hip_set_osc_table(h, w.data(), w.size())); }
   /// M3::float_t = double build (with a BinnedSplineHandlerT<double> behind the handle)
   void SetOscillationWeights(const std::vector<double>& w) { M3HIP_CALL(h, m3hip_set_osc_table_f64(h, w.data(), w.size())); }
+  /// The order in which to REGISTER the MC (events, their splines, everything per event) so that events of one oscillation bin lie
+  /// next to each other: stable by oscillation index, events without a pointer (NC: index -1) last.  Any order gives the same
+  /// bins up to fp64 summation order; this one makes the 64 look-ups of a wave fall into one or two 128-byte lines of the weight
+  /// table instead of 64.  It matters only for a LARGE table (atmospheric: 200 000 entries) that a fit MOVES every step: one GPU's
+  /// share of BASELINE configs[4], table replaced every step, 486 us (random order) -> 438 us (this order) = the resting table's
+  /// 436 us (profiles/r06_c5_moving_osc_*).  m3hip_info::osc_lines_per_kevent says which case a sample is in.
+  static std::vector<uint32_t> EventOrderByOscillationBin(const std::vector<int32_t>& osc_idx) {
+    std::vector<uint32_t> order(osc_idx.size());
+    for (size_t e = 0; e < order.size(); ++e) order[e] = uint32_t(e);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return uint32_t(osc_idx[a]) < uint32_t(osc_idx[b]); });
+    return order;
+  }
+  /// The weight array of a GPU oscillation calculator, read where it lies: the reference's events alias the calculator's array
+  /// (SetupNuOscillatorPointers, SampleHandlerFD.cpp:1108-1133) and OscillationHandler::Evaluate refills it inside every Reweight
+  /// (SampleHandlerFD.cpp:323).  Call after every refill; ordering and lifetime as m3hip_set_osc_table_device states (m3hip.h).
+  void SetOscillationWeightsDevice(const float* d_weights, size_t n) { M3HIP_CALL(h, m3hip_set_osc_table_device(h, d_weights, n)); }
+  void SetOscillationWeightsDevice(const double* d_weights, size_t n) { M3HIP_CALL(h, m3hip_set_osc_table_device_f64(h, d_weights, n)); }
 
   /// Experiment weights behind the spline weight.  The reference lets an experiment append pointers to an event's
   /// total_weight_pointers (AddAdditionalWeightPointers, SampleHandlerFD.cpp:196; multiplied in that order at :584-591)

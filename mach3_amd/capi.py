@@ -19,7 +19,7 @@ M3HIP_SYMBOLS = [
     "m3hip_set_spline_param_map", "m3hip_set_binning", "m3hip_upload_events", "m3hip_set_osc_table",
     "m3hip_set_data", "m3hip_set_test_statistic",
     "m3hip_binned_upload", "m3hip_binned_upload_events", "m3hip_get_binned_weights",
-    "m3hip_binned_upload_f64", "m3hip_get_binned_weights_f64", "m3hip_set_osc_table_f64", "m3hip_get_event_weights_f64",
+    "m3hip_binned_upload_f64", "m3hip_get_binned_weights_f64", "m3hip_set_osc_table_f64", "m3hip_set_osc_table_device", "m3hip_set_osc_table_device_f64", "m3hip_get_event_weights_f64",
     "m3hip_set_binning_edges", "m3hip_upload_kinematics", "m3hip_compute_bins", "m3hip_add_kin_shift", "m3hip_add_kin_shift_aux",
     "m3hip_clear_kin_shifts", "m3hip_add_kin_cut", "m3hip_get_event_bins",
     "m3hip_binning_begin", "m3hip_binning_add_uniform", "m3hip_binning_add_nonuniform", "m3hip_binning_end",
@@ -56,7 +56,7 @@ class Info(C.Structure):
         ("coeff_bytes", C.c_uint64), ("alg_bytes_eval", C.c_uint64), ("alg_bytes_fused", C.c_uint64),
         ("n_params", C.c_int), ("max_knots", C.c_int), ("n_bins", C.c_int), ("n_samples", C.c_int),
         ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64), ("brick_groups", C.c_uint64),
-        ("cached_stream_bytes", C.c_uint64), ("tf1_codes_around", C.c_uint64),
+        ("cached_stream_bytes", C.c_uint64), ("tf1_codes_around", C.c_uint64), ("osc_lines_per_kevent", C.c_double),
     ]
 
 
@@ -66,6 +66,7 @@ class SynthConfig(C.Structure):
         ("n_params", C.c_int32), ("n_knots", C.c_int32), ("mixed", C.c_int32), ("n_norm", C.c_int32),
         ("max_norm_per_event", C.c_int32), ("n_samples", C.c_int32), ("n_bins", C.c_int32), ("osc_n", C.c_int32),
         ("occupancy", C.c_double), ("bin_lo", C.c_double), ("bin_hi", C.c_double), ("nc_fraction", C.c_double),
+        ("osc_sorted_events", C.c_uint64),
     ]
 
 
@@ -124,6 +125,8 @@ def load_m3hip():
         "m3hip_binned_upload_f64": [vp, u64, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp],
         "m3hip_get_binned_weights_f64": [vp, vp, i32],
         "m3hip_set_osc_table_f64": [vp, vp, u64],
+        "m3hip_set_osc_table_device": [vp, vp, u64],
+        "m3hip_set_osc_table_device_f64": [vp, vp, u64],
         "m3hip_get_event_weights_f64": [vp, vp, u64, u64],
         "m3hip_upload_kinematics": [vp, u64, u64, vp, vp, i32],
         "m3hip_compute_bins": [vp],

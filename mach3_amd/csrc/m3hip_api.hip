@@ -283,6 +283,7 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) try {
   out->brick_groups = uint64_t(h->brick_groups);
   out->cached_stream_bytes = h->last_cached_bytes;
   out->tf1_codes_around = h->last_nt_codes;
+  out->osc_lines_per_kevent = h->osc_line_blocks ? double(h->osc_line_sum) / double(h->osc_line_blocks) : 0.0;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

@@ -201,6 +201,13 @@ struct m3hip_ctx {
   float* d_osc_table = nullptr;
   uint64_t n_osc = 0;
   bool osc_valid_f32 = false, osc_valid_f64 = false;  // which precision of the table is current on the device
+  // m3hip_set_osc_table_device(_f64): the current table is the CALLER's device array, read where a GPU calculator left it (no
+  // copy; ordered by the handle's stream).  Null: the engine's own copy (d_osc_table / d_osc_table_d) is the current one.
+  const float* d_osc_ext = nullptr;
+  const double* d_osc_ext_d = nullptr;
+  uint64_t osc_line_sum = 0, osc_line_blocks = 0;  // distinct table lines per 1024 consecutive events, summed over the uploaded blocks (m3hip_info)
+  const float* osc_f32() const { return d_osc_ext ? d_osc_ext : d_osc_table; }
+  const double* osc_f64() const { return d_osc_ext_d ? d_osc_ext_d : d_osc_table_d; }
   // per-event oscillation weights for the brick kernel, expanded from a large table once it has stopped changing
   float* d_oscw = nullptr;
   bool oscw_valid = false;

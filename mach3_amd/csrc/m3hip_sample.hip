@@ -136,6 +136,18 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
       h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
     }
     HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    // How local are the look-ups?  Distinct 128-byte lines of a float table per 1024 consecutive events (the events a brick's
+    // slab holds: its waves gather from these lines).  m3hip_info::osc_lines_per_kevent; SampleHandlerFD::EventOrderByOscillationBin.
+    if (event_offset == 0) h->osc_line_sum = h->osc_line_blocks = 0;
+    std::vector<int32_t> ln(1024);
+    for (uint64_t b0 = 0; b0 + 1024 <= n; b0 += 1024) {
+      size_t m = 0;
+      for (uint64_t i = b0; i < b0 + 1024; ++i)
+        if (osc_idx[i] >= 0) ln[m++] = osc_idx[i] >> 5;
+      std::sort(ln.begin(), ln.begin() + m);
+      h->osc_line_sum += uint64_t(std::unique(ln.begin(), ln.begin() + m) - ln.begin());
+      h->osc_line_blocks += 1;
+    }
   }
   if (norm_off) {
     if (norm_off[n] > norm_off[0] && !norm_idx) return fail(h, M3HIP_EINVAL, "upload_events: norm_idx is NULL");
@@ -495,6 +507,8 @@ int m3hip_set_osc_table(m3hip_handle h, const float* table, uint64_t n) try {
   int rc = osc_table_resize(h, n);
   if (rc) return rc;
   if ((rc = osc_upload(h, table, n, sizeof(float), h->d_osc_table))) return rc;
+  h->d_osc_ext = nullptr;
+  h->d_osc_ext_d = nullptr;
   h->osc_valid_f32 = true;
   h->osc_valid_f64 = false;
   h->oscw_valid = false;
@@ -510,12 +524,56 @@ int m3hip_set_osc_table_f64(m3hip_handle h, const double* table, uint64_t n) try
   int rc = osc_table_resize(h, n);
   if (rc) return rc;
   if ((rc = osc_upload(h, table, n, sizeof(double), h->d_osc_table_d))) return rc;
+  h->d_osc_ext = nullptr;
+  h->d_osc_ext_d = nullptr;
   h->osc_valid_f64 = true;
   h->osc_valid_f32 = false;
   h->oscw_valid = false;
   h->osc_static_steps = 0;
   if (h->evw_weight) h->evw_dirty = true;
   return M3HIP_OK;
+} M3_API_CATCH(h)
+
+// The table where a GPU calculator left it (NuOscillator's CUDAProb3-style back ends keep their weight array on the device, and
+// the reference's events alias that array: Samples/SampleHandlerFD.cpp:1108-1122): no copy, the kernels of the following reweights
+// read the caller's memory.  The engine's own buffers are still sized to n -- the other precision of M3::float_t is derived into
+// them when a reweight needs it.  Whether `d_table` really is device memory is checked once per call (a host pointer here would
+// fault inside a kernel, for everyone on the node).
+static int osc_bind_device(m3hip_handle h, const void* d_table, uint64_t n, bool is_f64, const char* who) {
+  if (!d_table || n == 0) return fail(h, M3HIP_EINVAL, std::string(who) + ": empty table");
+  HIPCHK(h, hipSetDevice(h->device));
+  const bool seen = n == h->n_osc && d_table == (is_f64 ? (const void*)h->d_osc_ext_d : (const void*)h->d_osc_ext);  // the per-step call of a fit: checked before
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  const hipError_t e = seen ? hipSuccess : hipPointerGetAttributes(&at, d_table);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(h, M3HIP_EINVAL, std::string(who) + ": not a device pointer (" + hipGetErrorString(e) + "); host tables go through m3hip_set_osc_table");
+  }
+  if (!seen && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged)
+    return fail(h, M3HIP_EINVAL, std::string(who) + ": the table is not in device memory; host tables go through m3hip_set_osc_table");
+  if (!seen && at.type == hipMemoryTypeDevice && at.device != h->device)
+    return fail(h, M3HIP_EINVAL, std::string(who) + ": the table lives on device " + std::to_string(at.device) + ", the engine on device " + std::to_string(h->device));
+  int rc = osc_table_resize(h, n);
+  if (rc) return rc;
+  h->d_osc_ext = is_f64 ? nullptr : static_cast<const float*>(d_table);
+  h->d_osc_ext_d = is_f64 ? static_cast<const double*>(d_table) : nullptr;
+  h->osc_valid_f32 = !is_f64;
+  h->osc_valid_f64 = is_f64;
+  h->oscw_valid = false;
+  h->osc_static_steps = 0;
+  if (h->evw_weight) h->evw_dirty = true;  // the packed words carry weights of the table that was just replaced
+  return M3HIP_OK;
+}
+
+int m3hip_set_osc_table_device(m3hip_handle h, const float* d_table, uint64_t n) try {
+  if (!h) return M3HIP_EINVAL;
+  return osc_bind_device(h, d_table, n, false, "set_osc_table_device");
+} M3_API_CATCH(h)
+
+int m3hip_set_osc_table_device_f64(m3hip_handle h, const double* d_table, uint64_t n) try {
+  if (!h) return M3HIP_EINVAL;
+  return osc_bind_device(h, d_table, n, true, "set_osc_table_device_f64");
 } M3_API_CATCH(h)
 
 /* ---------------------------------------------------------------- experiment weights behind the splines */

@@ -56,7 +56,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.osc = h->d_osc;
   a.nidx = h->d_nidx;
   a.params = h->d_params;
-  a.osc_table = h->d_osc_table;
+  a.osc_table = h->osc_f32();
   a.extras = h->d_extras;
   a.n_extra = uint32_t(h->n_extra);
   a.bwidx = h->d_bwidx;
@@ -66,7 +66,7 @@ ReweightArgs make_rw_args(m3hip_handle h) {
   a.bl_idx = h->d_bl_idx;
   a.bw = h->d_b_w;
   a.bw_d = h->d_b_w_d;
-  a.osc_table_d = h->d_osc_table_d;
+  a.osc_table_d = h->osc_f64();
   a.event_w_d = h->d_event_w_d;
   a.n_bw_slots = h->Kb;
   a.hist = h->d_hist;
@@ -334,7 +334,7 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     if (h->evw_ok) {
       if (!h->d_evw && (rc = dev_alloc(h, &h->d_evw, size_t(h->E_pad)))) return rc;
       launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
-                         int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, want_weight ? h->d_osc_table : nullptr, h->stream);
+                         int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, want_weight ? h->osc_f32() : nullptr, h->stream);
       h->evw_weight = want_weight;
     }
     h->evw_dirty = false;
@@ -369,17 +369,18 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       else launch_find_bins(b, h->stream);
       if (word_valid)  // (mixed tiles and bricks: the words follow the bins; rare)
         launch_pack_events(h->d_bin, h->d_osc, h->d_nidx, std::min(h->M, h->evw_norm_slots), h->E_pad,
-                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->evw_weight ? h->d_osc_table : nullptr, h->stream);
+                           int32_t(h->max_norm_idx_evw < 0 ? 0 : h->min_norm_idx), h->d_evw, h->evw_weight ? h->osc_f32() : nullptr, h->stream);
     }
   }
   const double t_c = now_s();
 
   if (h->n_osc) {  // the oscillation weights in the precision this build of the sample side multiplies in
+    // (the source may be the caller's device array, m3hip_set_osc_table_device; the converted copy is the engine's own)
     if (h->f64 && !h->osc_valid_f64) {
-      launch_osc_convert(h->d_osc_table, nullptr, h->d_osc_table_d, h->n_osc, true, h->stream);
+      launch_osc_convert(h->osc_f32(), nullptr, h->d_osc_table_d, h->n_osc, true, h->stream);
       h->osc_valid_f64 = true;
     } else if (!h->f64 && !h->osc_valid_f32) {
-      launch_osc_convert(nullptr, h->d_osc_table_d, h->d_osc_table, h->n_osc, false, h->stream);
+      launch_osc_convert(nullptr, h->osc_f64(), h->d_osc_table, h->n_osc, false, h->stream);
       h->osc_valid_f32 = true;
     }
   }
@@ -389,9 +390,11 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   // 5.5 % of the kernel).  With the packed word the weight travels in the word itself (above).
   if (osc_static_counts && !(word_valid && h->evw_weight)) {
     const bool large = sizeof(float) * h->n_osc > 64 * 1024;
-    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && osc_is_static))) {
+    // M3HIP_OSC_COLUMN = 2: a large table that MOVES is expanded into the column every step it changed (one pass of 8 B per
+    // event in front of the brick kernel, which then streams 4 B per event instead of gathering from the table)
+    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && (osc_is_static || h->oscw_mode == 2)))) {
       if (!h->d_oscw && (rc = dev_alloc(h, &h->d_oscw, size_t(h->E_pad)))) return rc;
-      launch_osc_expand(h->d_osc, h->d_osc_table, h->d_oscw, h->E_pad, h->stream);
+      launch_osc_expand(h->d_osc, h->osc_f32(), h->d_oscw, h->E_pad, h->stream);
       h->oscw_valid = true;
     }
   }

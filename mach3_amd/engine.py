@@ -421,6 +421,12 @@ class SampleHandlerFD:
         t = np.ascontiguousarray(table, np.float32)
         self.eng._chk(self.eng.lib.m3hip_set_osc_table(self.eng.h, _ptr(t, np.float32), len(t)))
 
+    def SetOscillationWeightsDevice(self, device_ptr: int, n: int, float_t=np.float32):
+        """the table where a GPU calculator left it (m3hip_set_osc_table_device): `device_ptr` is the address of n floats (or
+        doubles) in this device's memory, read in place; call again after every refill"""
+        fn = self.eng.lib.m3hip_set_osc_table_device_f64 if float_t == np.float64 else self.eng.lib.m3hip_set_osc_table_device
+        self.eng._chk(fn(self.eng.h, C.c_void_p(int(device_ptr)), int(n)))
+
     def AddData(self, data):
         d = np.ascontiguousarray(data, np.float64)
         self.eng._chk(self.eng.lib.m3hip_set_data(self.eng.h, _ptr(d, np.float64), len(d)))

@@ -32,6 +32,7 @@ class SynthSpec:
     nc_fraction: float = 0.1
     seed: int = 20260313
     test_statistic: int = capi.kPoisson
+    osc_sorted: bool = False     # MC registered in oscillation-bin order (event e points at entry e * osc_n // n_events)
 
     @property
     def n_par(self) -> int:
@@ -48,7 +49,8 @@ class SynthSpec:
     def cconfig(self) -> capi.SynthConfig:
         return capi.SynthConfig(self.seed, self.n_params, self.n_knots, int(self.mixed), self.n_norm,
                                 self.max_norm_per_event, self.n_samples, self.n_bins, self.osc_n,
-                                self.occupancy, self.bin_lo, self.bin_hi, self.nc_fraction)
+                                self.occupancy, self.bin_lo, self.bin_hi, self.nc_fraction,
+                                self.n_events if self.osc_sorted else 0)
 
 
 # BASELINE.json configs[0..4]

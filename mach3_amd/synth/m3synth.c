@@ -162,7 +162,11 @@ void m3synth_events(const m3synth_config* c, uint64_t e0, uint64_t e1, int32_t* 
     const double u1 = u01(h3(c->seed, ST_EREC, e, 0)), u2 = u01(h3(c->seed, ST_EREC, e, 1)), u3 = u01(h3(c->seed, ST_EREC, e, 2));
     erec[i] = -0.35 * log((1.0 - u1) * (1.0 - u2) * (1.0 - u3));
     const int nc = u01(h3(c->seed, ST_NC, e, 0)) < c->nc_fraction;
-    osc_idx[i] = (nc || c->osc_n <= 0) ? -1 : (int32_t)(h3(c->seed, ST_OSC, e, 0) % (uint64_t)c->osc_n);
+    if (nc || c->osc_n <= 0) osc_idx[i] = -1;
+    else if (c->osc_sorted_events) {
+      const uint64_t k = (uint64_t)(((unsigned __int128)e * (uint64_t)c->osc_n) / c->osc_sorted_events);
+      osc_idx[i] = (int32_t)(k < (uint64_t)c->osc_n ? k : (uint64_t)c->osc_n - 1);
+    } else osc_idx[i] = (int32_t)(h3(c->seed, ST_OSC, e, 0) % (uint64_t)c->osc_n);
     const int nn = (int)(norm_off[i + 1] - norm_off[i]);
     for (int k = 0; k < nn; ++k)
       norm_idx[norm_off[i] + k] = (int16_t)(c->n_params + (int)(h3(c->seed, ST_NORM, e, (uint64_t)k) % (uint64_t)c->n_norm));

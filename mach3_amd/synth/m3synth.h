@@ -33,6 +33,9 @@ typedef struct {
   double occupancy;   /* P(event has a response for a parameter) */
   double bin_lo, bin_hi;
   double nc_fraction; /* events with no oscillation pointer (weight 1) */
+  uint64_t osc_sorted_events; /* 0: every event draws its table index independently (the configurations' default);
+                               * N > 0: MC registered in oscillation-bin order -- event e of N points at entry
+                               * floor(e * osc_n / N) (same number of events per entry, ascending with the event number) */
 } m3synth_config;
 
 /* coeff_x[P*K] (-999 where unused, as SplineMonolith.cpp:105 initialises it) and

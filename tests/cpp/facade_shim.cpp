@@ -518,4 +518,14 @@ int facade_event_order(int n_events, int n_params, const int* kind, const int* i
     return -1;
   }
 }
+// SampleHandlerFD::EventOrderByOscillationBin
+int facade_osc_order(int n_events, const int* osc_idx, unsigned int* order_out) {
+  try {
+    const std::vector<uint32_t> order = SampleHandlerFD::EventOrderByOscillationBin(std::vector<int32_t>(osc_idx, osc_idx + n_events));
+    for (size_t i = 0; i < order.size(); ++i) order_out[i] = order[i];
+    return int(order.size());
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
 }

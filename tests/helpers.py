@@ -154,3 +154,35 @@ def make_binned_events(n_events, n_params, n_cells, rng, per_cell_lists=False, s
                 w_idx.append(cell * n_params + p)
         w_off.append(len(w_idx))
     return np.asarray(w_off, np.uint64), np.asarray(w_idx, np.int32)
+
+
+class DeviceArray:
+    """n elements of device memory that are NOT the engine's: what a GPU oscillation calculator owns.  Through the HIP runtime
+    libm3hip.so already brought into the process (ctypes resolves the same soname), so that no second runtime is loaded."""
+    _hip = None
+
+    def __init__(self, n, dtype=np.float32):
+        if DeviceArray._hip is None:
+            capi.load_m3hip()
+            hip = C.CDLL("libamdhip64.so.7")
+            hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            hip.hipFree.argtypes = [C.c_void_p]
+            DeviceArray._hip = hip
+        self.n, self.dtype = int(n), np.dtype(dtype)
+        p = C.c_void_p()
+        rc = self._hip.hipMalloc(C.byref(p), self.n * self.dtype.itemsize)
+        assert rc == 0 and p.value, f"hipMalloc: {rc}"
+        self.ptr = p.value
+
+    def set(self, host):
+        """synchronous refill (hipMemcpy returns once the copy has completed: ordered before any later reweight)"""
+        host = np.ascontiguousarray(host, self.dtype)
+        assert len(host) == self.n
+        rc = self._hip.hipMemcpy(self.ptr, host.ctypes.data, host.nbytes, 1)
+        assert rc == 0, f"hipMemcpy: {rc}"
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = None

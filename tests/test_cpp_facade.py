@@ -412,3 +412,27 @@ def test_binned_spline_index_event_fan_out():
                                  out_idx.ctypes.data, len(out_idx))
     assert n == len(exp_idx) and out_off.tolist() == exp_off and out_idx[:n].tolist() == exp_idx
     assert len(exp_idx) > 300 and exp_off.count(0) < n_ev
+
+
+def test_event_order_by_oscillation_bin():
+    """SampleHandlerFD::EventOrderByOscillationBin: ascending oscillation index, stable inside a bin, events without an
+    oscillation pointer (index -1) last"""
+    import ctypes as C
+    import numpy as np
+    so = os.path.join(ROOT, "build", "libm3facade_test.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    shim = C.CDLL(so)
+    shim.facade_osc_order.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    E = 4000
+    osc = rng.integers(-1, 300, E).astype(np.int32)
+    order = np.zeros(E, np.uint32)
+    assert shim.facade_osc_order(E, osc.ctypes.data, order.ctypes.data) == E
+    assert sorted(order.tolist()) == list(range(E))
+    key = osc[order].astype(np.int64)
+    key[key < 0] = 1 << 40
+    assert np.all(np.diff(key) >= 0)
+    for b in (-1, 0, 17, 299):
+        ev = order[osc[order] == b]
+        assert np.all(np.diff(ev.astype(np.int64)) > 0)

@@ -292,6 +292,36 @@ def test_bench_ranks_on_one_card_with_check(n_ranks):
         assert "configs[3]" not in line.get("extra", {})
 
 
+def test_bench_line_survives_a_stop_inside_an_extra_leg():
+    """From four ranks on bench.py runs configs[3] under `extra` AFTER the headline numbers are in hand.  A driver whose time-out
+    fires inside that leg (eight ranks building 4e7 events on a cold node) must still find the headline: rank 0 prints the line
+    (flushed, `"final": false`) before the collective legs and the complete line at the end.  Here the leg stalls and the whole
+    process group is stopped from outside as soon as the first line has arrived."""
+    import json
+    import signal
+    import socket
+    import threading
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, M3_BENCH_BACKEND="gloo", M3_BENCH_EXCHANGE="oneshot", HSA_ENABLE_IPC_MODE_LEGACY="0", M3_BENCH_TEST_STALL_LEG_S="300")
+    p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--events", "400000",
+                          "--steps", "6", "--warmup", "2", "--spinup-seconds", "0.3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                         start_new_session=True)
+    got = []
+    t = threading.Thread(target=lambda: got.append(p.stdout.readline()), daemon=True)
+    t.start()
+    t.join(400)
+    try:
+        os.killpg(p.pid, signal.SIGKILL)  # the group this test started, nothing else
+    except ProcessLookupError:
+        pass
+    p.wait(30)
+    assert got and got[0].strip(), "no line before the leg"
+    line = json.loads(got[0])
+    assert line["final"] is False and line["n_gpus"] == 4 and line["value"] > 0 and line["config"]["ranks_seen"] == 4
+    assert line["roofline"]["frac"] > 0 and "configs[2]" in line["config"]["workload"] and line["config"]["headline"] == "configs[2]"
+
+
 def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the process starts the two ranks itself as
     fresh children (it never touches the GPU), relays rank 0's line, and the line says two ranks took part -- the first

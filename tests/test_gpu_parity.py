@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from helpers import make_monolith, natural_cubic
+from helpers import DeviceArray, make_monolith, natural_cubic
 from mach3_amd import capi, synth
 from mach3_amd.engine import SMonolith, SampleHandlerFD, build_from_synth
 
@@ -553,6 +553,74 @@ def test_oscillation_weights_change_every_step(fresh_engine):
     _llh_close(llh, osamp.get_likelihood())
     osamp.close()
     omono.close()
+
+
+@pytest.mark.parametrize("cfg,n_params,osc_n,column", [("c2", 12, 4000, None), ("c3", 96, 4000, None), ("c3", 96, 40000, None), ("c3", 96, 40000, "2"), ("c5", 128, 40000, "2")])
+def test_oscillation_table_in_device_memory_is_read_in_place(monkeypatch, cfg, n_params, osc_n, column):
+    """A GPU oscillation calculator leaves its weights on the device, and the reference's events alias that array
+    (SampleHandlerFD.cpp:1108-1133); m3hip_set_osc_table_device reads it where it lies.  Uniform tiles and bricks; a small table
+    and one beyond 64 KB (the size from which a RESTING table is folded into the packed words -- a moving one never is); with
+    M3HIP_OSC_COLUMN=2 the moving table is expanded into the per-event column every step.  The caller refills ONE array in
+    place and announces it, lap after lap; then the table rests (word form), moves again through the host entry point, and
+    comes back to the device.  Every lap against the oracle: event weights bit for bit."""
+    if column is not None:
+        monkeypatch.setenv("M3HIP_OSC_COLUMN", column)
+    spec = synth.CONFIGS[cfg].scaled(9000, n_params=n_params, osc_n=osc_n)
+    eng, mono, sh, par = build_from_synth(spec)
+    omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, spec.n_events)
+    otbl = osamp.keep[7]
+    sh.Reweight()
+    osamp.reweight()
+    sh.AddData(osamp.mc)
+    osamp.add_data(osamp.mc)
+    sh.RecordEventWeights(True)
+    rng = np.random.default_rng(81)
+    d_tbl = DeviceArray(len(otbl))
+
+    def check(lap):
+        par[:] = synth.params(spec, lap)
+        opar[:] = par
+        llh = sh.Step()
+        osamp.reweight()
+        assert np.array_equal(sh.GetEventWeights(0, spec.n_events).view(np.uint32), osamp.event_weights().view(np.uint32)), lap
+        assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+        _llh_close(llh, osamp.get_likelihood())
+
+    for lap in range(1, 6):                      # the calculator refills its array in place; the engine is told
+        otbl[:] = rng.random(len(otbl)).astype(np.float32)
+        if lap == 3:
+            otbl[::5] = 0.0
+        d_tbl.set(otbl)                          # ordering: the refill has completed before the reweight is called
+        sh.SetOscillationWeightsDevice(d_tbl.ptr, len(otbl))
+        check(lap)
+    for lap in range(6, 11):                     # left alone: after a few steps the weights ride in the packed words (bricks, large table)
+        check(lap)
+    otbl[:] = rng.random(len(otbl)).astype(np.float32)
+    d_tbl.set(otbl)                              # refilled and announced again: the words go back to the index form
+    sh.SetOscillationWeightsDevice(d_tbl.ptr, len(otbl))
+    check(11)
+    otbl[:] = rng.random(len(otbl)).astype(np.float32)
+    sh.SetOscillationWeights(otbl)               # a host table takes over: the engine's own copy is current again
+    d_tbl.set(np.zeros(len(otbl), np.float32))   # ... and the caller's array is no longer read
+    check(12)
+    check(13)
+    # another array of the caller's
+    otbl[:] = rng.random(len(otbl)).astype(np.float32)
+    d2 = DeviceArray(len(otbl))
+    d2.set(otbl)
+    sh.SetOscillationWeightsDevice(d2.ptr, len(otbl))
+    check(14)
+    # a host pointer is refused, not dereferenced on the device
+    with pytest.raises(capi.M3HipError, match="device"):
+        sh.SetOscillationWeightsDevice(otbl.ctypes.data, len(otbl))
+    with pytest.raises(capi.M3HipError, match="empty"):
+        sh.SetOscillationWeightsDevice(0, len(otbl))
+    check(15)                                    # a refused call leaves the table in force
+    osamp.close()
+    omono.close()
+    eng.close()
+    d_tbl.free()
+    d2.free()
 
 
 @pytest.mark.parametrize("cfg,n_params,shape", [("c2", 24, (3, 60, 40)), ("c3", 96, (3, 60, 40)), ("c2", 24, (4, 100, 80)), ("c2", 24, (2, 50, 30))])
