@@ -10,7 +10,7 @@ bash scripts/profile_round.sh $TAG "$@" > gpurun_out/${NAME}_profile_round.log 2
 D=gpurun_out/prof_$TAG
 cp $(find $D/stats -name '*kernel_stats.csv' | head -1) gpurun_out/${NAME}_${KIND}_kernel_stats.csv
 cp gpurun_out/prof_${TAG}_bench.json gpurun_out/${NAME}_${KIND}_bench_under_rocprof.json
-M3_ROUND=5 python3 scripts/make_pmc_json.py $(dirname $(find $D/FETCH_SIZE -name '*counter_collection.csv' | head -1)) $(dirname $(find $D/WRITE_SIZE -name '*counter_collection.csv' | head -1)) \
+M3_ROUND=${M3_ROUND:-6} python3 scripts/make_pmc_json.py $(dirname $(find $D/FETCH_SIZE -name '*counter_collection.csv' | head -1)) $(dirname $(find $D/WRITE_SIZE -name '*counter_collection.csv' | head -1)) \
   gpurun_out/${NAME}_${KIND}_kernel_stats.csv gpurun_out/${NAME}_pmc_${KIND}.json "$VER" gpurun_out/${NAME}_${KIND}_bench_under_rocprof.json > /dev/null
 python3 - <<PY
 import json

@@ -311,11 +311,36 @@ def test_bench_line_survives_a_stop_inside_an_extra_leg():
     t = threading.Thread(target=lambda: got.append(p.stdout.readline()), daemon=True)
     t.start()
     t.join(400)
-    try:
-        os.killpg(p.pid, signal.SIGKILL)  # the group this test started, nothing else
-    except ProcessLookupError:
-        pass
+    # stop exactly what this test started: the launcher and its descendants (the ranks may sit in sessions of their own)
+    def descendants(root):
+        kids = {}
+        for d in os.listdir("/proc"):
+            if d.isdigit():
+                try:
+                    with open(f"/proc/{d}/stat") as f:
+                        ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+                    kids.setdefault(ppid, []).append(int(d))
+                except (OSError, ValueError, IndexError):
+                    pass
+        out, todo = [], [root]
+        while todo:
+            for k in kids.get(todo.pop(), []):
+                out.append(k)
+                todo.append(k)
+        return out
+    mine = descendants(p.pid) + [p.pid]
+    for pid in mine:
+        try:
+            os.kill(pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
     p.wait(30)
+    import time
+    for _ in range(600):  # ... and wait until they are gone, and with them their hold on the GPU, before the next test starts processes of its own
+        if not any(os.path.exists(f"/proc/{pid}") for pid in mine if pid != p.pid):
+            break
+        time.sleep(0.1)
+    time.sleep(1.0)
     assert got and got[0].strip(), "no line before the leg"
     line = json.loads(got[0])
     assert line["final"] is False and line["n_gpus"] == 4 and line["value"] > 0 and line["config"]["ranks_seen"] == 4
