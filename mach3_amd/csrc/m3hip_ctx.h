@@ -247,6 +247,12 @@ struct m3hip_ctx {
   uint32_t* d_perm = nullptr;     // processing order: lane position -> event (binned-only spaces: grouped by pointer
                                   // list; monoliths: chunks whose events were grouped by parameter list at upload)
   bool perm_dirty = false;
+  // the event side of a binned-only, shared-list sample in processing order (PosArgs; k_pack_positions), for k_reweight_lists
+  int32_t *d_pos_bin = nullptr, *d_pos_osc = nullptr;
+  uint32_t* d_pos_loff = nullptr;
+  uint16_t* d_pos_llen = nullptr;
+  bool pos_dirty = true;          // a per-event array (bin, osc, list id), the lists or the processing order changed since they were packed
+  int sw_lists = -1;              // M3HIP_LISTS_KERNEL = 0: keep such samples on the uniform-tile kernel (tests, A/B)
   std::vector<std::pair<uint64_t, std::vector<uint32_t>>> grouped;  // (first event, order) of every grouped chunk
   bool perm_monolith = false;     // some chunk was grouped
   int brick_groups = 0;           // G of this monolith's bricks (m3hip_layout.h); 0 until the first chunk with ragged events fixes it

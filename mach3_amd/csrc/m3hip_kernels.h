@@ -304,6 +304,20 @@ struct ReweightKnobs {
 
 void launch_reweight_uniform(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s, bool dyn_bins = false);
 // float_t = double epilogue (event spaces without event-by-event splines: all tiles uniform)
+// The event side of a binned-only sample in PROCESSING order (position p = the p-th event of the order the engine works in: events
+// with equal pointer lists next to each other), packed by k_pack_positions whenever one of the per-event arrays changes; read by
+// k_reweight_lists (m3hip_kernels.hip)
+struct PosArgs {
+  const uint32_t* ev;    // [n_pos] position -> event (= ReweightArgs::perm)
+  const int32_t* bin;    // bin of the event at the position
+  const int32_t* osc;    // its oscillation index (-1: none)
+  const uint32_t* loff;  // first entry of its pointer list in ReweightArgs::bl_idx
+  const uint16_t* llen;  // entries of the list (0: the event has none)
+  uint64_t n_pos;        // = events
+};
+void launch_reweight_lists(const ReweightArgs& a, const PosArgs& p, int mode, bool f64, const ReweightKnobs& k, hipStream_t s);
+void launch_pack_positions(const uint32_t* perm, const int32_t* bin, const int32_t* osc, const int32_t* bl_id, const int32_t* bl_off, uint64_t n, int32_t* p_bin,
+                           int32_t* p_osc, uint32_t* p_loff, uint16_t* p_llen, hipStream_t s);
 void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mode, const ReweightKnobs& k, hipStream_t s);
 void launch_reweight_brick(const ReweightArgs& a, uint32_t n_bricks, int mode, const ReweightKnobs& k, hipStream_t s);
 // dynamic LDS of a fill launch and whether the bin vector is privatised there (see ReweightArgs::hist_lds)

@@ -324,6 +324,47 @@ __device__ __forceinline__ WT mul_binned_weights(WT tw, const ReweightArgs& a, u
   return tw;
 }
 
+// The same product where the lanes of a wave mostly SHARE their pointer list (shared-list form; the engine processes events with
+// equal lists next to each other): the wave walks each distinct list ONCE -- lane j loads entry j's index and gathers its weight,
+// two vector loads per list instead of two per entry and lane -- and every lane that carries the list multiplies the entries in,
+// in list order, out of the loading lanes' registers (v_readlane).  Same factors in the same order as the per-lane loop: the
+// product is bit-identical.  Must be called by all 64 lanes of a wave together.  Lanes whose list has not come up after
+// kWaveLists rounds (a wave of unrelated events) walk theirs alone.
+constexpr int kWaveLists = 6;
+__device__ __forceinline__ float lane_value(float v, int j) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), j)); }
+__device__ __forceinline__ double lane_value(double v, int j) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+  return __hiloint2double(hi, lo);
+}
+template <class WT>
+__device__ __forceinline__ WT mul_binned_lists_wave(WT tw, const ReweightArgs& a, uint64_t ev) {
+  const WT* __restrict__ bw = binned_table<WT>(a);
+  const int id = a.bl_id[ev];
+  const int lane64 = (int)(threadIdx.x & 63u);
+  uint64_t todo = __ballot(id >= 0);
+  for (int round = 0; todo != 0ull && round < kWaveLists; ++round) {
+    const int lid = __builtin_amdgcn_readlane(id, (int)__ffsll((unsigned long long)todo) - 1);  // wave-uniform: the first waiting lane's list
+    const bool mine = id == lid;
+    const int off = a.bl_off[lid], end = a.bl_off[lid + 1];
+    for (int o = off; o < end; o += 64) {
+      const int n = end - o < 64 ? end - o : 64;
+      const int bi = a.bl_idx[o + (lane64 < n ? lane64 : 0)];
+      const WT wv = bw[bi];
+      for (int j = 0; j < n; ++j) {
+        const WT f = lane_value(wv, j);
+        tw = mine ? tw * f : tw;
+      }
+    }
+    todo &= ~__ballot(mine);
+  }
+  if ((todo >> lane64) & 1ull) {  // (rare) the lane's own walk
+    int off = a.bl_off[id];
+    const int end = a.bl_off[id + 1];
+    for (; off < end; ++off) tw *= bw[a.bl_idx[off]];
+  }
+  return tw;
+}
+
 // experiment weights behind the spline weight in total_weight_pointers, in the order they were appended (slot order)
 __device__ __forceinline__ float mul_extra_weights(float tw, const ReweightArgs& a, uint64_t ev) {
   for (uint32_t s = 0; s < a.n_extra; ++s) {
@@ -435,7 +476,8 @@ __global__ __launch_bounds__(256) void k_reweight_uniform(ReweightArgs a) {
     WT tw = mul_norm_weights<WT>(WT(1), a, ev);  // -1: empty ELL slot
     const int oi = a.osc[ev];
     if (oi >= 0) tw *= F64 ? (WT)a.osc_table_d[oi] : (WT)a.osc_table[oi];
-    tw = mul_binned_weights<WT>(tw, a, ev);  // bin-spline weights, in SetSplinePointers order
+    // bin-spline weights, in SetSplinePointers order (all 256 lanes are here: the shared-list form is walked wave by wave)
+    tw = a.bl_id ? mul_binned_lists_wave<WT>(tw, a, ev) : mul_binned_weights<WT>(tw, a, ev);
     tw *= (WT)w;                              // F64: no event-by-event splines in that build, w == 1
     if (!F64 && a.n_extra) tw = (WT)mul_extra_weights((float)tw, a, ev);  // AddAdditionalWeightPointers: behind the splines
     if (MODE & kModeEventW) {
@@ -534,6 +576,209 @@ void launch_reweight_uniform_f64(const ReweightArgs& a, uint32_t n_tiles, int mo
   const dim3 g(n_tiles), b(256);
   if (mode == kModeFill) M3_LAUNCH((k_reweight_uniform<kModeFill, 8, true, true>), g, b, lds, s, k, a);
   else M3_LAUNCH((k_reweight_uniform<kModeFill | kModeEval | kModeEventW, 8, true, true>), g, b, lds, s, k, a);
+}
+
+// ------------------------------------------------------------------------------------
+// k_reweight_lists: the event side of a BINNED-ONLY sample whose events share their pointer lists -- what MaCh3Tutorial's far-detector
+// sample runs: SampleHandlerFD::FillArray over events whose total_weight_pointers are {osc, bin-spline weights...}
+// (Samples/SampleHandlerFD.cpp:390-448, 568-594, 1196-1243).  No event-by-event splines, static bins.
+//
+// The uniform-tile kernel did this with zero spline slots: a 256-event workgroup per tile, whose every lane walked
+// position -> event -> {bin, osc, list id} -> list bounds -> entry -> weight, six dependent loads deep, for 16 bytes per event -- bound by
+// that chain's latency (22 us per 1e6 events with the MC in list order, 43 us in any other) and by 3 900 flushes of the bin vector.
+// Here the event side is read in PROCESSING order (PosArgs, packed by k_pack_positions when an input changes: whatever order the MC
+// was registered in, every load below is coalesced), a workgroup takes 1 024 consecutive positions (a quarter of the flushes), every
+// lane has its four events' loads in flight together, and the lists are walked by the WAVE: the distinct lists among 64 neighbouring
+// positions (one to three when the order is by list) are found from the registers, lane j fetches entry j of each, and every lane
+// that carries a list multiplies its entries in, in list order, out of the fetching lanes' registers.  Chain: position record ->
+// list entry -> weight.  Same factors in the same order as CalcWeightTotal: weights bit-identical to the oracle's.
+// ------------------------------------------------------------------------------------
+constexpr int kListsEPL = 4;     // events per lane
+constexpr int kListsRounds = 3;  // distinct lists of a wave's 64 positions fetched ahead; lanes whose list is a fourth (or later) walk theirs alone
+
+template <bool F64>
+__global__ __launch_bounds__(256) void k_reweight_lists(ReweightArgs a, PosArgs p, int mode) {
+  using WT = typename std::conditional<F64, double, float>::type;  // M3::float_t
+  extern __shared__ double lds_hist[];  // [n_bins] mc, [n_bins] w2 when the bin vector is workgroup-private; then the list staging
+  const uint32_t lane = threadIdx.x;
+  const int l64 = (int)(lane & 63u);
+  const int nb = a.fill_w2 ? 2 * a.n_bins : a.n_bins;
+  if (a.hist_lds)
+    for (int b = lane; b < nb; b += 256) lds_hist[b] = 0.0;
+  // staging of the lists' weights: one region of 64 per (wave, row, list fetched ahead) + one region of ones per wave
+  WT* const stage = reinterpret_cast<WT*>(lds_hist + (a.hist_lds ? ((nb + 1) & ~1) : 0)) + (size_t)(lane >> 6) * ((kListsEPL * kListsRounds + 1) * 64);
+  WT* const ones = stage + kListsEPL * kListsRounds * 64;
+  ones[l64] = WT(1);
+  const WT* __restrict__ bw = binned_table<WT>(a);
+  const uint64_t base = (uint64_t)blockIdx.x * (256u * kListsEPL);
+  uint32_t ev[kListsEPL], loff[kListsEPL], llen[kListsEPL];
+  int32_t bin[kListsEPL], osc[kListsEPL];
+  bool valid[kListsEPL];
+#pragma unroll
+  for (int u = 0; u < kListsEPL; ++u) {  // the position records: five coalesced loads per event, all in flight together
+    const uint64_t pos = base + (uint64_t)u * 256u + lane;
+    valid[u] = pos < p.n_pos;
+    const uint64_t pc = valid[u] ? pos : 0;
+    ev[u] = p.ev[pc];
+    bin[u] = p.bin[pc];
+    osc[u] = p.osc[pc];
+    loff[u] = p.loff[pc];
+    llen[u] = valid[u] ? (uint32_t)p.llen[pc] : 0u;
+  }
+  // the distinct lists of each wave-row, from the registers: no memory involved
+  uint32_t s_off[kListsEPL][kListsRounds], s_len[kListsEPL][kListsRounds];
+  int my_round[kListsEPL];  // which of the row's lists is this lane's (-1: none, or one beyond those fetched ahead)
+  bool alone[kListsEPL];
+#pragma unroll
+  for (int u = 0; u < kListsEPL; ++u) {
+    uint64_t todo = __ballot(llen[u] > 0u);
+    my_round[u] = -1;
+#pragma unroll
+    for (int r = 0; r < kListsRounds; ++r) {
+      s_off[u][r] = s_len[u][r] = 0u;
+      if (todo != 0ull) {  // (wave-uniform)
+        const int leader = (int)__ffsll((unsigned long long)todo) - 1;
+        s_off[u][r] = (uint32_t)__builtin_amdgcn_readlane((int)loff[u], leader);
+        s_len[u][r] = (uint32_t)__builtin_amdgcn_readlane((int)llen[u], leader);
+        const bool m = llen[u] > 0u && loff[u] == s_off[u][r];  // lists are stored once: equal first entry = the same list
+        my_round[u] = m ? r : my_round[u];
+        todo &= ~__ballot(m);
+      }
+    }
+    alone[u] = ((todo >> l64) & 1ull) != 0ull;
+  }
+  // lane j fetches entry j of every list found (the first 64 entries; longer lists continue below), then its weight
+  WT wv[kListsEPL][kListsRounds];
+  {
+    int32_t bi[kListsEPL][kListsRounds];
+#pragma unroll
+    for (int u = 0; u < kListsEPL; ++u)
+#pragma unroll
+      for (int r = 0; r < kListsRounds; ++r) {
+        const uint32_t n = s_len[u][r] < 64u ? s_len[u][r] : 64u;
+        bi[u][r] = n ? a.bl_idx[s_off[u][r] + ((uint32_t)l64 < n ? (uint32_t)l64 : 0u)] : 0;
+      }
+#pragma unroll
+    for (int u = 0; u < kListsEPL; ++u)
+#pragma unroll
+      for (int r = 0; r < kListsRounds; ++r) wv[u][r] = s_len[u][r] ? bw[bi[u][r]] : WT(1);
+  }
+  // oscillation weights (a small table in L2 / L1) while the lists travel
+  WT ow[kListsEPL];
+#pragma unroll
+  for (int u = 0; u < kListsEPL; ++u) {
+    const int oi = osc[u] >= 0 ? osc[u] : 0;
+    ow[u] = F64 ? (WT)(a.osc_table_d ? a.osc_table_d[oi] : 1.0) : (WT)(a.osc_table ? a.osc_table[oi] : 1.0f);
+  }
+  // the weights change lanes through the wave's staging regions, padded with ones to 64: a lane then reads ITS list's entries
+  // front to back whatever its neighbours carry (a factor of exactly 1 leaves a product's bits alone)
+#pragma unroll
+  for (int u = 0; u < kListsEPL; ++u)
+#pragma unroll
+    for (int r = 0; r < kListsRounds; ++r) {
+      const uint32_t n = s_len[u][r] < 64u ? s_len[u][r] : 64u;
+      if (n) stage[(u * kListsRounds + r) * 64 + l64] = (uint32_t)l64 < n ? wv[u][r] : WT(1);  // (wave-uniform branch)
+    }
+  const int rep = (int)(blockIdx.x % (uint32_t)a.hist_rep);
+  __syncthreads();  // the workgroup's bin vector is zeroed, the staging regions are written
+#pragma unroll
+  for (int u = 0; u < kListsEPL; ++u) {
+    // CalcWeightTotal (SampleHandlerFD.cpp:568-594): norm pointers first (double -> float_t cast each), then
+    // total_weight_pointers = {osc, bin-spline weights in SetSplinePointers order, [spline total weight: none here], extras}
+    WT tw = mul_norm_weights<WT>(WT(1), a, ev[u]);
+    if (osc[u] >= 0) tw *= ow[u];
+    uint32_t longest = 0;  // (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < kListsRounds; ++r) longest = s_len[u][r] > longest ? s_len[u][r] : longest;
+    const int n64 = (int)(longest < 64u ? longest : 64u);
+    const WT* mine = my_round[u] >= 0 ? stage + (u * kListsRounds + my_round[u]) * 64 : ones;
+    constexpr int kVec = 16 / (int)sizeof(WT);  // entries per 16-byte LDS read
+    for (int j = 0; j < n64; j += kVec) {
+      WT f[kVec];
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) f[i] = mine[j + i];
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) tw *= f[i];
+    }
+    if (longest > 64u) {  // (rare) lists of more than 64 entries: the rest 64 at a time, list after list
+#pragma unroll
+      for (int r = 0; r < kListsRounds; ++r) {
+        const bool m = my_round[u] == r;
+        for (uint32_t o = 64u; o < s_len[u][r]; o += 64u) {
+          const uint32_t nn = s_len[u][r] - o < 64u ? s_len[u][r] - o : 64u;
+          const WT more = bw[a.bl_idx[s_off[u][r] + o + ((uint32_t)l64 < nn ? (uint32_t)l64 : 0u)]];
+          for (int j = 0; j < (int)nn; ++j) {
+            const WT f = lane_value(more, j);
+            tw = m ? tw * f : tw;
+          }
+        }
+      }
+    }
+    if (alone[u]) {  // (rare) a wave of unrelated events: the lane's own walk
+      for (uint32_t o = loff[u]; o < loff[u] + llen[u]; ++o) tw *= bw[a.bl_idx[o]];
+    }
+    if (!F64 && a.n_extra) tw = (WT)mul_extra_weights((float)tw, a, ev[u]);  // AddAdditionalWeightPointers: behind the splines
+    if (valid[u]) {
+      if (mode & kModeEval) a.spline_w[ev[u]] = 1.0f;  // no event-by-event splines: SMonolith's total weight of every event is 1
+      if (mode & kModeEventW) {
+        if (F64) a.event_w_d[ev[u]] = (double)tw;
+        else a.event_w[ev[u]] = (float)tw;
+      }
+      // SampleHandlerFD.cpp:432 `if (totalweight <= 0.) continue;`  :443 `if (GlobalBin > -1)`; a NaN weight fills, as there
+      const int b = bin[u];
+      if (!(tw <= WT(0)) && b >= 0) {
+        if (a.hist_lds) {
+          atomicAdd(&lds_hist[b], (double)tw);
+          if (a.fill_w2) atomicAdd(&lds_hist[a.n_bins + b], (double)(tw * tw));  // square in float_t, then widened (:445)
+        } else {  // many bins: straight into this workgroup's replica
+          atomicAdd(&a.hist[(size_t)rep * a.n_bins + b], (double)tw);
+          if (a.fill_w2) atomicAdd(&a.hist[(size_t)(a.hist_rep + rep) * a.n_bins + b], (double)(tw * tw));
+        }
+      }
+    }
+  }
+  if (a.hist_lds) {
+    __syncthreads();
+    for (int i = lane; i < nb; i += 256) {
+      const double v = lds_hist[i];
+      const int slot = i < a.n_bins ? rep * a.n_bins + i : (a.hist_rep + rep) * a.n_bins + (i - a.n_bins);
+      if (v != 0.0) atomicAdd(&a.hist[slot], v);
+    }
+  }
+}
+
+void launch_reweight_lists(const ReweightArgs& a, const PosArgs& p, int mode, bool f64, const ReweightKnobs& k, hipStream_t s) {
+  if (p.n_pos == 0) return;
+  const size_t nb = a.hist_lds ? (size_t)(a.fill_w2 ? 2 : 1) * (size_t)a.n_bins : 0;
+  const size_t lds = sizeof(double) * ((nb + 1) & ~size_t(1)) + (f64 ? sizeof(double) : sizeof(float)) * 4 * (kListsEPL * kListsRounds + 1) * 64;
+  const dim3 g((unsigned)((p.n_pos + 256u * kListsEPL - 1) / (256u * kListsEPL))), b(256);
+  if (k.ev_start || k.ev_stop) {
+    if (f64) hipExtLaunchKernelGGL((k_reweight_lists<true>), g, b, (uint32_t)lds, s, k.ev_start, k.ev_stop, 0, a, p, mode);
+    else hipExtLaunchKernelGGL((k_reweight_lists<false>), g, b, (uint32_t)lds, s, k.ev_start, k.ev_stop, 0, a, p, mode);
+  } else {
+    if (f64) hipLaunchKernelGGL((k_reweight_lists<true>), g, b, lds, s, a, p, mode);
+    else hipLaunchKernelGGL((k_reweight_lists<false>), g, b, lds, s, a, p, mode);
+  }
+}
+
+// k_pack_positions: the event side in processing order (PosArgs) from the per-event arrays, which stay in the caller's order
+__global__ __launch_bounds__(256) void k_pack_positions(const uint32_t* __restrict__ perm, const int32_t* __restrict__ bin, const int32_t* __restrict__ osc,
+                                                        const int32_t* __restrict__ bl_id, const int32_t* __restrict__ bl_off, uint64_t n, int32_t* __restrict__ p_bin,
+                                                        int32_t* __restrict__ p_osc, uint32_t* __restrict__ p_loff, uint16_t* __restrict__ p_llen) {
+  const uint64_t pos = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t e = perm[pos];
+  p_bin[pos] = bin[e];
+  p_osc[pos] = osc[e];
+  const int id = bl_id[e];
+  const int o0 = id >= 0 ? bl_off[id] : 0, o1 = id >= 0 ? bl_off[id + 1] : 0;
+  p_loff[pos] = (uint32_t)o0;
+  p_llen[pos] = (uint16_t)(o1 - o0);
+}
+void launch_pack_positions(const uint32_t* perm, const int32_t* bin, const int32_t* osc, const int32_t* bl_id, const int32_t* bl_off, uint64_t n, int32_t* p_bin,
+                           int32_t* p_osc, uint32_t* p_loff, uint16_t* p_llen, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pack_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, bin, osc, bl_id, bl_off, n, p_bin, p_osc, p_loff, p_llen);
 }
 
 // ------------------------------------------------------------------------------------

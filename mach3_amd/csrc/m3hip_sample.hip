@@ -126,6 +126,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   }
   h->max_bin_idx = std::max(h->max_bin_idx, mx);  // re-checked by m3hip_reweight: the bin space may be (re)defined later
   h->evw_dirty = true;
+  h->pos_dirty = true;
   HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
   if (osc_idx) {
     h->oscw_valid = false;
@@ -390,6 +391,7 @@ int m3hip_compute_bins(m3hip_handle h) try {
   b.n_shifts = 0;
   launch_find_bins(b, h->stream);
   h->evw_dirty = true;  // d_bin is rewritten
+  h->pos_dirty = true;
   h->bins_in_word = false;
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, wait_stream(h->stream));

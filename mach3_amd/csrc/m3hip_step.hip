@@ -411,7 +411,21 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
       if (!h->d_perm && (rc = dev_alloc(h, &h->d_perm, perm.size()))) return rc;
       HIPCHK(h, wait_stream(h->stream));
       HIPCHK(h, hipMemcpy(h->d_perm, perm.data(), sizeof(uint32_t) * perm.size(), hipMemcpyHostToDevice));
+      h->pos_dirty = true;
     }
+  }
+  // A binned-only sample whose events share their pointer lists (what MaCh3Tutorial's far-detector sample is) runs k_reweight_lists
+  // on the event side in processing order; packed here whenever a per-event array, the lists or the order changed (set-up time).
+  // Functional shifts re-bin inside the uniform-tile kernel's epilogue, the deterministic fill orders its waves there: both keep it.
+  const bool use_lists = h->bl_mode == 1 && h->S + h->T == 0 && h->h_bricks.empty() && h->d_perm && h->d_bl_id && h->d_bl_off && h->h_shifts.empty() &&
+                         !h->deterministic && h->sw_lists != 0;
+  if (use_lists && h->pos_dirty) {
+    if (!h->d_pos_bin && (rc = dev_alloc(h, &h->d_pos_bin, size_t(h->E_pad)))) return rc;
+    if (!h->d_pos_osc && (rc = dev_alloc(h, &h->d_pos_osc, size_t(h->E_pad)))) return rc;
+    if (!h->d_pos_loff && (rc = dev_alloc(h, &h->d_pos_loff, size_t(h->E_pad)))) return rc;
+    if (!h->d_pos_llen && (rc = dev_alloc(h, &h->d_pos_llen, size_t(h->E_pad)))) return rc;
+    launch_pack_positions(h->d_perm, h->d_bin, h->d_osc, h->d_bl_id, h->d_bl_off, h->E, h->d_pos_bin, h->d_pos_osc, h->d_pos_loff, h->d_pos_llen, h->stream);
+    h->pos_dirty = false;
   }
   ReweightArgs a = make_rw_args(h);
   a.n_par_total = n_par;
@@ -459,7 +473,16 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     a.partial = h->d_partial;
     a.partial_row0 = n_tiles;
   }
-  if (h->f64) {
+  if (use_lists) {
+    PosArgs pa;
+    pa.ev = h->d_perm;
+    pa.bin = h->d_pos_bin;
+    pa.osc = h->d_pos_osc;
+    pa.loff = h->d_pos_loff;
+    pa.llen = h->d_pos_llen;
+    pa.n_pos = h->E;
+    launch_reweight_lists(a, pa, mode, h->f64, ku, h->stream);
+  } else if (h->f64) {
     launch_reweight_uniform_f64(a, n_tiles, mode, ku, h->stream);
   } else {
     launch_reweight_uniform(a, n_tiles, mode, ku, h->stream, dyn_bins);

@@ -69,6 +69,11 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_bl_off); h->d_bl_off = nullptr;
   dev_free(h->d_bl_idx); h->d_bl_idx = nullptr;
   dev_free(h->d_perm); h->d_perm = nullptr;
+  dev_free(h->d_pos_bin); h->d_pos_bin = nullptr;
+  dev_free(h->d_pos_osc); h->d_pos_osc = nullptr;
+  dev_free(h->d_pos_loff); h->d_pos_loff = nullptr;
+  dev_free(h->d_pos_llen); h->d_pos_llen = nullptr;
+  h->pos_dirty = true;
   h->grouped.clear();
   h->perm_monolith = false;
   h->n_grouped_chunks = 0;
@@ -170,6 +175,7 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
   { const char* f = getenv("M3HIP_PACKED_EVENTS"); h->sw_packed = f && f[0] ? f[0] : '1'; }
   { const char* f = getenv("M3HIP_REBIN"); h->sw_rebin = f && f[0] ? f[0] : 'p'; }
   { const char* f = getenv("M3HIP_OSC_COLUMN"); h->oscw_mode = f && f[0] ? atoi(f) : -1; }
+  { const char* f = getenv("M3HIP_LISTS_KERNEL"); h->sw_lists = f && f[0] ? atoi(f) : -1; }
   h->upload_expect = h->expect_events;  // the hint belongs to this upload, whether it completes or not
   h->short_bricks = ShortBrickPlan();
   { const char* f = getenv("M3HIP_NT_MASK"); h->nt_force = f && f[0] ? atoi(f) : -1; }
@@ -682,6 +688,7 @@ int m3hip_binned_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n
     if (h->h_bl_id.size() != h->E_pad) h->h_bl_id.assign(size_t(h->E_pad), -1);
     std::copy(ids.begin(), ids.end(), h->h_bl_id.begin() + event_offset);
     h->perm_dirty = true;
+    h->pos_dirty = true;
     return M3HIP_OK;
   }
   if (mx > h->Kb) {

@@ -1221,6 +1221,89 @@ def test_binned_splines_match_oracle(fresh_engine, lists, monkeypatch):
     ob_binned.close()
 
 
+@pytest.mark.parametrize("float_t,P,cells,sort,kernel", [(np.float32, 130, 40, True, "lists"), (np.float32, 130, 40, False, "lists"), (np.float64, 130, 40, True, "lists"),
+                                                        (np.float32, 12, 1500, False, "lists"), (np.float64, 12, 1500, True, "lists"), (np.float32, 130, 40, False, "tiles")])
+def test_lists_kernel_long_lists_many_lists_and_reuploads(monkeypatch, float_t, P, cells, sort, kernel):
+    """k_reweight_lists, the event kernel of a binned-only sample with shared pointer lists (what MaCh3Tutorial's far-detector sample
+    runs, SampleHandlerFD.cpp:1196-1243): lists of more than 64 entries (78 on average of 130 parameters: the wave fetches
+    them 64 at a time), waves with more distinct lists than the kernel fetches ahead (1 500 lists for 9 000 events: six events per
+    list -- most lanes walk alone), both builds of M3::float_t, events in list order and in any order, a slice of bins and of
+    oscillation indices re-uploaded after the first reweight (the processing-order copy is packed again), a slice of pointer lists
+    replaced; `tiles`: the same sample kept on the uniform-tile kernel (M3HIP_LISTS_KERNEL=0).  Event weights bit for bit."""
+    from helpers import make_binned, make_binned_events
+    from mach3_amd.engine import BinnedSplineHandler, Engine
+    if kernel == "tiles":
+        monkeypatch.setenv("M3HIP_LISTS_KERNEL", "0")
+    monkeypatch.setenv("M3HIP_BINNED_LISTS", "shared")
+    rng = np.random.default_rng(57)
+    E, n_norm = 9000, 4
+    bs = make_binned(P, cells, rng, float_t=float_t)
+    w_off, w_idx = make_binned_events(E, P, cells, rng, per_cell_lists=True, sort_by_cell=sort)
+    assert P < 64 or int(np.diff(w_off).max()) > 64
+    par = np.zeros(P + n_norm)
+    par[P:] = 1.0
+    opar = par.copy()
+    edges = np.linspace(0, 5, 41)
+    kin = rng.gamma(3.0, 0.4, E)
+    sample_id = np.zeros(E, np.int32)
+    nn = rng.integers(0, 3, E)
+    norm_off = np.concatenate([[0], np.cumsum(nn)]).astype(np.uint64)
+    norm_idx = (P + rng.integers(0, n_norm, int(norm_off[-1]))).astype(np.int16)
+    osc_idx = rng.integers(-1, 50, E).astype(np.int32)
+    osc = rng.random(50).astype(float_t)
+    bins = synth.find_global_bin_uniform_1d(edges, kin, sample_id, 40)
+
+    lib = ob.load("serial_f64" if float_t == np.float64 else "serial")
+    ob_binned = ob.OracleBinned(lib, bs)
+    ob_binned.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    def oracle_sample():
+        o = ob.OracleSample(lib, b, sample_id, kin, norm_off, norm_idx, opar, osc_idx.copy(), osc, None)
+        o.set_binned(ob_binned, w_off, w_idx)
+        o.set_test_statistic(capi.kPoisson)
+        return o
+    osamp = oracle_sample()
+
+    eng = Engine(0)
+    handler = BinnedSplineHandler(eng, E, bs)
+    handler.setSplinePointers(par)
+    sh = SampleHandlerFD(eng, 1, np.array([0, 40], np.int32), par, capi.kPoisson)
+    sh.SetupEvents(0, bins, osc_idx, norm_off, norm_idx)
+    handler.SetEventSplines(0, w_off, w_idx)
+    sh.SetOscillationWeights(osc)
+    sh.RecordEventWeights(True)
+    sh.Reweight()
+    osamp.reweight()
+    data = osamp.mc
+    sh.AddData(data)
+    osamp.add_data(data)
+    view = np.uint64 if float_t == np.float64 else np.uint32
+
+    def laps(n, osamp):
+        for _ in range(n):
+            par[:P] = rng.uniform(-3.5, 3.5, P)
+            par[P:] = 1 + 0.05 * rng.standard_normal(n_norm)
+            opar[:] = par
+            llh = sh.Step()
+            osamp.reweight()
+            assert np.array_equal(sh.GetEventWeights(0, E, float_t).view(view), osamp.event_weights().view(view))
+            assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+            _llh_close(llh, osamp.get_likelihood())
+    laps(3, osamp)
+    # a slice of the events gets other oscillation indices (the bins stay what the kinematics say): the packed copy follows
+    a0, a1 = 2048, 5000
+    osc_idx[a0:a1] = rng.integers(-1, 50, a1 - a0)
+    sh.SetupEvents(a0, bins[a0:a1], osc_idx[a0:a1], None, None)
+    osamp.close()
+    osamp = oracle_sample()                      # (the oracle takes its pointers at construction)
+    osamp.reweight()
+    osamp.add_data(data)
+    laps(2, osamp)
+    osamp.close()
+    eng.close()
+
+
 def test_binned_splines_double_build_match_oracle(fresh_engine):
     """The reference's default build, M3::float_t = double (Manager/Core.h:27-51): bin-spline tables,
     std::fma cubic on the parameter's own double value, float-cast value against double knots in the
