@@ -112,6 +112,9 @@ void launch_rebin_pack(const BinArgs& a, uint64_t* evw, hipStream_t s);
 // ... with the binning tables in LDS (uniform samples whose tables fit: rebin_tables_fit_lds); evw null: into a.bin instead
 bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform);
 void launch_rebin_lds(const BinArgs& a, uint64_t* evw, int n_samples, int n_axes, int n_edges, hipStream_t s);
+// ... one sample binned in one variable (rebin_fits_1d): everything but the edges in registers (k_rebin_1d)
+bool rebin_fits_1d(const BinSample* samples, int n_samples, const BinAxis* axes, const KinShift* shifts, int n_shifts, const KinCut* cuts, int n_cuts, int kin_stride);
+void launch_rebin_1d(const BinArgs& b, const BinSample& sm, const BinAxis& ax, const KinShift* shifts, const KinCut* cuts, uint64_t* evw, hipStream_t s);
 void launch_osc_expand(const int32_t* osc, const float* table, float* out, uint64_t n, hipStream_t s);
 void launch_unpack_bins(const uint64_t* evw, int32_t* bin, uint64_t n, uint64_t bin_mask, hipStream_t s);
 

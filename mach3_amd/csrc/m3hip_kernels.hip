@@ -13,6 +13,7 @@
 // explicit fmaf() calls the reference itself makes, so per-event float weights are
 // bit-identical to a serial CPU evaluation in the reference's operation order.
 #include "m3hip_kernels.h"
+#include <cstring>
 
 #include <hip/hip_ext.h>
 
@@ -1803,6 +1804,153 @@ __global__ __launch_bounds__(1024, 8) void k_rebin_lds(BinArgs a, uint64_t* __re
       finish(sl + U, rb);
     }
   }
+}
+// k_rebin_1d: the same pass for the shape real far-detector samples mostly have -- ONE sample binned in ONE variable (kin_stride 1), a
+// handful of functional parameters on it.  k_rebin_lds is written for any number of samples, axes, shifts and cuts: per event it reads
+// the sample's and the axis' records, every shift record and its parameter from LDS and walks run-time loops over them -- some 200
+// instructions per event, and at 1e7 events the pass took what those instructions take (40-52 us), not what its 160 MB do.  Here
+// everything that is the same for every event -- the axis, the shifts with 1 + theta formed once, the cuts -- sits in registers for the
+// whole launch, and only the edges are in LDS.  FindBin (Samples/SampleStructs.h:577-613) as before -- the event's last bin first (two
+// edges), the range test, the +-1 neighbours -- then, for an event that moved further, ONE guess from the axis' mean bin width,
+// verified against its two edges, before the binary search: every route returns the bin with e[b] <= x < e[b + 1], so the index is
+// the reference's whichever route finds it.  The kinematics are read around the Infinity Cache (once per step, nothing re-reads
+// them); the words stay in it for the brick kernel that follows.
+struct Rebin1D {
+  const double* kin;     // [E] the binning variable
+  const double* edges;   // [n_bins + 1]
+  const double* params;  // device parameter vector
+  uint64_t n_events, bin_mask;
+  int32_t n_bins, global_offset, axis_stride, n_shifts, n_cuts;
+  int32_t kind[4], param[4];  // shifts in registration order: 1 x *= 1 + theta, 2 x += theta, 3 x += theta * (nominal x)
+  double cut_lo[2], cut_hi[2];
+};
+constexpr int kRebin1DEdges = 2049;
+template <int NS>  // the number of shifts: the loop over them is unrolled, nothing of an absent one is computed
+__global__ __launch_bounds__(1024, 8) void k_rebin_1d(Rebin1D a, uint64_t* __restrict__ evw) {
+  __shared__ double s_e[kRebin1DEdges];
+  const int t = threadIdx.x;
+  for (int i = t; i <= a.n_bins; i += 1024) s_e[i] = a.edges[i];
+  double th[NS], opt[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    th[q] = a.params[a.param[q]];
+    opt[q] = 1.0 + th[q];
+  }
+  __syncthreads();
+  const int nb = a.n_bins;
+  const double e_first = s_e[0], e_last = s_e[nb];
+  const double inv_w = (double)nb / (e_last - e_first);
+  constexpr int U = 2;
+  const uint64_t n = a.n_events, slabs = (n + 1023u) / 1024u, per = (slabs + gridDim.x - 1) / gridDim.x;
+  const uint64_t s0 = (uint64_t)blockIdx.x * per, s1 = s0 + per < slabs ? s0 + per : slabs;
+  if (s0 >= s1) return;
+  const uint64_t lim = s1 * 1024u < n ? s1 * 1024u : n;
+  const uint64_t bin_mask = a.bin_mask;
+  struct Round { double x[U]; uint64_t w[U]; };
+  auto issue = [&](uint64_t sl, Round& r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t ev = (sl + (uint64_t)u) * 1024u + t;
+      const uint64_t e = ev < lim ? ev : lim - 1;
+      r.x[u] = __builtin_nontemporal_load(a.kin + e);
+      r.w[u] = evw[e];
+    }
+  };
+  auto finish = [&](uint64_t sl, const Round& r) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t ev = (sl + (uint64_t)u) * 1024u + t;
+      const double x0 = r.x[u];
+      double x = x0;
+#pragma unroll
+      for (int q = 0; q < NS; ++q)  // ApplyShifts, in registration order (the kinds are launch-uniform)
+        x = a.kind[q] == 1 ? x * opt[q] : (a.kind[q] == 2 ? x + th[q] : x + th[q] * x0);
+      bool out = false;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (c < a.n_cuts) out = out || (x < a.cut_lo[c]) || (x >= a.cut_hi[c]);
+      const int last = (int)(uint32_t)(r.w[u] & bin_mask) - 1 - a.global_offset;  // the event's bin of the step before
+      const int hint = last >= 0 && last < nb ? last : -1;
+      int b;
+      {
+        const int h0 = hint >= 0 ? hint : 0;
+        const double lower = s_e[h0], upper = s_e[h0 + 1];
+        if (hint >= 0 && x < upper && x >= lower) {
+          b = hint;
+        } else if (!(x >= e_first && x < e_last)) {
+          b = -1;
+        } else {
+          b = -2;
+          if (hint >= 0) {  // SampleStructs.h:615-646
+            const double lower_lower = hint == 0 ? e_first : s_e[hint - 1];
+            const double upper_upper = (hint + 2 < nb) ? s_e[hint + 2] : ((hint + 1 < nb) ? s_e[hint + 1] : -999999.123456);
+            if (x < lower && x >= lower_lower) b = hint - 1;
+            else if (x < upper_upper && x >= upper) b = hint + 1;
+          }
+          if (b == -2) {
+            int g = (int)((x - e_first) * inv_w);
+            g = g < 0 ? 0 : (g >= nb ? nb - 1 : g);
+            if (x >= s_e[g] && x < s_e[g + 1]) b = g;
+            else b = d_upper_bound_bin(s_e, nb + 1, x);
+          }
+        }
+      }
+      const int global = (out || b < 0) ? -1 : b * a.axis_stride + a.global_offset;
+      const uint64_t wn = (r.w[u] & ~bin_mask) | (uint64_t)(uint32_t)(global + 1);
+      // only events that changed bin are written back -- and, where at least half of a 128-byte line's sixteen words changed, the
+      // whole line (the others with the value they had): a line written whole needs no merge with what memory holds
+      const bool changed = ev < lim && wn != r.w[u];
+      const uint32_t line = (uint32_t)(__ballot(changed) >> (t & 48)) & 0xFFFFu;
+      if (changed || (ev < lim && __popc(line) >= 8)) evw[ev] = wn;
+    }
+  };
+  Round ra, rb;
+  issue(s0, ra);
+  for (uint64_t sl = s0; sl < s1; sl += 2 * U) {
+    issue(sl + U, rb);
+    finish(sl, ra);
+    issue(sl + 2 * U, ra);
+    finish(sl + U, rb);
+  }
+}
+void launch_rebin_1d(const BinArgs& b, const BinSample& sm, const BinAxis& ax, const KinShift* shifts, const KinCut* cuts, uint64_t* evw, hipStream_t s) {
+  if (b.n_events == 0) return;
+  Rebin1D a;
+  memset(&a, 0, sizeof(a));
+  a.kin = b.kin;
+  a.edges = b.edges + ax.edge_off;
+  a.params = b.params;
+  a.n_events = b.n_events;
+  a.bin_mask = b.word_bin_mask;
+  a.n_bins = ax.n_bins;
+  a.global_offset = sm.global_offset;
+  a.axis_stride = ax.stride;
+  for (int q = 0; q < b.n_shifts; ++q) {
+    if (shifts[q].dim != 0 || shifts[q].sample > 0) continue;  // (a shift on a column or a sample that is not there is skipped, as d_event_bin_x does)
+    a.kind[a.n_shifts] = shifts[q].kind & 0xFF;
+    a.param[a.n_shifts] = shifts[q].param;
+    ++a.n_shifts;
+  }
+  for (int c = 0; c < b.n_cuts; ++c) {
+    if (cuts[c].column != 0 || cuts[c].sample > 0) continue;
+    a.cut_lo[a.n_cuts] = cuts[c].lo;
+    a.cut_hi[a.n_cuts] = cuts[c].hi;
+    ++a.n_cuts;
+  }
+  const uint64_t chunks = (b.n_events + 1023) / 1024;
+  const dim3 g((unsigned)(chunks < 512 ? chunks : 512)), blk(1024);
+  if (a.n_shifts <= 1) hipLaunchKernelGGL(k_rebin_1d<1>, g, blk, 0, s, a, evw);  // (no shift on the axis: kind 0 = x + 0 * x)
+  else if (a.n_shifts == 2) hipLaunchKernelGGL(k_rebin_1d<2>, g, blk, 0, s, a, evw);
+  else if (a.n_shifts == 3) hipLaunchKernelGGL(k_rebin_1d<3>, g, blk, 0, s, a, evw);
+  else hipLaunchKernelGGL(k_rebin_1d<4>, g, blk, 0, s, a, evw);
+}
+bool rebin_fits_1d(const BinSample* samples, int n_samples, const BinAxis* axes, const KinShift* shifts, int n_shifts, const KinCut* cuts, int n_cuts, int kin_stride) {
+  if (n_samples != 1 || kin_stride != 1 || !samples[0].uniform || samples[0].n_dim != 1) return false;
+  if (axes[samples[0].axis_off].n_bins + 1 > kRebin1DEdges || axes[samples[0].axis_off].n_bins < 1) return false;
+  int ns = 0, nc = 0;
+  for (int q = 0; q < n_shifts; ++q) ns += (shifts[q].dim == 0 && shifts[q].sample <= 0) ? 1 : 0;
+  for (int c = 0; c < n_cuts; ++c) nc += (cuts[c].column == 0 && cuts[c].sample <= 0) ? 1 : 0;
+  return ns <= 4 && nc <= 2;
 }
 bool rebin_tables_fit_lds(int n_samples, int n_axes, int n_edges, int n_shifts, int n_cuts, bool nonuniform) {
   return !nonuniform && n_samples <= RebinLimits::kSamples && n_axes <= RebinLimits::kAxes && n_edges <= RebinLimits::kEdges && n_shifts <= RebinLimits::kShifts &&

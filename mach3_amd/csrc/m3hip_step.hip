@@ -359,7 +359,11 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
     b.word_bin_mask = h->evw_weight ? kEvwBinMaskWeight : kEvwBinMask;
     if (word_valid && h->h_tiles.empty()) {  // bricks only: nothing but the words needs the bins
       if (use_lds) {
-        launch_rebin_lds(b, h->d_evw, int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), h->stream);
+        if (h->sw_rebin != 'l' && rebin_fits_1d(h->bb_samples.data(), int(h->bb_samples.size()), h->bb_axes.data(), h->h_shifts.data(), int(h->h_shifts.size()),
+                                                h->h_cuts.data(), int(h->h_cuts.size()), h->kin_stride))  // (M3HIP_REBIN=lds: the general pass; tests)
+          launch_rebin_1d(b, h->bb_samples[0], h->bb_axes[size_t(h->bb_samples[0].axis_off)], h->h_shifts.data(), h->h_cuts.data(), h->d_evw, h->stream);
+        else
+          launch_rebin_lds(b, h->d_evw, int(h->bb_samples.size()), int(h->bb_axes.size()), int(h->bb_edges.size()), h->stream);
         h->bins_in_word = true;  // d_bin is stale until somebody asks for it (bins_from_word)
       } else {
         launch_rebin_pack(b, h->d_evw, h->stream);

@@ -14,7 +14,7 @@ CAND="${TA_CAND:-TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_
 HAVE=""
 for C in $CAND; do grep -qw "$C" $OUT/avail.txt && HAVE="$HAVE $C"; done
 echo "counters found:$HAVE" > $OUT/summary.txt
-BENCH="python3 $ROOT/bench.py $* --no-cpu-baseline --no-extra --steps 8 --warmup 2 --spinup-seconds 0"
+BENCH="${TA_CMD:-python3 $ROOT/bench.py $* --no-cpu-baseline --no-extra --steps 8 --warmup 2 --spinup-seconds 0}"  # TA_CMD: another driver (absolute paths), TA_KERNEL: the kernel to report
 set -- $HAVE
 P=0
 while [ $# -gt 0 ]; do
@@ -32,7 +32,7 @@ import csv, glob, collections, os
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_reweight" in r["Kernel_Name"]:
+        if "${TA_KERNEL:-k_reweight}" in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)

@@ -1645,7 +1645,8 @@ def test_deterministic_fill_needs_the_private_bin_vector(fresh_engine):
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", ["lds_pass_into_word", "lds_pass_into_word_g2", "lds_pass_into_word_g4", "global_pass_into_word", "global_pass_into_word_g4",
                                   "lds_pass_no_word", "global_pass_no_word", "lds_pass_weight_words_rule", "lds_pass_weight_words_rule_g4",
-                                  "global_pass_weight_words_forced_g4", "lds_pass_weight_words_forced"])
+                                  "global_pass_weight_words_forced_g4", "lds_pass_weight_words_forced", "general_lds_pass_into_word",
+                                  "general_lds_pass_weight_words_forced"])
 def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
     """SURVEY 8f row 4 on a brick sample of a size where the launch has rounds of workgroups (120 000 events of configs[2]'s
     shape): an energy-scale functional parameter re-bins every event every step (ApplyShifts, Samples/SampleHandlerFD.cpp:545-564;
@@ -1661,6 +1662,8 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         monkeypatch.setenv("M3HIP_PACKED_EVENTS", "0")
     if path.startswith("global"):
         monkeypatch.setenv("M3HIP_REBIN", "global")
+    if path.startswith("general"):  # round 6: one sample in one variable runs k_rebin_1d; this keeps the pass for any shape on the same sample
+        monkeypatch.setenv("M3HIP_REBIN", "lds")
     # round 5: a pre-staged oscillation table that rests is folded into the packed words (the weight's float bits instead of the
     # index, a 14-bit bin field for the passes to write into): by the engine's rule for a LARGE table (200 KB here: index words
     # for the first laps, weight words from the third reweight on, index words again when the table moves, ...), or forced
@@ -1728,6 +1731,85 @@ def test_functional_shift_on_a_ragged_sample_of_1e5_events(path, monkeypatch):
         par[NP] = opar[NP] = 0.3       # ... and the parameter no longer moves anything
         sh.Reweight()
         assert np.array_equal(sh.GetEventBins(0, E), nominal)
+    finally:
+        eng.close()
+        osamp.close()
+        omono.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shifts,edges_kind", [(1, "equal"), (3, "equal"), (4, "variable"), (2, "variable")])
+def test_rebin_1d_shift_kinds_cuts_and_variable_width_bins(n_shifts, edges_kind):
+    """k_rebin_1d, the re-binning pass of ONE sample binned in ONE variable (round 6): up to four functional parameters on the axis in
+    registration order -- a scale `x *= 1 + a`, an offset `x += b`, `x += c * x_nominal`, a second scale --, two selection cuts on the
+    shifted value, bins of equal width and of variable width (where the pass's one guess from the mean bin width misses and the
+    binary search answers), values that leave the axis on both sides and come back.  Bins integer-exact against the oracle every lap
+    (FindBin, Samples/SampleStructs.h:577-613; ApplyShifts and IsEventSelected, Samples/SampleHandlerFD.cpp:545-564, 281-294),
+    event weights bit for bit."""
+    from mach3_amd.engine import Engine
+    spec = synth.CONFIGS["c3"].scaled(70_000)
+    E, NP = spec.n_events, spec.n_par
+    rng = np.random.default_rng(91)
+    lib = ob.load("serial")
+    cx, npts = synth.knots(spec)
+    ch = synth.monolith_chunk(spec, 0, E)
+    ev = synth.events_chunk(spec, 0, E)
+    if edges_kind == "equal":
+        edges = synth.bin_edges(spec)
+    else:
+        w = rng.uniform(0.2, 3.0, spec.n_bins) ** 2
+        edges = np.concatenate([[0.0], np.cumsum(w)]) * (5.0 / w.sum())
+    kinds = [1, 2, 3, 1][:n_shifts]
+    opar = np.concatenate([synth.params(spec, 0), np.zeros(n_shifts)])
+    omono = ob.OracleMonolith(lib, spec.n_params, spec.n_knots, cx, npts, ch)
+    omono.set_spline_pointers(opar)
+    b = ob.OracleBinning(lib)
+    b.add_uniform([edges])
+    osamp = ob.OracleSample(lib, b, ev["sample_id"], ev["erec"], ev["norm_off"], ev["norm_idx"], opar, ev["osc_idx"], synth.osc_table(spec), omono)
+    osamp.set_test_statistic(spec.test_statistic, False)
+    for q, k in enumerate(kinds):
+        osamp.add_shift(-1, 0, k, opar, NP + q)
+    osamp.add_cut(-1, 0, 0.15, 4.6)
+    osamp.add_cut(0, 0, 0.0, 4.2)
+    eng = Engine(0)
+    try:
+        par = opar.copy()
+        mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, [ch], expect_events=E)
+        mono.setSplinePointers(par)
+        sh = SampleHandlerFD(eng, 1, None, par, spec.test_statistic, bin_edges=[[edges]])
+        sh.SetupKinematics(0, ev["sample_id"], ev["erec"])
+        sh.ComputeBins()
+        sh.SetupEvents(0, sh.GetEventBins(0, E), ev["osc_idx"], ev["norm_off"], ev["norm_idx"])
+        sh.SetOscillationWeights(synth.osc_table(spec))
+        for q, k in enumerate(kinds):
+            if k == 3:
+                sh.AddKinShiftAux(-1, 0, 0, NP + q)
+            else:
+                sh.AddKinShift(-1, 0, k, NP + q)
+        sh.AddKinCut(-1, 0, 0.15, 4.6)
+        sh.AddKinCut(0, 0, 0.0, 4.2)
+        assert eng.info().n_tiles_brick > 0 and eng.info().n_tiles_uniform == 0
+        sh.RecordEventWeights(True)
+        sh.Reweight()
+        osamp.reweight()
+        sh.AddData(osamp.mc)
+        osamp.add_data(osamp.mc)
+        nominal = osamp.event_bins().copy()
+        moved = 0
+        for lap in range(9):
+            par[:NP] = synth.params(spec, 1 + lap)
+            amp = [0.0, 0.01, 0.3, 0.02, 3.0, 0.002, 0.1, 0.0, 0.05][lap]  # small walks, a jump, everything off the axis, and back
+            par[NP:] = amp * rng.standard_normal(n_shifts)
+            opar[:] = par
+            llh = sh.Step()
+            osamp.reweight()
+            got, exp = sh.GetEventBins(0, E), osamp.event_bins()
+            assert np.array_equal(got, exp), (lap, par[NP:])
+            moved += int((exp != nominal).sum())
+            assert np.array_equal(sh.GetEventWeights(0, E).view(np.uint32), osamp.event_weights().view(np.uint32))
+            assert np.allclose(sh.GetMCArray(), osamp.mc, rtol=RTOL_BIN, atol=0)
+            _llh_close(llh, osamp.get_likelihood())
+        assert moved > E // 2
     finally:
         eng.close()
         osamp.close()

@@ -12,6 +12,10 @@
 //   5  the three launches of step s + 1 ENQUEUED WHILE STEP s RUNS: its prep kernel waits (one lane polls a doorbell word in mapped
 //      host memory, with a time-out) until the host has written the step's parameters -- launch latency leaves the critical path
 //   6  3 and 5 together: two launches enqueued ahead, every workgroup of the reweight kernel waits for the doorbell itself
+//   7  as 4 with the hand-off protocol of MI355X_MICROARCH.md (barrier-counter / fanin rows): every wave waits for its own flush adds
+//      (s_waitcnt vmcnt(0)), workgroup barrier, then LANE 0 ALONE issues the agent-scope release fence and ONE relaxed returning add;
+//      the workgroup whose add came last acquires once and runs the likelihood.  (4 fences from all 256 lanes of every workgroup.)
+//   8  two launches: k_prep as in 1, and the reweight kernel ends in 7's last-arriver likelihood -- the one launch it saves, alone
 // Results are checked against each other (the same sum every scheme).  Build: make tools; run: build/step_floor [steps=3000]
 #include <hip/hip_runtime.h>
 
@@ -71,7 +75,9 @@ __global__ __launch_bounds__(kLanes) void k_prep(Args a) {
   if (a.step && threadIdx.x == 0) *a.step += 1;
 }
 
-template <bool OWN_PREP, bool LAST_LLH>
+__global__ __launch_bounds__(kLanes) void k_prep_table_only(Args a) { prep_table(a, a.table, threadIdx.x, kLanes); }
+
+template <bool OWN_PREP, int LAST_LLH>
 __global__ __launch_bounds__(kLanes) void k_reweight(Args a);
 
 __device__ double bin_llh(double d, double m) { return d > 0 && m > 0 ? m - d + d * log(d / m) : m; }
@@ -104,7 +110,7 @@ __device__ void llh_block(const Args& a, unsigned long long ticket) {
 template <bool RESET>
 __global__ __launch_bounds__(kLanes) void k_llh(Args a) { llh_block<RESET>(a, a.step ? *a.step : a.ticket); }
 
-template <bool OWN_PREP, bool LAST_LLH>
+template <bool OWN_PREP, int LAST_LLH>
 __global__ __launch_bounds__(kLanes) void k_reweight(Args a) {
   __shared__ float s_table[kPar];
   __shared__ double s_hist[kBins];
@@ -134,7 +140,21 @@ __global__ __launch_bounds__(kLanes) void k_reweight(Args a) {
   const int rep = blockIdx.x % kRep;
   for (int b = threadIdx.x; b < kBins; b += kLanes)
     if (s_hist[b] != 0.0) atomicAdd(&a.hist[rep * kBins + b], s_hist[b]);
-  if (LAST_LLH) {
+  if (LAST_LLH == 2) {  // the guide's protocol
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flush adds have completed ...
+    __syncthreads();                                    // ... and so have every other wave's of this workgroup
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md, compiler hazard)
+      s_last = __hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (threadIdx.x == 0) __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      llh_block<true>(a, a.ticket);
+    }
+  } else if (LAST_LLH) {
     __threadfence();  // this workgroup's adds are visible device-wide before it announces itself
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(a.arrived, 1u) == gridDim.x - 1;
@@ -209,7 +229,7 @@ int main(int argc, char** argv) {
   hipGraphExec_t gexec;
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, ag);
-  hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, ag);
+  hipLaunchKernelGGL((k_reweight<false, 0>), dim3(kTiles), dim3(kLanes), 0, st, ag);
   hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, ag);
   CK(hipStreamEndCapture(st, &graph));
   CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
@@ -229,20 +249,20 @@ int main(int argc, char** argv) {
       x.door = d_door;
       if (scheme == 5) {
         hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, x);
-        hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        hipLaunchKernelGGL((k_reweight<false, 0>), dim3(kTiles), dim3(kLanes), 0, st, x);
         hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, x);
       } else {
-        hipLaunchKernelGGL((k_reweight<true, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        hipLaunchKernelGGL((k_reweight<true, 0>), dim3(kTiles), dim3(kLanes), 0, st, x);
         hipLaunchKernelGGL(k_llh<true>, dim3(1), dim3(kLanes), 0, st, x);
       }
     };
-    if (scheme >= 5) enqueue_armed(ticket + 1 + (1ull << 40));
+    if (scheme == 5 || scheme == 6) enqueue_armed(ticket + 1 + (1ull << 40));
     for (int s = 0; s < warm + steps; ++s) {
       if (s == warm) t0 = now_s();
       set_params((unsigned long long)s);
       Args x = a;
       unsigned long long want;
-      if (scheme >= 5) {
+      if (scheme == 5 || scheme == 6) {
         want = ++ticket + (1ull << 40);
         __atomic_store_n(h_door, want, __ATOMIC_RELEASE);  // the parameters are in place: go
         enqueue_armed(want + 1);                           // the next step's launches, behind this step's kernels
@@ -253,14 +273,21 @@ int main(int argc, char** argv) {
         want = x.ticket = ++ticket + (1ull << 40);
         if (scheme == 1) {
           hipLaunchKernelGGL(k_prep, dim3(1), dim3(kLanes), 0, st, x);
-          hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+          hipLaunchKernelGGL((k_reweight<false, 0>), dim3(kTiles), dim3(kLanes), 0, st, x);
           hipLaunchKernelGGL(k_llh<false>, dim3(1), dim3(kLanes), 0, st, x);
         } else if (scheme == 3) {
-          hipLaunchKernelGGL((k_reweight<true, false>), dim3(kTiles), dim3(kLanes), 0, st, x);
+          hipLaunchKernelGGL((k_reweight<true, 0>), dim3(kTiles), dim3(kLanes), 0, st, x);
           hipLaunchKernelGGL(k_llh<true>, dim3(1), dim3(kLanes), 0, st, x);  // (no k_prep to empty the replicas: the likelihood kernel leaves them empty)
-        } else {
+        } else if (scheme == 4) {
           x.arrived = d_arr;
-          hipLaunchKernelGGL((k_reweight<true, true>), dim3(kTiles), dim3(kLanes), 0, st, x);
+          hipLaunchKernelGGL((k_reweight<true, 1>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        } else if (scheme == 7) {
+          x.arrived = d_arr;
+          hipLaunchKernelGGL((k_reweight<true, 2>), dim3(kTiles), dim3(kLanes), 0, st, x);
+        } else {  // 8
+          x.arrived = d_arr;
+          hipLaunchKernelGGL(k_prep_table_only, dim3(1), dim3(kLanes), 0, st, x);  // (the last arriver leaves the replicas empty)
+          hipLaunchKernelGGL((k_reweight<false, 2>), dim3(kTiles), dim3(kLanes), 0, st, x);
         }
       }
       wait(want);
@@ -270,7 +297,7 @@ int main(int argc, char** argv) {
       if (!have_ref && s == 127) have_ref = true;
     }
     const double el = now_s() - t0;
-    if (scheme >= 5) {  // the step that was enqueued last never gets parameters of its own: let it run on the last ones
+    if (scheme == 5 || scheme == 6) {  // the step that was enqueued last never gets parameters of its own: let it run on the last ones
       __atomic_store_n(h_door, ++ticket + (1ull << 40), __ATOMIC_RELEASE);
       wait(ticket + (1ull << 40));
     }
@@ -282,9 +309,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, a);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_reweight<false, 0>), dim3(kTiles), dim3(kLanes), 0, st, a);
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((k_reweight<false, false>), dim3(kTiles), dim3(kLanes), 0, st, a);
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((k_reweight<false, 0>), dim3(kTiles), dim3(kLanes), 0, st, a);
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -298,6 +325,8 @@ int main(int argc, char** argv) {
     run(4, "one launch: ... and the likelihood by the last workgroup");
     run(5, "three launches enqueued a step ahead, prep waits for a doorbell");
     run(6, "two launches enqueued a step ahead, every workgroup waits");
+    run(7, "one launch, likelihood by the last workgroup, lane-0 release");
+    run(8, "two launches: prep, reweight + last-workgroup likelihood");
   }
   return 0;
 }
