@@ -188,6 +188,12 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n,
  * monolith (m3hip_upload_monolith), as in the reference.  Then: m3hip_set_spline_param_map,
  * m3hip_set_binning..., m3hip_upload_events (bins, osc, norms) and m3hip_binned_upload_events
  * (per event the CSR of indices into weightvec_Monolith, in pointer order).
+ * Device memory: the tables are kept segment-major with max_knots - 1 planes for EVERY non-flat bin-spline, i.e.
+ * 5 x sizeof(float_t) x (max_knots - 1) bytes each whatever its own knot count; an upload that would not fit the device's free
+ * memory fails with M3HIP_ENOMEM and a message that says so.
+ * Events that share their pointer list (at most one distinct list per 8 events of the first m3hip_binned_upload_events call) are
+ * run by a kernel of their own on a processing-order copy of the event side (k_reweight_lists): event weights bit-identical to
+ * the reference's loop in any MC order.
  */
 int m3hip_binned_upload(m3hip_handle h, uint64_t n_events, int n_params, int max_knots, const float* xpts,
                         const int16_t* npts, int monolith_size, const int32_t* coeffindexvec,

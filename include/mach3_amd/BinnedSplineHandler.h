@@ -107,6 +107,10 @@ class BinnedSplineIndex {
   int AddSystematic(std::vector<int> SplineModes, std::vector<int32_t> SplineID) {
     const size_t cells = size_t(GetNBins(0)) * size_t(GetNBins(1)) * size_t(GetNBins(2));
     if (SplineID.size() != SplineModes.size() * cells) throw MaCh3Exception(__FILE__, __LINE__, "BinnedSplineIndex: one spline index per (mode, bin1, bin2, bin3)");
+    // the reference's indexvec holds valid monolith indices only (BinnedSplineHandler.cpp:1100-1140): enforce it here, where the
+    // numbers come in, so that GetEventSplines can index the handler's arrays with them
+    for (const int32_t id : SplineID)
+      if (id < 0) throw MaCh3Exception(__FILE__, __LINE__, "BinnedSplineIndex: negative spline index (every (mode, bin) of a registered systematic needs its weightvec_Monolith index)");
     Modes.push_back(std::move(SplineModes));
     Index.push_back(std::move(SplineID));
     return int(Modes.size()) - 1;
@@ -128,6 +132,9 @@ class BinnedSplineIndex {
       for (size_t iMode = 0; iMode < Modes[iSyst].size(); ++iMode)
         if (Modes[iSyst][iMode] == SplineMode) {
           const int32_t id = Index[iSyst][((iMode * size_t(GetNBins(0)) + size_t(b1)) * size_t(GetNBins(1)) + size_t(b2)) * size_t(GetNBins(2)) + size_t(b3)];
+          if (isflatarray && size_t(id) >= isflatarray->size())
+            throw MaCh3Exception(__FILE__, __LINE__, "BinnedSplineIndex::GetEventSplines: spline index " + std::to_string(id) + " beyond the handler's " +
+                                                         std::to_string(isflatarray->size()) + " bin-splines");
           if (!(isflatarray && (*isflatarray)[size_t(id)])) out.push_back(id);
         }
     return out;

@@ -52,6 +52,14 @@ class ParameterHandlerBase {
     _fGlobalStepScale = 2.38 / std::sqrt(double(_fNumPar));  // the usual optimal scale for a Gaussian target
   }
   virtual ~ParameterHandlerBase() {}
+  // An attached handler owns a context on the engine (AttachDevice: dev).  A copy would share it -- detaching either one
+  // frees the slot under the other, and the engine may hand it to another handler -- so there are no copies; a move takes the
+  // attachment along and leaves the source detached.  (Samples hold RetPointer() addresses: they stay valid across a move, the
+  // vectors' buffers move with the object.)
+  ParameterHandlerBase(const ParameterHandlerBase&) = delete;
+  ParameterHandlerBase& operator=(const ParameterHandlerBase&) = delete;
+  ParameterHandlerBase(ParameterHandlerBase&& o) = default;
+  ParameterHandlerBase& operator=(ParameterHandlerBase&&) = delete;
 
   std::string GetName() const { return matrixName; }
   int GetNumParams() const { return _fNumPar; }
@@ -159,13 +167,13 @@ class ParameterHandlerBase {
       throw MaCh3Exception(__FILE__, __LINE__, "AttachDevice: " + why);
     }
     dev = h;
-    dev_slot = slot;
+    dev.slot = slot;
   }
   /// back to the host loops (call before the engine behind the handle is destroyed)
   void DetachDevice() {
-    if (dev) m3hip_par_destroy(dev, dev_slot);
+    if (dev) m3hip_par_destroy(dev, dev.slot);
     dev = nullptr;
-    dev_slot = -1;
+    dev.slot = -1;
   }
   bool OnDevice() const { return dev != nullptr; }
   /// enqueue (nothing waits): the prior of the CURRENT proposal and the correlated throw of the NEXT one
@@ -177,7 +185,7 @@ class ParameterHandlerBase {
       for (int i = 0; i < _fNumPar; ++i) randParams[size_t(i)] = IsParameterFixed(i) ? 0.0 : gaus(rng);
       throw_drawn = true;
     }
-    if (m3hip_par_launch(dev, dev_slot, d.data(), randParams.data(), _fNumPar) != M3HIP_OK)
+    if (m3hip_par_launch(dev, dev.slot, d.data(), randParams.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("LaunchDeviceStep: ") + m3hip_last_error(dev));
     launched_epoch = throw_epoch;
   }
@@ -187,7 +195,7 @@ class ParameterHandlerBase {
     double prior = 0.0;
     std::vector<double>& t = throw_scratch;
     t.resize(size_t(_fNumPar));
-    if (m3hip_par_result(dev, dev_slot, &prior, t.data(), _fNumPar) != M3HIP_OK)
+    if (m3hip_par_result(dev, dev.slot, &prior, t.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("CollectDeviceStep: ") + m3hip_last_error(dev));
     if (launched_epoch == throw_epoch && throw_drawn) {
       corr_throw.swap(t);
@@ -417,7 +425,7 @@ M3_OMP(omp for schedule(static, 4))
     throwMatrixCholDecomp = L;
     throw_ready = false;  // a throw prepared with the old matrix is recomputed (same random vector)
     ++throw_epoch;
-    if (dev && m3hip_par_upload(dev, dev_slot, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
+    if (dev && m3hip_par_upload(dev, dev.slot, 1, throwMatrixCholDecomp.data(), _fNumPar) != M3HIP_OK)
       throw MaCh3Exception(__FILE__, __LINE__, std::string("SetThrowMatrix: ") + m3hip_last_error(dev));
   }
 
@@ -472,9 +480,16 @@ M3_OMP(omp for schedule(static, 4))
   mutable std::vector<double> diff_scratch;
   std::vector<double> throw_scratch;
   bool adaption_pending = false, throw_ready = false, throw_drawn = false;
-  // device side (AttachDevice)
-  m3hip_handle dev = nullptr;
-  int dev_slot = -1;  // this handler's context on the engine (m3hip_par_create)
+  // device side (AttachDevice): the engine and this handler's context on it (m3hip_par_create); moved-from = detached
+  struct DeviceSlot {
+    m3hip_handle h = nullptr;
+    int slot = -1;
+    DeviceSlot() = default;
+    DeviceSlot(DeviceSlot&& o) noexcept : h(o.h), slot(o.slot) { o.h = nullptr; o.slot = -1; }
+    DeviceSlot& operator=(DeviceSlot&& o) noexcept { h = o.h; slot = o.slot; o.h = nullptr; o.slot = -1; return *this; }
+    DeviceSlot& operator=(m3hip_handle x) { h = x; return *this; }
+    operator m3hip_handle() const { return h; }
+  } dev;
   uint64_t throw_epoch = 0, launched_epoch = 0;  // bumped whenever a throw in flight would be stale
 #if defined(_OPENMP)
   int adaption_threads = std::max(1, std::min(8, omp_get_max_threads()));

@@ -5,7 +5,7 @@
 Rccl g_rccl;
 std::string g_create_err;
 std::mutex g_xch_mu;
-std::map<std::string, void*> g_xch_local;
+std::map<std::string, std::pair<void*, int>> g_xch_local;
 
 int fail(m3hip_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;

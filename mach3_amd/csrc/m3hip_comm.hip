@@ -82,7 +82,7 @@ int m3hip_xch_destroy(m3hip_handle h) try {
   if (h->xch_own) {
     std::lock_guard<std::mutex> lk(g_xch_mu);
     for (auto it = g_xch_local.begin(); it != g_xch_local.end();)
-      it = it->second == (void*)h->xch_own ? g_xch_local.erase(it) : std::next(it);
+      it = it->second.first == (void*)h->xch_own ? g_xch_local.erase(it) : std::next(it);
   }
   if (h->xch_own) (void)hipFree(h->xch_own);
   h->xch_own = nullptr;
@@ -138,7 +138,7 @@ int m3hip_xch_create(m3hip_handle h, int rank, int n_ranks, void* handle_out) tr
   memcpy(handle_out, &ipc, sizeof(ipc));
   {
     std::lock_guard<std::mutex> lk(g_xch_mu);
-    g_xch_local[std::string(static_cast<const char*>(handle_out), M3HIP_XCH_HANDLE_BYTES)] = h->xch_own;
+    g_xch_local[std::string(static_cast<const char*>(handle_out), M3HIP_XCH_HANDLE_BYTES)] = {h->xch_own, h->device};
   }
   return M3HIP_OK;
 } M3_API_CATCH(h)
@@ -153,10 +153,35 @@ int m3hip_xch_open(m3hip_handle h, const void* handles) try {
   for (int r = 0; r < N; ++r) {
     if (r == h->xch_rank) { h->xch_peer[r] = h->xch_own; h->xch_peer_local[r] = 1; continue; }
     const char* hb = static_cast<const char*>(handles) + size_t(r) * M3HIP_XCH_HANDLE_BYTES;
-    {  // a peer in this process: its buffer as it is (another device of this process: peer access through the runtime's default)
+    void* local = nullptr;
+    int local_dev = -1;
+    {  // a peer in this process: its buffer as it is
       std::lock_guard<std::mutex> lk(g_xch_mu);
       auto it = g_xch_local.find(std::string(hb, M3HIP_XCH_HANDLE_BYTES));
-      if (it != g_xch_local.end()) { h->xch_peer[r] = it->second; h->xch_peer_local[r] = 1; continue; }
+      if (it != g_xch_local.end()) { local = it->second.first; local_dev = it->second.second; }
+    }
+    if (local) {
+      if (local_dev != h->device) {
+        // ... on ANOTHER device of this process: this device's kernels store into it, so it must be mapped here.  The IPC route
+        // gets that from hipIpcMemLazyEnablePeerAccess; a raw pointer needs peer access enabled by hand, or the first push faults
+        int can = 0;
+        const hipError_t ec = hipDeviceCanAccessPeer(&can, h->device, local_dev);
+        if (ec != hipSuccess || !can) {
+          const std::string why = "xch_open: device " + std::to_string(h->device) + " has no peer access to device " + std::to_string(local_dev) + " (rank " + std::to_string(r) + ")";
+          m3hip_xch_destroy(h);
+          return fail(h, M3HIP_ECOMM, why);
+        }
+        const hipError_t ep = hipDeviceEnablePeerAccess(local_dev, 0);  // (current device = h->device)
+        if (ep != hipSuccess && ep != hipErrorPeerAccessAlreadyEnabled) {
+          const std::string why = std::string("xch_open: hipDeviceEnablePeerAccess: ") + hipGetErrorString(ep);
+          m3hip_xch_destroy(h);
+          return fail(h, M3HIP_ECOMM, why);
+        }
+        (void)hipGetLastError();
+      }
+      h->xch_peer[r] = local;
+      h->xch_peer_local[r] = 1;
+      continue;
     }
     hipIpcMemHandle_t ipc;
     memcpy(&ipc, hb, sizeof(ipc));

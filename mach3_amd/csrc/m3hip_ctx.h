@@ -97,7 +97,7 @@ extern std::string g_create_err;
 // process (one process driving several engines / devices) takes the peer's pointer from here -- hipIpcOpenMemHandle refuses
 // a handle of the opening process's own.
 extern std::mutex g_xch_mu;
-extern std::map<std::string, void*> g_xch_local;
+extern std::map<std::string, std::pair<void*, int>> g_xch_local;  // IPC handle -> {buffer, owning device} of the engines of THIS process
 
 // which events of an upload get bricks of three quarters of the size (described at ShortBrickPlan::begin)
 struct ShortBrickPlan {

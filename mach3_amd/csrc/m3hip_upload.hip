@@ -121,6 +121,18 @@ static int binned_planes(m3hip_handle h, int n_params, int max_knots, const int1
   if (n_unique < block) block = std::max(256, (n_unique + 255) / 256 * 256);
   const size_t n_blocks = (size_t(n_unique) + size_t(block) - 1) / size_t(block);
   const size_t plane_len = n_blocks * size_t(n_seg) * size_t(block);
+  // Every bin-spline gets max_knots - 1 segment planes, whatever its own knot count (a short one repeats its last segment): the
+  // store is 5 * sizeof(T) * (max_knots - 1) bytes per non-flat bin-spline, on the device and once more in the staging vectors
+  // below -- a handler that mixes a few many-knot parameters with many three-knot ones pays the many-knot price for all of them.
+  // Said here rather than found out by a failed allocation half-way through.
+  {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = plane_len * 5 * sizeof(T);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 10 * 9)
+      return fail(h, M3HIP_ENOMEM, "binned_upload: the segment-major tables need " + std::to_string(need >> 20) + " MiB (" + std::to_string(5 * sizeof(T) * size_t(n_seg)) +
+                                       " B per non-flat bin-spline = 5 x sizeof(float_t) x (max_knots - 1), max_knots = " + std::to_string(max_knots) + ", " +
+                                       std::to_string(n_unique) + " bin-splines), the device has " + std::to_string(free_b >> 20) + " MiB free");
+  }
   std::vector<int16_t> par(static_cast<size_t>(n_unique));
   std::vector<int32_t> target(static_cast<size_t>(n_unique));
   std::vector<T> xk(plane_len, T(0)), many(plane_len * 4, T(0));

@@ -344,7 +344,8 @@ int facade_two_handlers_one_engine(int na, int nb, unsigned long long seed, int 
       return ParameterHandlerBase(name, prefit, c, lo, up, {}, sd);
     };
     ParameterHandlerBase A = make("xsec", na, 0.5, seed + 1), B = make("detector", nb, 0.3, seed + 2);
-    ParameterHandlerBase Ah = A, Bh = B;  // host-only twins: same state, same random streams
+    // host-only twins: same state, same random streams (built again from the same seeds: a handler cannot be copied, it may own a device slot)
+    ParameterHandlerBase Ah = make("xsec", na, 0.5, seed + 1), Bh = make("detector", nb, 0.3, seed + 2);
     A.AttachDevice(h);
     B.AttachDevice(h);
     double worst = 0.0;

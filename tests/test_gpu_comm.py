@@ -7,6 +7,7 @@ ranks on one device (NCCL's "duplicate GPU" check): that test skips with RCCL's 
 driver's.  The one-shot exchange needs only IPC-mapped memory, which two processes on one card have: there the engine's
 N = 2 logic (w2 in the same message while it accumulates, the first_w2 transition, the replica fold, the parities) runs
 on a device."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -205,6 +206,46 @@ def test_eight_ranks_one_shot_exchange_matches_unsharded(update_w2):
 def test_two_ranks_in_one_process_one_shot_exchange():
     """one process driving two engines (ranks 0 and 1 of two): no IPC mapping at all, the peers' buffers as they are"""
     _two_ranks("oneshot", False, world=2, per_process=2)
+
+
+def test_two_engines_of_one_process_on_two_devices_one_shot_exchange():
+    """one process driving one engine on each of TWO devices: the peers are found by their handles and wired up without IPC, so the
+    pushing device must be given peer access to the other's buffer by hand (hipDeviceEnablePeerAccess; the IPC route gets it from
+    hipIpcMemLazyEnablePeerAccess) -- without it the first push is a memory access fault.  Skipped on a box with one device."""
+    from mach3_amd import dist as m3dist
+    n_dev = C.c_int(0)
+    capi.load_m3hip().m3hip_device_count(C.byref(n_dev))
+    if n_dev.value < 2:
+        pytest.skip("needs two devices in one process")
+    spec = synth.CONFIGS["c3"].scaled(7000, n_params=64)
+    cuts = m3dist.shard_ranges(spec.n_events, 2)
+    local = []
+    for rank in (0, 1):
+        eng, mono, sh, par = build_from_synth(spec, device_id=rank, event_range=cuts[rank])
+        local.append((eng, sh, par))
+    handles = [eng.xch_create(rank, 2) for rank, (eng, sh, par) in enumerate(local)]
+    for eng, sh, par in local:
+        eng.xch_open(handles)
+        eng.xch_set_timeout(20.0)
+    ref_eng, ref_mono, ref_sh, ref_par = build_from_synth(spec, device_id=0)
+    for lap in range(4):
+        for eng, sh, par in local:
+            par[:] = synth.params(spec, lap)
+            sh.Reweight()  # a step is a collective: both launch before either waits
+        llh = [sh.GetLikelihood() for eng, sh, par in local]
+        ref_par[:] = synth.params(spec, lap)
+        want = ref_sh.Step()
+        if lap == 0:
+            for eng, sh, par in local:
+                sh.AddData(sh.GetMCArray())
+            ref_sh.AddData(ref_sh.GetMCArray())
+            continue
+        assert llh[0] == llh[1] and llh[0] == pytest.approx(want, rel=1e-9)
+        assert np.array_equal(local[0][1].GetMCArray(), local[1][1].GetMCArray())
+        assert np.allclose(local[0][1].GetMCArray(), ref_sh.GetMCArray(), rtol=1e-12)
+    for eng, sh, par in local:
+        eng.close()
+    ref_eng.close()
 
 
 _SILENT_PEER = r"""
