@@ -64,7 +64,7 @@ clean:
 .PHONY: all oracle clean isa stamps hollow variant
 
 # C++ host driver over the facade headers (include/mach3_amd/): DragRace + a short MR2T2 chain
-examples: build/mr2t2_dragrace build/mr2t2_sharded build/two_samples_one_fitter build/facade_check build/c5_step_loop build/libm3facade_test.so build/libm3seam2_test.so
+examples: build/mr2t2_dragrace build/likelihood_fit_nm build/mr2t2_sharded build/two_samples_one_fitter build/facade_check build/c5_step_loop build/libm3facade_test.so build/libm3seam2_test.so
 
 # C shim over the header-only facade for the CPU tests (links libm3hip.so only for the symbols the headers reference)
 build/libm3facade_test.so: tests/cpp/facade_shim.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so
@@ -92,6 +92,12 @@ build/c5_step_loop: examples/c5_step_loop.cpp include/mach3_amd/*.h include/m3hi
 build/mr2t2_dragrace: examples/mr2t2_dragrace.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
 	@mkdir -p build
 	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude -o $@ examples/mr2t2_dragrace.cpp -L$(LIBDIR) -lm3hip -lm3synth \
+	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
+
+# the minimisers' caller: LikelihoodFit::CalcChi2 under a Nelder-Mead simplex, an Asimov fit that must return its truth
+build/likelihood_fit_nm: examples/likelihood_fit_nm.cpp include/mach3_amd/*.h include/m3hip.h $(LIBDIR)/libm3hip.so $(LIBDIR)/libm3synth.so
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude -o $@ examples/likelihood_fit_nm.cpp -L$(LIBDIR) -lm3hip -lm3synth \
 	    -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 # one sample over several GPUs through the facade: N processes, one per GPU, the same seeded chain on every rank

@@ -90,7 +90,9 @@ def _self_launch():
     raise SystemExit(rc)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+    pass  # (handled below, once the helpers are defined: no launcher, no torch)
+elif __name__ == "__main__":
     _self_launch()
 
 # host thread pools sized to one GPU's CPU share (the reference recommends 8, allows 16 threads:
@@ -149,30 +151,25 @@ def pmc_traffic(config_name, per_gpu):
 EVENT_EVERY = int(os.environ.get("M3_BENCH_EVENT_EVERY", "2"))  # a 20-step driver run times 10 launches
 
 
-def cpu_baseline(spec, budget_s=15.0, sample_events=300_000):
-    """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events` events of
-    the same configuration; steps/s scaled to the full event count.  The big arrays are first touched
-    inside OpenMP loops with the compute loops' static schedule (m3o_monolith_localise, HomedArray),
-    threads bound to cores, so a multi-socket host is not handicapped by single-node page placement.
-    Timed DragRace style at 8, 16 (the most the reference uses unless OMP_NUM_THREADS is exported,
-    Manager/Monitor.cpp:122-138), 32, 64 and the physical cores as far as the host has them; the best point is `value`,
-    the 16-thread point is reported beside it (`at_16_threads`).  Everything in `sample` was measured by this run."""
+def cpu_baseline_child(cfg_name, n_events_total, sample_events, threads_csv, seconds_per_point):
+    """`python bench.py --cpu-baseline-child ...`: one binding's thread sweep of the OpenMP port in a process of its own -- the binding
+    (OMP_PROC_BIND / OMP_PLACES) is fixed when the OpenMP runtime starts, so every binding needs its process; no torch, no GPU here.
+    For EVERY team size the oracle is built afresh with that team: its arrays are first touched by the threads that will stream them
+    (m3o_monolith_localise inside OpenMP loops of the compute loops' static schedule) -- a team timed on pages a wider team placed
+    reads most of them from the wrong memory node.  Prints one JSON list."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from mach3_amd import synth
-
+    base = synth.CONFIGS[cfg_name]
+    spec = base.scaled(n_events_total) if n_events_total != base.n_events else base
     n = min(sample_events, spec.n_events)
     lib = ob.load("omp")
-    cores = os.cpu_count() or 1
-    physical = max(1, cores // 2) if cores >= 32 else cores  # SMT hosts of the pool: two hardware threads per core
-    sweep_threads = sorted({t for t in (8, 16, 32, 64, min(physical, 128)) if t <= min(cores, physical)} or {cores})
-    lib.m3o_set_num_threads(max(sweep_threads))  # first touch with the widest team: pages spread over all its nodes
-    mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp", localise=True)
-    samp.reweight()
-    samp.add_data(samp.mc)
-
-    def run(threads, budget, max_laps):
+    runs = []
+    for threads in [int(t) for t in threads_csv.split(",")]:
         lib.m3o_set_num_threads(threads)
+        mono, samp, par, ch, ev = ob.build_oracle_from_synth(spec, 0, n, variant="omp", localise=True)
+        samp.reweight()
+        samp.add_data(samp.mc)
         for lap in range(1, 3):  # warm-up
             par[:] = synth.params(spec, lap)
             samp.reweight()
@@ -190,36 +187,71 @@ def cpu_baseline(spec, budget_s=15.0, sample_events=300_000):
             t_fill += b
             laps += 1
             el = time.perf_counter() - t0
-            if el > budget or laps >= max_laps:
+            if el > seconds_per_point or laps >= 4000:
                 break
-        return {"threads": int(lib.m3o_max_threads()), "laps": laps, "seconds": el, "steps_per_s": laps / el * n / spec.n_events,
-                "ms_per_lap": 1e3 * el / laps, "spline_eval_ms": 1e3 * t_spl / laps, "fill_ms": 1e3 * t_fill / laps,
-                "llh_ms": 1e3 * t_llh / laps}
+        runs.append({"threads": int(lib.m3o_max_threads()), "laps": laps, "seconds": el, "steps_per_s": laps / el * n / spec.n_events,
+                     "ms_per_lap": 1e3 * el / laps, "spline_eval_ms": 1e3 * t_spl / laps, "fill_ms": 1e3 * t_fill / laps, "llh_ms": 1e3 * t_llh / laps})
+        samp.close()
+        mono.close()
+    print(json.dumps(runs), flush=True)
 
-    runs = [run(t, budget_s / len(sweep_threads), 4000) for t in sweep_threads]
+
+def cpu_baseline(spec, budget_s=20.0, sample_events=300_000, full_lap=False):
+    """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events` events of the same configuration;
+    steps/s scaled to the full event count.  Two bindings, each a child process of its own (cpu_baseline_child): threads packed on
+    neighbouring cores (OMP_PROC_BIND=close) and spread over the sockets (spread: all memory links), OMP_PLACES=cores; within a
+    binding a sweep over team sizes -- 8, 16 (the most the reference uses unless OMP_NUM_THREADS is exported,
+    Manager/Monitor.cpp:122-138), 32, 64 and the physical cores as far as the host has them -- every team on arrays it first-touched
+    itself.  `value` is the best point of all, with its binding stated; the reference's 16-thread point is beside it.  Everything in
+    `sample` was measured by this run.  `full_lap` (--cpu-full-lap, off by default: minutes of host time and ~25 GB): one lap of ALL
+    events on this host (scripts/cpu_full_lap.py) beside the event-scaled figure."""
+    import subprocess
+    n = min(sample_events, spec.n_events)
+    cores = os.cpu_count() or 1
+    physical = max(1, cores // 2) if cores >= 32 else cores  # SMT hosts of the pool: two hardware threads per core
+    sweep = sorted({t for t in (8, 16, 32, 64, min(physical, 128)) if t <= min(cores, physical)} or {cores})
+    plans = [("close", sweep)]
+    if cores >= 32:
+        plans.append(("spread", [t for t in sweep if t >= 16]))
+    per_point = budget_s / sum(len(p[1]) for p in plans)
+    base_name = spec.name.split("@")[0]
+    runs = []
+    for bind, threads in plans:
+        env = dict(os.environ, OMP_PROC_BIND=bind, OMP_PLACES="cores", OMP_NUM_THREADS=str(max(threads)))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", base_name, str(spec.n_events), str(n),
+                            ",".join(str(t) for t in threads), f"{per_point:.2f}"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(f"cpu baseline child ({bind}): {r.stderr[-400:]}")
+        for x in json.loads(r.stdout.strip().splitlines()[-1]):
+            runs.append(dict(x, bind=bind))
     best = max(runs, key=lambda r: r["steps_per_s"])
-    at16 = next((r for r in runs if r["threads"] == 16), None)
-    samp.close()
-    mono.close()
+    at16 = max((r for r in runs if r["threads"] == 16), key=lambda r: r["steps_per_s"], default=None)
     out = {
         "value": best["steps_per_s"],
         "unit": "steps/s",
         "cores": best["threads"],
         "kind": "port",
+        "binding": f"OMP_PROC_BIND={best['bind']} OMP_PLACES=cores",
         "sample": f"first {n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
-                  f"{best['threads']} threads ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
-                  f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; arrays first-touched in "
-                  f"OpenMP loops, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}; thread sweep "
-                  f"{', '.join(str(r['threads']) for r in runs)}, {budget_s / len(sweep_threads):.1f} s each",
-        "steps_per_s_by_threads": {str(r["threads"]): r["steps_per_s"] for r in runs},
+                  f"{best['threads']} threads bound {best['bind']} ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
+                  f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; every team size on arrays "
+                  f"first-touched by that team in OpenMP loops; sweep: " + "; ".join(f"{b} {', '.join(str(t) for t in ts)}" for b, ts in plans) +
+                  f", {per_point:.1f} s per point",
+        "steps_per_s_by_threads": {f"{r['bind']}:{r['threads']}": r["steps_per_s"] for r in runs},
         "host_cores": cores,
     }
     if at16 is not None:  # the reference's own thread cap (Manager/Monitor.cpp:122-138)
-        out["at_16_threads"] = {"value": at16["steps_per_s"], "unit": "steps/s", "ms_per_lap": at16["ms_per_lap"], "laps": at16["laps"]}
-    if spec.name == "c3" and spec.n_events == 10_000_000:
+        out["at_16_threads"] = {"value": at16["steps_per_s"], "unit": "steps/s", "ms_per_lap": at16["ms_per_lap"], "laps": at16["laps"], "bind": at16["bind"]}
+    if full_lap:
+        env = dict(os.environ, OMP_PROC_BIND=best["bind"], OMP_PLACES="cores", OMP_NUM_THREADS=str(best["threads"]))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_full_lap.py"), base_name, str(best["threads"])], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=3000)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("full size") or ln.startswith("ratio")]
+        out["full_lap_this_host"] = {"threads": best["threads"], "bind": best["bind"], "output": lines or r.stdout[-400:]}
+    elif spec.name == "c3" and spec.n_events == 10_000_000:
         # NOT measured by this run: one full-size lap on record, which backs the scaling by events (another host, round 3)
         out["full_lap_on_record"] = {"file": "profiles/r03_cpu_full_c3.log", "ms": 161.6, "threads": 16, "ratio_to_event_scaled_sample": 0.970,
-                                     "host": "the box of that log (round 3), not this run's"}
+                                     "host": "the box of that log (round 3), not this run's; --cpu-full-lap measures one on this host"}
     return out
 
 
@@ -627,6 +659,7 @@ def main():
     ap.add_argument("--strict", action="store_true", help="exit with code 6 when a leg under `extra` failed or was abandoned (the line is printed either way)")
     ap.add_argument("--events", type=int, default=0, help="override the TOTAL number of events (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-lap", action="store_true", help="cpu_baseline: also time ONE lap of all events on this host (scripts/cpu_full_lap.py; minutes, ~25 GB of host memory)")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] line under `extra`")
     ap.add_argument("--chunk", type=int, default=131072)
     ap.add_argument("--table", choices=["resting", "host", "device"], default="resting",
@@ -753,7 +786,7 @@ def main():
             out["check"] = check
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(spec)
+                out["cpu_baseline"] = cpu_baseline(spec, full_lap=args.cpu_full_lap)
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if n_gpus == 1 and not args.no_extra and cfg != "c2":
@@ -856,4 +889,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        cpu_baseline_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], float(sys.argv[6]))
+    else:
+        main()

@@ -75,6 +75,11 @@ class ParameterHandlerBase {
   double GetUpperBound(const int i) const { return _fUpBound[size_t(i)]; }
   double GetParCurr(int i) const { return _fCurrVal[size_t(i)]; }
   void SetParCurrProp(const int parNo, const double parVal) { _fPropVal[size_t(parNo)] = _fCurrVal[size_t(parNo)] = parVal; }
+  /// all proposed values at once (ref: ParameterHandlerBase::SetParameters, Parameters/ParameterHandlerBase.cpp:871-890)
+  void SetParameters(const std::vector<double>& pars) {
+    if (int(pars.size()) != _fNumPar) throw MaCh3Exception(__FILE__, __LINE__, "SetParameters: " + std::to_string(pars.size()) + " values for " + std::to_string(_fNumPar) + " parameters");
+    _fPropVal = pars;
+  }
   void SetStepScale(const double scale, bool = false) { _fGlobalStepScale = scale; }
   double GetGlobalStepScale() const { return _fGlobalStepScale; }
   void SetIndivStepScale(int i, double s) { _fIndivStepScale[size_t(i)] = s; }
@@ -758,6 +763,66 @@ class MCMCBase {
   std::uniform_real_distribution<double> unif{0.0, 1.0};
   std::vector<double> StepStore, LogLStore, stepTime;
   std::vector<char> AccStore;
+};
+
+/// The minimisers' caller of the hot path (ref: Fitters/LikelihoodFit.h:6-36, Fitters/LikelihoodFit.cpp:20-123): MinuitFit and PSO
+/// hand a flat parameter vector to CalcChi2, which sets it on the systematics objects (mirrored at the bounds if asked), sums their
+/// prior terms, reweights every sample, adds the samples' likelihoods and returns 2 x the total -- the same Reweight() +
+/// GetLikelihood() pair as a chain's step, with every evaluation accepted.  The minimiser itself (Minuit2 in the reference) is the
+/// derived class's; examples/likelihood_fit_nm.cpp drives this with a Nelder-Mead simplex.
+class LikelihoodFit : public MCMCBase {
+ public:
+  explicit LikelihoodFit(uint64_t seed = 12345) : MCMCBase(seed) {}
+  void SetMirroring(const bool on) { fMirroring = on; }
+  /// ref: LikelihoodFit::PrepareFit (:20-36): the length of CalcChi2's argument
+  void PrepareFit() {
+    NPars = 0;
+    for (auto* s : systematics) NPars += s->GetNumParams();
+    syst_llh.assign(systematics.size(), 0.0);
+    sample_llh.assign(samples.size(), 0.0);
+  }
+  int GetNPars() const { return NPars; }
+  /// ref: LikelihoodFit::CalcChi2 (:39-123), statement for statement without the output tree
+  double CalcChi2(const double* x) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (syst_llh.size() != systematics.size() || sample_llh.size() != samples.size()) PrepareFit();
+    int ParCounter = 0;
+    double llh = 0.0;
+    for (auto* it : systematics) {
+      const int NumPar = it->GetNumParams();
+      std::vector<double> pars(static_cast<size_t>(NumPar));
+      for (int i = 0; i < NumPar; ++i, ++ParCounter) {
+        double ParVal = x[ParCounter];
+        if (fMirroring) {  // a value beyond a bound is reflected back inside
+          if (ParVal < it->GetLowerBound(i)) ParVal = it->GetLowerBound(i) + (it->GetLowerBound(i) - ParVal);
+          else if (ParVal > it->GetUpperBound(i)) ParVal = it->GetUpperBound(i) - (ParVal - it->GetUpperBound(i));
+        }
+        pars[size_t(i)] = ParVal;
+      }
+      it->SetParameters(pars);
+      it->AcceptStep();
+    }
+    for (size_t k = 0; k < systematics.size(); ++k) {
+      // (CalcLikelihood, not GetLikelihood: out of bounds is the minimiser's business, ref :84-86)
+      syst_llh[k] = systematics[k]->CalcLikelihood();
+      llh += syst_llh[k];
+    }
+    for (auto* s : samples) s->Reweight();
+    for (size_t i = 0; i < samples.size(); ++i) {
+      sample_llh[i] = samples[i]->GetLikelihood();
+      llh += sample_llh[i];
+    }
+    logLProp = logLCurr = llh;  // (accProb = 1: every evaluation is kept)
+    ++step;
+    ++accCount;
+    stepTime.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return 2.0 * llh;
+  }
+
+ protected:
+  void DoStep() override { throw MaCh3Exception(__FILE__, __LINE__, "LikelihoodFit is driven through CalcChi2 by its minimiser, not through RunMCMC"); }
+  int NPars = 0;
+  bool fMirroring = false;
 };
 
 /// ref: Fitters/MR2T2.cpp:11-115

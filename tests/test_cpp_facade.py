@@ -35,6 +35,19 @@ def test_cpp_driver_runs_a_chain():
 
 
 @pytest.mark.gpu
+def test_likelihood_fit_calc_chi2_under_nelder_mead_returns_the_asimov_point():
+    """examples/likelihood_fit_nm.cpp: LikelihoodFit::CalcChi2 (Fitters/LikelihoodFit.cpp:39-123: the minimisers' Reweight +
+    GetLikelihood pair) over the GPU sample, minimised by a Nelder-Mead simplex from half a sigma away: chi2 = 0 at the Asimov
+    point, mirroring at a bound, and the fit returns the point the data were made at to 1e-6 in every parameter."""
+    exe = os.path.join(ROOT, "build", "likelihood_fit_nm")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", ROOT, "examples"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "largest |fitted - true|" in r.stdout and r.stdout.strip().endswith("OK")
+
+
+@pytest.mark.gpu
 def test_cpp_facade_binned_double_build_and_box_bins():
     """examples/facade_check.cpp: BinnedSplineHandlerT<double>, a uniform + a non-uniform sample binned on the
     device, a selection cut, double oscillation weights -- all through the C++ facade, against a host
