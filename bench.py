@@ -157,6 +157,13 @@ def cpu_baseline_child(cfg_name, n_events_total, sample_events, threads_csv, sec
     For EVERY team size the oracle is built afresh with that team: its arrays are first touched by the threads that will stream them
     (m3o_monolith_localise inside OpenMP loops of the compute loops' static schedule) -- a team timed on pages a wider team placed
     reads most of them from the wrong memory node.  Prints one JSON list."""
+    # the parent's main thread may be bound to one core (its own OpenMP runtime, started under OMP_PROC_BIND, pins it), and a child
+    # inherits that mask: every team of this process would then share that core.  Back to every CPU the host allows, BEFORE an
+    # OpenMP runtime is loaded here (libgomp reads the mask when it is loaded)
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     from mach3_amd import synth
@@ -196,7 +203,7 @@ def cpu_baseline_child(cfg_name, n_events_total, sample_events, threads_csv, sec
     print(json.dumps(runs), flush=True)
 
 
-def cpu_baseline(spec, budget_s=20.0, sample_events=300_000, full_lap=False):
+def cpu_baseline(spec, budget_s=18.0, sample_events=300_000, full_lap=False, confirm_events=2_400_000):
     """Reference-layout OpenMP port (oracle/libm3oracle_omp.so) on the first `sample_events` events of the same configuration;
     steps/s scaled to the full event count.  Two bindings, each a child process of its own (cpu_baseline_child): threads packed on
     neighbouring cores (OMP_PROC_BIND=close) and spread over the sockets (spread: all memory links), OMP_PLACES=cores; within a
@@ -224,24 +231,46 @@ def cpu_baseline(spec, budget_s=20.0, sample_events=300_000, full_lap=False):
             raise RuntimeError(f"cpu baseline child ({bind}): {r.stderr[-400:]}")
         for x in json.loads(r.stdout.strip().splitlines()[-1]):
             runs.append(dict(x, bind=bind))
-    best = max(runs, key=lambda r: r["steps_per_s"])
+    sweep_best = max(runs, key=lambda r: r["steps_per_s"])
     at16 = max((r for r in runs if r["threads"] == 16), key=lambda r: r["steps_per_s"], default=None)
+    # The sweep's sample is small (configs[2]: 0.6 GB in the reference's layout) and, with the threads spread over the sockets, sits
+    # in the host's L3 slices: its steps/s scaled by events would flatter the CPU (the full sample is 18 GB and streams from DRAM).
+    # So the sweep only RANKS the (binding, team) points; the two best are then timed on a sample eight times as large, too large
+    # for any cache, and `value` is the better of those, scaled by events.
+    big_n = min(spec.n_events, max(n, confirm_events))
+    confirmed = []
+    if big_n > n:
+        ranked = sorted(runs, key=lambda r: -r["steps_per_s"])
+        cands = [ranked[0]] + [r for r in ranked[1:] if r["bind"] != ranked[0]["bind"]][:1]
+        for c in cands:
+            env = dict(os.environ, OMP_PROC_BIND=c["bind"], OMP_PLACES="cores", OMP_NUM_THREADS=str(c["threads"]))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", base_name, str(spec.n_events), str(big_n),
+                                str(c["threads"]), "2.0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            if r.returncode == 0:
+                confirmed.append(dict(json.loads(r.stdout.strip().splitlines()[-1])[0], bind=c["bind"]))
+    best = max(confirmed, key=lambda r: r["steps_per_s"]) if confirmed else sweep_best
+    best_n = big_n if confirmed else n
     out = {
         "value": best["steps_per_s"],
         "unit": "steps/s",
         "cores": best["threads"],
         "kind": "port",
         "binding": f"OMP_PROC_BIND={best['bind']} OMP_PLACES=cores",
-        "sample": f"first {n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
+        "sample": f"first {best_n} of {spec.n_events} events of the same configuration, {best['laps']} laps in {best['seconds']:.1f} s at "
                   f"{best['threads']} threads bound {best['bind']} ({best['ms_per_lap']:.2f} ms/lap: spline eval {best['spline_eval_ms']:.2f} ms, fill "
-                  f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {n}/{spec.n_events}; every team size on arrays "
-                  f"first-touched by that team in OpenMP loops; sweep: " + "; ".join(f"{b} {', '.join(str(t) for t in ts)}" for b, ts in plans) +
-                  f", {per_point:.1f} s per point",
+                  f"{best['fill_ms']:.2f} ms, LLH {best['llh_ms']:.3f} ms); steps/s scaled by {best_n}/{spec.n_events}; arrays first-touched by the "
+                  f"timed team in OpenMP loops; the (binding, team) point chosen by a sweep on the first {n} events (" +
+                  "; ".join(f"{b} {', '.join(str(t) for t in ts)}" for b, ts in plans) + f", {per_point:.1f} s per point, every team on arrays it first-touched), "
+                  f"whose own event-scaled figures are not `value`: that sample fits the host's caches",
+        "sweep_events": n,
         "steps_per_s_by_threads": {f"{r['bind']}:{r['threads']}": r["steps_per_s"] for r in runs},
+        "confirmed_on_events": best_n,
+        "confirmed": {f"{r['bind']}:{r['threads']}": r["steps_per_s"] for r in confirmed},
         "host_cores": cores,
     }
     if at16 is not None:  # the reference's own thread cap (Manager/Monitor.cpp:122-138)
-        out["at_16_threads"] = {"value": at16["steps_per_s"], "unit": "steps/s", "ms_per_lap": at16["ms_per_lap"], "laps": at16["laps"], "bind": at16["bind"]}
+        out["at_16_threads"] = {"value": at16["steps_per_s"], "unit": "steps/s", "ms_per_lap": at16["ms_per_lap"], "laps": at16["laps"], "bind": at16["bind"],
+                                "on_events": n}  # (the sweep's sample)
     if full_lap:
         env = dict(os.environ, OMP_PROC_BIND=best["bind"], OMP_PLACES="cores", OMP_NUM_THREADS=str(best["threads"]))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu_full_lap.py"), base_name, str(best["threads"])], env=env,

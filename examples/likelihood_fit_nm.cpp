@@ -3,7 +3,11 @@
 // minimises CalcChi2 over every parameter of a small synthetic sample, starting half a prior sigma away from an Asimov data set's
 // truth.  The minimum of an Asimov fit is the point the data were made at, with chi2 = 0: the fit must return it.
 //
-//   usage: likelihood_fit_nm [n_events=200000] [n_spline_params=4] [n_norm=2]
+// How close a minimiser can get is set by the likelihood's own rounding: near the minimum chi2 = sum (delta_i / sigma_i)^2 (the prior
+// dominates this sample's curvature), and a Poisson bin's mc - data + data log(data / mc) cancels to ~1e-16 x its content -- with
+// 2e4 events chi2 is known to ~1e-13, i.e. the parameters to ~5e-7 sigma; with 1e6 events (fifty times the content per bin) to 3e-6.
+//
+//   usage: likelihood_fit_nm [n_events=20000] [n_spline_params=4] [n_norm=2]
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -71,7 +75,7 @@ static int nelder_mead(const std::function<double(const double*)>& f, std::vecto
 }
 
 int main(int argc, char** argv) {
-  const uint64_t E = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 200000;
+  const uint64_t E = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 20000;
   const int P = argc > 2 ? std::atoi(argv[2]) : 4;
   const int NN = argc > 3 ? std::atoi(argv[3]) : 2;
   m3synth_config cfg{};

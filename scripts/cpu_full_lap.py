@@ -9,6 +9,10 @@ import os
 import sys
 import time
 
+try:  # a parent whose main thread is pinned (its own OpenMP runtime under OMP_PROC_BIND) hands its one-core mask down: undo it
+    os.sched_setaffinity(0, range(os.cpu_count() or 1))
+except OSError:
+    pass
 os.environ.setdefault("OMP_NUM_THREADS", "16")
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
