@@ -328,9 +328,9 @@ int facade_two_handlers_one_engine(int na, int nb, unsigned long long seed, int 
   m3hip_handle h = nullptr;
   try {
     if (m3hip_create(0, &h) != M3HIP_OK) return 100;
-    std::mt19937_64 g(seed);
-    std::normal_distribution<double> N(0.0, 1.0);
     auto make = [&](const char* name, int n, double ridge, unsigned long long sd) {
+      std::mt19937_64 g(sd ^ 0x9E3779B97F4A7C15ull);  // the handler is a function of its seed: a second call builds its twin
+      std::normal_distribution<double> N(0.0, 1.0);
       std::vector<double> a(size_t(n) * n), c(size_t(n) * n, 0.0);
       for (auto& v : a) v = N(g);
       for (int i = 0; i < n; ++i)
