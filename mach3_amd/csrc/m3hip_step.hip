@@ -394,9 +394,10 @@ int m3hip_reweight(m3hip_handle h, const double* params, int n_par) try {
   // 5.5 % of the kernel).  With the packed word the weight travels in the word itself (above).
   if (osc_static_counts && !(word_valid && h->evw_weight)) {
     const bool large = sizeof(float) * h->n_osc > 64 * 1024;
-    // M3HIP_OSC_COLUMN = 2: a large table that MOVES is expanded into the column every step it changed (one pass of 8 B per
-    // event in front of the brick kernel, which then streams 4 B per event instead of gathering from the table)
-    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && (osc_is_static || h->oscw_mode == 2)))) {
+    // (a table that MOVES is gathered from in the kernel's tail: expanding it into the column every step measured slower -- 60 us of
+    // pass + 466 us of kernel against 486 us on one GPU's share of config 5, scripts/experiments/README.md.  What makes a moving
+    // table free is the MC's order: SampleHandlerFD::EventOrderByOscillationBin)
+    if (!h->oscw_valid && ((h->oscw_mode == 1) || (large && osc_is_static))) {
       if (!h->d_oscw && (rc = dev_alloc(h, &h->d_oscw, size_t(h->E_pad)))) return rc;
       launch_osc_expand(h->d_osc, h->osc_f32(), h->d_oscw, h->E_pad, h->stream);
       h->oscw_valid = true;

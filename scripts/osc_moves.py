@@ -5,8 +5,7 @@ configuration (or a shard of it) with the table
   moving, host     m3hip_set_osc_table every step (pinned staging + asynchronous H2D copy of the table)
   moving, device   m3hip_set_osc_table_device every step (the table where a GPU calculator left it: no copy)
 usage: python scripts/osc_moves.py <config> <events> [sorted] [spl]
-  sorted: the MC registered in oscillation-bin order (SynthSpec.osc_sorted);  M3HIP_OSC_COLUMN=2: the moving table is expanded into
-  a per-event column every step.  M3HIP_LIB names another build."""
+  sorted: the MC registered in oscillation-bin order (SynthSpec.osc_sorted).  M3HIP_LIB names another build."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

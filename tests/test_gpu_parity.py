@@ -555,12 +555,12 @@ def test_oscillation_weights_change_every_step(fresh_engine):
     omono.close()
 
 
-@pytest.mark.parametrize("cfg,n_params,osc_n,column", [("c2", 12, 4000, None), ("c3", 96, 4000, None), ("c3", 96, 40000, None), ("c3", 96, 40000, "2"), ("c5", 128, 40000, "2")])
+@pytest.mark.parametrize("cfg,n_params,osc_n,column", [("c2", 12, 4000, None), ("c3", 96, 4000, None), ("c3", 96, 40000, None), ("c3", 96, 40000, "1"), ("c5", 128, 40000, None)])
 def test_oscillation_table_in_device_memory_is_read_in_place(monkeypatch, cfg, n_params, osc_n, column):
     """A GPU oscillation calculator leaves its weights on the device, and the reference's events alias that array
     (SampleHandlerFD.cpp:1108-1133); m3hip_set_osc_table_device reads it where it lies.  Uniform tiles and bricks; a small table
-    and one beyond 64 KB (the size from which a RESTING table is folded into the packed words -- a moving one never is); with
-    M3HIP_OSC_COLUMN=2 the moving table is expanded into the per-event column every step.  The caller refills ONE array in
+    and one beyond 64 KB (the size from which a RESTING table is folded into the packed words -- a moving one never is; with
+    M3HIP_OSC_COLUMN=1 every table is, at once, and unfolded again whenever it moves).  The caller refills ONE array in
     place and announces it, lap after lap; then the table rests (word form), moves again through the host entry point, and
     comes back to the device.  Every lap against the oracle: event weights bit for bit."""
     if column is not None:
