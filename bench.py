@@ -319,7 +319,7 @@ def measure(spec, rank, n_ranks, local_rank, args, dist, torch, allow_fallback, 
 
     e0, e1 = shard_of(spec, rank, n_ranks, dist if n_ranks > 1 else None)
     t_setup = time.perf_counter()
-    eng, mono, sh, par = build_from_synth(spec, device_id=local_rank, chunk_events=args.chunk, event_range=(e0, e1))
+    eng, mono, sh, par = build_from_synth(spec, device_id=local_rank, chunk_events=args.chunk, event_range=(e0, e1), order_by_osc=getattr(args, "order_key", False))
     info = eng.info()
     log(f"[bench] rank {rank}: {spec.name} events [{e0}, {e1}) of {spec.n_events}, P={spec.n_params}, S={info.n_splines}, "
         f"T={info.n_tf1}, coeff store {info.coeff_bytes / 1e9:.2f} GB, tiles {info.n_tiles_uniform}u/{info.n_tiles_brick}b, "
@@ -619,7 +619,8 @@ def workload_text(base, spec, n_ranks):
 def table_text(args, spec):
     t = getattr(args, "table", "resting")
     out = "" if t == "resting" else f"; oscillation table REPLACED EVERY STEP from {t} memory ({spec.osc_n} entries)"
-    return out + ("; MC in oscillation-bin order" if spec.osc_sorted else "")
+    out += "; MC in oscillation-bin order" if spec.osc_sorted else ""
+    return out + ("; events stored by the engine in oscillation-bin order (m3hip_monolith_order_key)" if getattr(args, "order_key", False) else "")
 
 
 def osc_moves_leg(args, local_rank, torch):
@@ -629,14 +630,19 @@ def osc_moves_leg(args, local_rank, torch):
     oscillation-bin order (M3::OscillationBinOrder), where a wave's 64 events read one or two lines of the table instead of 64."""
     from mach3_amd import synth
     res = {"what": "kernel = fused reweight kernel by dispatch-stamped events; frac = algorithmic bytes / kernel / 8 TB/s; table replaced before every step"}
-    shapes = [("configs[4] one GPU's share of 8", synth.CONFIGS["c5"].scaled(12_500_000), "c5"),
-              ("configs[4] share, MC in oscillation-bin order", synth.CONFIGS["c5"].scaled(12_500_000, osc_sorted=True), "c5"),
-              ("configs[2]", synth.CONFIGS["c3"], "c3")]
-    for name, spec, base_name in shapes:
+    shapes = [("configs[4] one GPU's share of 8", synth.CONFIGS["c5"].scaled(12_500_000), "c5", False),
+              ("configs[4] share, stored by the engine in oscillation-bin order (m3hip_monolith_order_key, upload chunks of 2^20 events)",
+               synth.CONFIGS["c5"].scaled(12_500_000), "c5", True),
+              ("configs[4] share, MC in oscillation-bin order", synth.CONFIGS["c5"].scaled(12_500_000, osc_sorted=True), "c5", False),
+              ("configs[2]", synth.CONFIGS["c3"], "c3", False)]
+    for name, spec, base_name, keyed in shapes:
         row = {"events": spec.n_events, "osc_entries": spec.osc_n}
         lines = None
         for tbl in ("resting", "device", "host"):
             a = argparse.Namespace(**vars(args))
+            a.order_key = keyed
+            if keyed:
+                a.chunk = 1 << 20  # the key orders a chunk's events: 131 072 events leave 51 table lines per 1024 events (0.696), 2^20 leave 7 (0.710)
             a.check, a.table, a.spinup_seconds, a.warmup = False, tbl, min(args.spinup_seconds, 0.5), max(args.warmup, 8)
             m = measure(spec, 0, 1, local_rank, a, None, torch, False)
             row[tbl] = {"ms_per_step": 1e3 * m["el"] / a.steps, "avg_kernel_ms": m["k_ms"], "launches_timed": m["k_n"],
@@ -694,6 +700,7 @@ def main():
     ap.add_argument("--table", choices=["resting", "host", "device"], default="resting",
                     help="the oscillation table of the HEADLINE workload: resting = pre-staged once (BASELINE's configs; the default), host / device = "
                          "replaced before every step through m3hip_set_osc_table / m3hip_set_osc_table_device (profiling the moving-table step; the workload text says so)")
+    ap.add_argument("--order-key", action="store_true", help="every upload chunk goes up with its events' oscillation indices as the order key (m3hip_monolith_order_key)")
     ap.add_argument("--osc-sorted", action="store_true", help="the MC registered in oscillation-bin order (SynthSpec.osc_sorted; the workload text says so)")
     ap.add_argument("--osc-moves", action="store_true",
                     help="N = 1: also measure the step of a fit that moves oscillation parameters -- one GPU's share of configs[4] (1.25e7 events, 204 000-entry table) and "

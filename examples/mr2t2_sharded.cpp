@@ -8,7 +8,8 @@
 // The two small blobs the ranks must hand each other (RCCL's 128-byte unique id from rank 0, or every rank's 64-byte IPC
 // handle) travel through files in a directory here; MPI_Bcast / MPI_Allgather do the same job in an MPI build.
 //
-//   usage: mr2t2_sharded <rank> <n_ranks> <dir> [exchange=oneshot|rccl|none] [n_events=200000] [n_params=64] [n_steps=300] [device=-1]
+//   usage: mr2t2_sharded <rank> <n_ranks> <dir> [exchange=oneshot|rccl|none] [n_events=200000] [n_params=64] [n_steps=300] [device=-1] [order_key=0]
+//          order_key 1: the events' oscillation bins go to the engine as its order key (SMonolithGPU::next_event_order_key)
 //          device -1: rank % visible devices (one process per GPU; ranks that share a card: the one-shot exchange only)
 //   every rank prints one line  `RESULT rank=.. events=[a,b) steps=.. accepted=.. acc=<0/1 per step> logl=<%.17g> mc0=<%.17g> ...`
 //   and writes it to <dir>/result_<rank>.txt; with n_ranks = 1 and exchange = none it is the one-process chain to compare with.
@@ -65,6 +66,7 @@ int main(int argc, char** argv) {
   const int P = argc > 6 ? std::atoi(argv[6]) : 64;
   const int NSteps = argc > 7 ? std::atoi(argv[7]) : 300;
   int device = argc > 8 ? std::atoi(argv[8]) : -1;
+  const bool order_key = argc > 9 && std::atoi(argv[9]) != 0;  // the engine stores the events in oscillation-bin order (invisible here)
   if (rank < 0 || rank >= n_ranks || (n_ranks > 1 && exchange == "none")) {
     std::fprintf(stderr, "bad rank / n_ranks / exchange\n");
     return 2;
@@ -145,6 +147,14 @@ int main(int argc, char** argv) {
     }
     ParameterHandlerBase ph("synthetic_systematics", nominal, cov, lo, hi, {}, 4242);  // the same seed on every rank
 
+    if (order_key) {  // the events' oscillation bins, handed over before the monolith they order is built
+      std::vector<int32_t> sid(n), osc(n);
+      std::vector<double> erec(n);
+      std::vector<uint64_t> noff(n + 1);
+      std::vector<int16_t> nidx(n * cfg.max_norm_per_event + 1);
+      m3synth_events(&cfg, e0, e1, sid.data(), erec.data(), osc.data(), noff.data(), nidx.data());
+      SMonolithGPU::next_event_order_key() = osc;
+    }
     auto splines = std::make_unique<SMonolith>(MasterSpline, SplineType, false, "", device);
     std::vector<const double*> ptrs(P);
     for (int p = 0; p < P; ++p) ptrs[p] = ph.RetPointer(p);
@@ -210,9 +220,11 @@ int main(int argc, char** argv) {
     std::string acc;
     for (char a : fitter.GetAcceptStore()) acc.push_back(a ? '1' : '0');
     char line[512];
-    std::snprintf(line, sizeof(line), "RESULT rank=%d ranks=%d exchange=%s events=[%llu,%llu) steps=%d accepted=%d oob=%d logl=%.17g mc0=%.17g mcsum=%.17g steps_per_s=%.0f",
+    m3hip_info info{};
+    m3hip_get_info(sample.GetSplineHandler()->Handle(), &info);
+    std::snprintf(line, sizeof(line), "RESULT rank=%d ranks=%d exchange=%s events=[%llu,%llu) steps=%d accepted=%d oob=%d logl=%.17g mc0=%.17g mcsum=%.17g steps_per_s=%.0f keyed_chunks=%llu osc_lines=%.1f",
                   rank, n_ranks, exchange.c_str(), (unsigned long long)e0, (unsigned long long)e1, fitter.GetStepCount(), fitter.GetAccCount(),
-                  fitter.GetOutOfBoundsCount(), fitter.GetLogLCurr(), mc[0], mc_sum, NSteps / el);
+                  fitter.GetOutOfBoundsCount(), fitter.GetLogLCurr(), mc[0], mc_sum, NSteps / el, (unsigned long long)info.n_keyed_chunks, info.osc_lines_per_kevent);
     const std::string out = std::string(line) + " acc=" + acc + "\n";
     std::fputs(out.c_str(), stdout);
     {

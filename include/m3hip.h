@@ -117,6 +117,16 @@ int m3hip_monolith_expect_events(m3hip_handle h, uint64_t n_events);
  */
 int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const float* coeff_x,
                          const int16_t* npts);
+/* Optional, before an m3hip_monolith_append: a key per event of THAT chunk by which the engine may order the chunk's events in its
+ * own memory (stable sort, ascending as unsigned: -1 sorts last).  Meant for the events' oscillation index: the reference's events
+ * alias the calculator's weight array (Samples/SampleHandlerFD.cpp:1108-1133) and read it in MC order; with the events of a chunk
+ * stored in table order, the 64 look-ups of a wavefront fall into a few 128-byte lines of a large table instead of 64, which is what a
+ * table that MOVES every step costs (one GPU's share of BASELINE configs[4], 485 us in MC order, 437 in table order).
+ * Invisible through this interface: every per-event array handed over later and every per-event result keeps the CALLER's event
+ * numbering (the library scatters / gathers at the boundary; set-up and diagnostics only -- a step moves no per-event data).  The
+ * bin contents are the same sums in another order.  A chunk whose layout the key's order would inflate by more than 2 % (it tears
+ * runs of equal parameter lists apart) keeps its order: m3hip_info::n_key_refused.  The key is consumed by the next append. */
+int m3hip_monolith_order_key(m3hip_handle h, const int32_t* key, uint64_t n_events);
 int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many,
                           uint64_t total_nknots, const unsigned int* nknots_arr,
                           const int16_t* param_no, uint64_t n_splines, const float* coeff_tf1,
@@ -443,7 +453,10 @@ typedef struct {
                                  * over the uploaded events (0: none uploaded).  Near 1: the MC is registered in oscillation-bin order and a
                                  * wave's look-ups share a line or two; hundreds: every event reads a line of its own -- free while the table
                                  * rests (the weights are folded into the events' words), +11 % on BASELINE configs[4]'s kernel when a fit moves
-                                 * oscillation parameters.  SampleHandlerFD::EventOrderByOscillationBin gives the order to register the MC in. */
+                                 * oscillation parameters.  m3hip_monolith_order_key lets the engine store the events in table order itself
+                                 * (the figure is then of ITS order); SampleHandlerFD::EventOrderByOscillationBin gives the order to register the MC in. */
+  uint64_t n_keyed_chunks;      /* upload chunks stored in the order of the caller's key (m3hip_monolith_order_key) */
+  uint64_t n_key_refused;       /* ... that kept their order because the key's would have cost more than 2 % of layout bytes */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);
 /* Average duration (ms) of the dominant kernel over the launches since the last reset,

@@ -27,7 +27,7 @@ M3HIP_SYMBOLS = [
     "m3hip_get_bins", "m3hip_get_spline_weights", "m3hip_record_event_weights", "m3hip_get_event_weights",
     "m3hip_get_segments",
     "m3hip_comm_get_unique_id", "m3hip_comm_init", "m3hip_comm_destroy", "m3hip_comm_available", "m3hip_device_synchronize", "m3hip_upload_event_weights", "m3hip_upload_weight_index",
-    "m3hip_set_weight_table", "m3hip_set_deterministic", "m3hip_monolith_expect_events",
+    "m3hip_set_weight_table", "m3hip_set_deterministic", "m3hip_monolith_expect_events", "m3hip_monolith_order_key",
     "m3hip_comm_set_validate", "m3hip_comm_last_validation", "m3hip_xch_create", "m3hip_xch_open", "m3hip_xch_destroy", "m3hip_xch_set_timeout", "m3hip_device_count", "m3hip_par_create", "m3hip_par_destroy", "m3hip_par_upload", "m3hip_par_launch", "m3hip_par_result",
     "m3hip_debug_layout", "m3hip_debug_short_brick_plan", "m3hip_debug_set_bins", "m3hip_debug_host_times", "m3hip_debug_set_knobs", "m3hip_debug_set_hist_replicas", "m3hip_debug_device_span",
     "m3hip_get_info", "m3hip_timing_enable", "m3hip_timing_read", "m3hip_timing_reset", "m3hip_version",
@@ -57,6 +57,7 @@ class Info(C.Structure):
         ("n_params", C.c_int), ("max_knots", C.c_int), ("n_bins", C.c_int), ("n_samples", C.c_int),
         ("n_tiles_padded", C.c_uint64), ("pad_responses", C.c_uint64), ("n_grouped_chunks", C.c_uint64), ("brick_groups", C.c_uint64),
         ("cached_stream_bytes", C.c_uint64), ("tf1_codes_around", C.c_uint64), ("osc_lines_per_kevent", C.c_double),
+        ("n_keyed_chunks", C.c_uint64), ("n_key_refused", C.c_uint64),
     ]
 
 
@@ -106,6 +107,7 @@ def load_m3hip():
         "m3hip_free_pinned": [vp, vp],
         "m3hip_monolith_begin": [vp, i32, i32, vp, vp],
         "m3hip_monolith_append": [vp, u64, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp],
+        "m3hip_monolith_order_key": [vp, vp, u64],
         "m3hip_monolith_end": [vp],
         "m3hip_upload_monolith": [vp, u64, i32, i32, vp, vp, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp],
         "m3hip_eval_splines": [vp, vp, vp, vp],

@@ -123,6 +123,7 @@ int m3hip_destroy(m3hip_handle h) try {
   m3hip_comm_destroy(h);
   m3hip_xch_destroy(h);
   free_monolith(h);
+  dev_free(h->d_xfer);
   for (int i = 0; i < kRing; ++i) {
     if (h->h_params[i]) (void)hipHostFree(h->h_params[i]);
   }
@@ -283,7 +284,25 @@ int m3hip_get_info(m3hip_handle h, m3hip_info* out) try {
   out->brick_groups = uint64_t(h->brick_groups);
   out->cached_stream_bytes = h->last_cached_bytes;
   out->tf1_codes_around = h->last_nt_codes;
+  if (h->osc_lines_stale && h->d_osc && h->E) {  // an upload the engine re-ordered (m3hip_monolith_order_key): counted in ITS order, from the device
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, wait_stream(h->stream));
+    std::vector<int32_t> osc(size_t(h->E)), ln(1024);
+    HIPCHK(h, hipMemcpy(osc.data(), h->d_osc, sizeof(int32_t) * h->E, hipMemcpyDeviceToHost));
+    h->osc_line_sum = h->osc_line_blocks = 0;
+    for (uint64_t b0 = 0; b0 + 1024 <= h->E; b0 += 1024) {
+      size_t m = 0;
+      for (uint64_t i = b0; i < b0 + 1024; ++i)
+        if (osc[i] >= 0) ln[m++] = osc[i] >> 5;
+      std::sort(ln.begin(), ln.begin() + m);
+      h->osc_line_sum += uint64_t(std::unique(ln.begin(), ln.begin() + m) - ln.begin());
+      h->osc_line_blocks += 1;
+    }
+    h->osc_lines_stale = false;
+  }
   out->osc_lines_per_kevent = h->osc_line_blocks ? double(h->osc_line_sum) / double(h->osc_line_blocks) : 0.0;
+  out->n_keyed_chunks = h->n_keyed_chunks;
+  out->n_key_refused = h->n_key_refused;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

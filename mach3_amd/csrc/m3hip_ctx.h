@@ -265,6 +265,17 @@ struct m3hip_ctx {
   int nt_force = -1;              // M3HIP_NT_MASK = 0 | 4: the TF1 codes cached / around the Infinity Cache instead of the engine's choice (experiments)
   double cached_mb = 200.0;       // what the engine plans to keep in the Infinity Cache from step to step (of its 256 MB)
   uint64_t n_grouped_chunks = 0;
+  // m3hip_monolith_order_key: chunks the engine laid out in the order of a caller-supplied key (stable sort inside the chunk).
+  // EVERYTHING on the device is in that physical order -- the kernels know nothing of it; the API translates: per-event uploads
+  // are scattered and per-event results gathered through c2p (caller's event number -> physical event).  Empty: identity.
+  std::vector<int32_t> next_key;  // key of the next m3hip_monolith_append (which takes it)
+  std::vector<std::pair<uint64_t, std::vector<uint32_t>>> keyed;  // (first event, physical position -> caller's event, chunk-local) of every keyed chunk, until monolith_end
+  std::vector<uint32_t> h_c2p;
+  uint32_t* d_c2p = nullptr;
+  uint64_t n_keyed_chunks = 0, n_key_refused = 0;
+  void* d_xfer = nullptr;         // device staging of the translated transfers
+  size_t xfer_cap = 0;
+  bool osc_lines_stale = false;   // osc_line_sum / _blocks are to be re-counted from d_osc (physical order) by m3hip_get_info
 
   // device-side binning (optional): axes, nominal kinematics, shifts
   BinSample* d_bin_samples = nullptr;
@@ -399,4 +410,9 @@ void free_monolith(m3hip_handle h);                     // m3hip_upload.hip
 void par_free(m3hip_handle h, m3hip_ctx::ParDev& p);    // m3hip_par.hip
 BinArgs make_bin_args(m3hip_handle h);                  // m3hip_sample.hip
 int bins_from_word(m3hip_handle h);                     // m3hip_sample.hip
+// Per-event transfers in the CALLER's event order (m3hip_sample.hip): elements [off, off + n) of an array over the events, rows of
+// `width` elements of `elem` bytes (2, 4 or 8).  Plain copies unless m3hip_monolith_order_key re-ordered a chunk (m3hip_ctx::h_c2p).
+int put_events(m3hip_handle h, void* dst_base, uint64_t off, const void* src, uint64_t n, size_t elem, uint32_t width = 1);
+int get_events(m3hip_handle h, void* out, const void* src_base, uint64_t off, uint64_t n, size_t elem);
+int gather_events_async(m3hip_handle h, const void* src_base, uint64_t n, size_t elem);  // all n events, caller's order -> m3hip_ctx::d_xfer, on the handle's stream (c2p non-empty)
 bool evw_fits(m3hip_handle h);                          // m3hip_sample.hip

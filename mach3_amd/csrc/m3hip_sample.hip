@@ -2,6 +2,70 @@
 // device binning with shifts and cuts, oscillation tables, experiment weights, data, test statistic.
 #include "m3hip_ctx.h"
 
+// ---- per-event transfers of an engine whose upload re-ordered events (m3hip_monolith_order_key): set-up and diagnostics only
+template <class T>
+__global__ __launch_bounds__(256) void k_scatter_rows(T* __restrict__ dst, const T* __restrict__ src, const uint32_t* __restrict__ c2p, uint64_t n, uint32_t width) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * width) return;
+  const uint64_t e = i / width, k = i - e * width;
+  dst[(uint64_t)c2p[e] * width + k] = src[i];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_events(T* __restrict__ dst, const T* __restrict__ src, const uint32_t* __restrict__ c2p, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[c2p[i]];
+}
+static int xfer_reserve(m3hip_handle h, size_t bytes) {
+  if (h->xfer_cap >= bytes) return M3HIP_OK;
+  dev_free(h->d_xfer);
+  h->d_xfer = nullptr;
+  h->xfer_cap = 0;
+  HIPCHK(h, hipMalloc(&h->d_xfer, bytes));
+  h->xfer_cap = bytes;
+  return M3HIP_OK;
+}
+int put_events(m3hip_handle h, void* dst_base, uint64_t off, const void* src, uint64_t n, size_t elem, uint32_t width) {
+  if (n == 0) return M3HIP_OK;
+  const size_t bytes = size_t(n) * width * elem;
+  if (h->h_c2p.empty()) {
+    HIPCHK(h, hipMemcpy(static_cast<char*>(dst_base) + size_t(off) * width * elem, src, bytes, hipMemcpyHostToDevice));
+    return M3HIP_OK;
+  }
+  if (int rc = xfer_reserve(h, bytes)) return rc;
+  HIPCHK(h, hipMemcpy(h->d_xfer, src, bytes, hipMemcpyHostToDevice));
+  const dim3 g((unsigned)((n * width + 255) / 256)), b(256);
+  const uint32_t* map = h->d_c2p + off;
+  if (elem == 2) hipLaunchKernelGGL(k_scatter_rows<uint16_t>, g, b, 0, h->stream, static_cast<uint16_t*>(dst_base), static_cast<const uint16_t*>(h->d_xfer), map, n, width);
+  else if (elem == 4) hipLaunchKernelGGL(k_scatter_rows<uint32_t>, g, b, 0, h->stream, static_cast<uint32_t*>(dst_base), static_cast<const uint32_t*>(h->d_xfer), map, n, width);
+  else hipLaunchKernelGGL(k_scatter_rows<uint64_t>, g, b, 0, h->stream, static_cast<uint64_t*>(dst_base), static_cast<const uint64_t*>(h->d_xfer), map, n, width);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging buffer is reused by the next transfer
+  return M3HIP_OK;
+}
+// elements [off, off + n) in the caller's order -> d_xfer, enqueued on the handle's stream
+static int gather_into_xfer(m3hip_handle h, const void* src_base, uint64_t off, uint64_t n, size_t elem) {
+  if (int rc = xfer_reserve(h, size_t(n) * elem)) return rc;
+  const dim3 g((unsigned)((n + 255) / 256)), b(256);
+  const uint32_t* map = h->d_c2p + off;
+  if (elem == 4) hipLaunchKernelGGL(k_gather_events<uint32_t>, g, b, 0, h->stream, static_cast<uint32_t*>(h->d_xfer), static_cast<const uint32_t*>(src_base), map, n);
+  else hipLaunchKernelGGL(k_gather_events<uint64_t>, g, b, 0, h->stream, static_cast<uint64_t*>(h->d_xfer), static_cast<const uint64_t*>(src_base), map, n);
+  HIPCHK(h, hipGetLastError());
+  return M3HIP_OK;
+}
+int gather_events_async(m3hip_handle h, const void* src_base, uint64_t n, size_t elem) { return gather_into_xfer(h, src_base, 0, n, elem); }
+int get_events(m3hip_handle h, void* out, const void* src_base, uint64_t off, uint64_t n, size_t elem) {
+  if (n == 0) return M3HIP_OK;
+  const size_t bytes = size_t(n) * elem;
+  if (h->h_c2p.empty()) {
+    HIPCHK(h, hipMemcpy(out, static_cast<const char*>(src_base) + size_t(off) * elem, bytes, hipMemcpyDeviceToHost));
+    return M3HIP_OK;
+  }
+  if (int rc = gather_into_xfer(h, src_base, off, n, elem)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_xfer, bytes, hipMemcpyDeviceToHost));
+  return M3HIP_OK;
+}
+
 BinArgs make_bin_args(m3hip_handle h) {
   BinArgs b;
   memset(&b, 0, sizeof(b));
@@ -127,7 +191,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
   h->max_bin_idx = std::max(h->max_bin_idx, mx);  // re-checked by m3hip_reweight: the bin space may be (re)defined later
   h->evw_dirty = true;
   h->pos_dirty = true;
-  HIPCHK(h, hipMemcpy(h->d_bin + event_offset, bin_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (int rc_p = put_events(h, h->d_bin, event_offset, bin_idx, n, sizeof(int32_t))) return rc_p;
   if (osc_idx) {
     h->oscw_valid = false;
     h->osc_static_steps = 0;
@@ -136,12 +200,13 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
       if (osc_idx[i] < -1) return fail(h, M3HIP_EINVAL, "upload_events: oscillation index below -1");
       h->max_osc_idx = std::max<int64_t>(h->max_osc_idx, osc_idx[i]);
     }
-    HIPCHK(h, hipMemcpy(h->d_osc + event_offset, osc_idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (int rc_p = put_events(h, h->d_osc, event_offset, osc_idx, n, sizeof(int32_t))) return rc_p;
     // How local are the look-ups?  Distinct 128-byte lines of a float table per 1024 consecutive events (the events a brick's
     // slab holds: its waves gather from these lines).  m3hip_info::osc_lines_per_kevent; SampleHandlerFD::EventOrderByOscillationBin.
     if (event_offset == 0) h->osc_line_sum = h->osc_line_blocks = 0;
+    h->osc_lines_stale = !h->h_c2p.empty();  // (the engine's own event order: counted from d_osc when m3hip_get_info asks)
     std::vector<int32_t> ln(1024);
-    for (uint64_t b0 = 0; b0 + 1024 <= n; b0 += 1024) {
+    for (uint64_t b0 = 0; !h->osc_lines_stale && b0 + 1024 <= n; b0 += 1024) {
       size_t m = 0;
       for (uint64_t i = b0; i < b0 + 1024; ++i)
         if (osc_idx[i] >= 0) ln[m++] = osc_idx[i] >> 5;
@@ -181,7 +246,7 @@ int m3hip_upload_events(m3hip_handle h, uint64_t event_offset, uint64_t n, const
             h->max_norm_idx_evw = std::max<int64_t>(h->max_norm_idx_evw, plane[i]);
           }
         }
-        HIPCHK(h, hipMemcpy(h->d_nidx + size_t(m) * h->E_pad + event_offset, plane.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice));
+        if (int rc_p = put_events(h, h->d_nidx + size_t(m) * h->E_pad, event_offset, plane.data(), n, sizeof(int16_t))) return rc_p;
       }
     }
   }
@@ -373,9 +438,9 @@ int m3hip_upload_kinematics(m3hip_handle h, uint64_t event_offset, uint64_t n, c
       if (sample_id[i] < 0 || sample_id[i] >= int(h->h_sample_ndim.size())) return fail(h, M3HIP_EINVAL, "upload_kinematics: sample id out of range");
       if (h->h_sample_ndim[sample_id[i]] > kin_stride) return fail(h, M3HIP_EINVAL, "upload_kinematics: kin_stride smaller than the sample's dimension");
     }
-    HIPCHK(h, hipMemcpy(h->d_sample_id + event_offset, sample_id, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (int rc_p = put_events(h, h->d_sample_id, event_offset, sample_id, n, sizeof(int32_t))) return rc_p;
   }
-  HIPCHK(h, hipMemcpy(h->d_kin + event_offset * kin_stride, kin, sizeof(double) * n * kin_stride, hipMemcpyHostToDevice));
+  if (int rc_p = put_events(h, h->d_kin, event_offset, kin, n, sizeof(double), uint32_t(kin_stride))) return rc_p;
   h->bins_computed = false;
   return M3HIP_OK;
 } M3_API_CATCH(h)
@@ -459,7 +524,7 @@ int m3hip_get_event_bins(m3hip_handle h, int32_t* out, uint64_t event_offset, ui
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc_b = bins_from_word(h)) return rc_b;
   HIPCHK(h, wait_stream(h->stream));
-  HIPCHK(h, hipMemcpy(out, h->d_bin + event_offset, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (int rc_g = get_events(h, out, h->d_bin, event_offset, n, sizeof(int32_t))) return rc_g;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -602,7 +667,7 @@ int m3hip_upload_event_weights(m3hip_handle h, int slot, uint64_t event_offset, 
     std::vector<float> ones(size_t(h->E_pad), 1.0f);  // events never uploaded: no such pointer, i.e. a factor of exactly 1
     HIPCHK(h, hipMemcpy(x.d_col, ones.data(), sizeof(float) * h->E_pad, hipMemcpyHostToDevice));
   }
-  HIPCHK(h, hipMemcpy(x.d_col + event_offset, w, sizeof(float) * n, hipMemcpyHostToDevice));
+  if (int rc_p = put_events(h, x.d_col, event_offset, w, n, sizeof(float))) return rc_p;
   h->n_extra = std::max(h->n_extra, slot + 1);
   h->extras_dirty = true;
   return M3HIP_OK;
@@ -626,7 +691,7 @@ int m3hip_upload_weight_index(m3hip_handle h, int slot, uint64_t event_offset, u
     if ((rc = dev_alloc(h, &x.d_idx, size_t(h->E_pad)))) return rc;
     HIPCHK(h, hipMemset(x.d_idx, 0xFF, sizeof(int32_t) * h->E_pad));  // -1: no pointer
   }
-  HIPCHK(h, hipMemcpy(x.d_idx + event_offset, idx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  if (int rc_p = put_events(h, x.d_idx, event_offset, idx, n, sizeof(int32_t))) return rc_p;
   h->n_extra = std::max(h->n_extra, slot + 1);
   h->extras_dirty = true;
   return M3HIP_OK;

@@ -168,8 +168,14 @@ int m3hip_eval_splines(m3hip_handle h, const float* vals, const int16_t* segment
     h->pending = 1;
   }
   HIPCHK(h, hipGetLastError());
-  if (cpu_total_weights)  // gpuSplineUtils.cu:505 cudaMemcpyAsync(cpu_total_weights, gpu_total_weights, ...)
-    HIPCHK(h, hipMemcpyAsync(cpu_total_weights, h->d_spline_w, sizeof(float) * h->E, hipMemcpyDeviceToHost, h->stream));
+  if (cpu_total_weights) {  // gpuSplineUtils.cu:505 cudaMemcpyAsync(cpu_total_weights, gpu_total_weights, ...)
+    const float* src = h->d_spline_w;
+    if (!h->h_c2p.empty()) {  // an upload the engine re-ordered (m3hip_monolith_order_key): back into the caller's event order first
+      if (int rc_g = gather_events_async(h, h->d_spline_w, h->E, sizeof(float))) return rc_g;
+      src = static_cast<const float*>(h->d_xfer);
+    }
+    HIPCHK(h, hipMemcpyAsync(cpu_total_weights, src, sizeof(float) * h->E, hipMemcpyDeviceToHost, h->stream));
+  }
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -636,7 +642,7 @@ int m3hip_get_spline_weights(m3hip_handle h, float* out, uint64_t event_offset, 
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
-  HIPCHK(h, hipMemcpy(out, h->d_spline_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+  if (int rc_g = get_events(h, out, h->d_spline_w, event_offset, n, sizeof(float))) return rc_g;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -653,7 +659,7 @@ int m3hip_get_event_weights(m3hip_handle h, float* out, uint64_t event_offset, u
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
-  HIPCHK(h, hipMemcpy(out, h->d_event_w + event_offset, sizeof(float) * n, hipMemcpyDeviceToHost));
+  if (int rc_g = get_events(h, out, h->d_event_w, event_offset, n, sizeof(float))) return rc_g;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
@@ -664,7 +670,7 @@ int m3hip_get_event_weights_f64(m3hip_handle h, double* out, uint64_t event_offs
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   collect_timing(h);
-  HIPCHK(h, hipMemcpy(out, h->d_event_w_d + event_offset, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (int rc_g = get_events(h, out, h->d_event_w_d, event_offset, n, sizeof(double))) return rc_g;
   return M3HIP_OK;
 } M3_API_CATCH(h)
 

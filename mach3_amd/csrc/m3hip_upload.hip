@@ -75,6 +75,13 @@ void free_monolith(m3hip_handle h) {
   dev_free(h->d_pos_llen); h->d_pos_llen = nullptr;
   h->pos_dirty = true;
   h->grouped.clear();
+  h->keyed.clear();
+  h->next_key.clear();
+  h->h_c2p.clear();
+  dev_free(h->d_c2p); h->d_c2p = nullptr;
+  h->n_keyed_chunks = h->n_key_refused = 0;
+  h->osc_lines_stale = false;
+  h->osc_line_sum = h->osc_line_blocks = 0;
   h->perm_monolith = false;
   h->n_grouped_chunks = 0;
   h->brick_groups = 0;
@@ -297,6 +304,14 @@ int m3hip_monolith_expect_events(m3hip_handle h, uint64_t n_events) try {
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
+int m3hip_monolith_order_key(m3hip_handle h, const int32_t* key, uint64_t n_events) try {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_order_key outside monolith_begin / monolith_end");
+  if (!key && n_events) return fail(h, M3HIP_EINVAL, "monolith_order_key: NULL key");
+  h->next_key.assign(key, key + n_events);
+  return M3HIP_OK;
+} M3_API_CATCH(h)
+
 int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
                           const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
                           const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
@@ -333,56 +348,113 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   h->short_bricks.take(h->E, n_events, &short_from, &short_to);
   if (!plan_chunk(h->P, h->K, h->h_npts.data(), in, &plan, &err, G, short_from, short_to)) return fail(h, M3HIP_EINVAL, "monolith_append: " + err);
 
+  // A candidate lay-out of the chunk: the {count,start} pairs in some order of the events (they point into the flat response
+  // arrays, which stay as they are) and its plan.
+  struct Candidate {
+    ChunkInput in;
+    ChunkPlan plan;
+    std::vector<unsigned int> npe, npe_tf1;  // storage behind in.npe / in.npe_tf1 once the events were permuted
+    std::vector<uint32_t> group_order;       // processing position -> event of `in`, when the grouping below was taken
+    void permute(const std::vector<uint32_t>& ord) {  // events of `in` re-ordered: new event pos = old event ord[pos]
+      std::vector<unsigned int> a(2 * ord.size()), b(2 * ord.size());
+      for (size_t pos = 0; pos < ord.size(); ++pos) {
+        const uint32_t e = ord[pos];
+        a[2 * pos] = in.npe[2 * e];
+        a[2 * pos + 1] = in.npe[2 * e + 1];
+        b[2 * pos] = in.npe_tf1[2 * e];
+        b[2 * pos + 1] = in.npe_tf1[2 * e + 1];
+      }
+      npe.swap(a);
+      npe_tf1.swap(b);
+      in.npe = npe.data();
+      in.npe_tf1 = npe_tf1.data();
+    }
+  };
+  auto bytes_of = [](const ChunkPlan& p) { return double(p.spl_float4) * 16 + double(p.tf1_float2) * 8 + double(p.meta_int32) * 4 + double(p.brick_words.size()) * 4; };
   // Grouping.  When a sizeable part of the chunk would end up in bricks, try the chunk with its events grouped by
   // parameter list (stable sort): events of one interaction mode then sit together and form uniform (or padded)
-  // tiles.  Only the small {count,start} arrays are permuted -- they point into the flat response arrays, which
-  // stay as they are -- and the kernels map a lane position back to its event through the permutation, so every
-  // per-event array and every result keeps the caller's event order.
-  std::vector<uint32_t> order;
-  std::vector<unsigned int> npe_g, npe_tf1_g;
-  {
+  // tiles.  The kernels map a lane position back to its event through the permutation (ReweightArgs::perm), so the
+  // per-event arrays stay in event order.
+  auto group = [&](Candidate& c) {
     uint64_t ragged = 0;
-    for (const BrickHost& bh : plan.bricks) ragged += bh.n_events;
+    for (const BrickHost& bh : c.plan.bricks) ragged += bh.n_events;
     const char* f = getenv("M3HIP_GROUP_EVENTS");
     const bool enabled = !(f && f[0] == '0');
-    if (enabled && ragged * 10 > n_events) {
-      std::vector<uint32_t> ord(n_events);
-      for (uint64_t e = 0; e < n_events; ++e) ord[e] = uint32_t(e);
-      auto less = [&](uint32_t x, uint32_t y) {  // lexicographic on (spline parameters, TF1 parameters)
-        const unsigned int cx = n_param_per_event[2 * x], sx = n_param_per_event[2 * x + 1];
-        const unsigned int cy = n_param_per_event[2 * y], sy = n_param_per_event[2 * y + 1];
-        if (std::lexicographical_compare(param_no + sx, param_no + sx + cx, param_no + sy, param_no + sy + cy)) return true;
-        if (std::lexicographical_compare(param_no + sy, param_no + sy + cy, param_no + sx, param_no + sx + cx)) return false;
-        const unsigned int tx = n_param_per_event_tf1[2 * x], ux = n_param_per_event_tf1[2 * x + 1];
-        const unsigned int ty = n_param_per_event_tf1[2 * y], uy = n_param_per_event_tf1[2 * y + 1];
-        return std::lexicographical_compare(param_no_tf1 + ux, param_no_tf1 + ux + tx, param_no_tf1 + uy, param_no_tf1 + uy + ty);
-      };
-      std::stable_sort(ord.begin(), ord.end(), less);
-      npe_g.resize(2 * n_events);
-      npe_tf1_g.resize(2 * n_events);
-      for (uint64_t pos = 0; pos < n_events; ++pos) {
-        const uint32_t e = ord[pos];
-        npe_g[2 * pos] = n_param_per_event[2 * e];
-        npe_g[2 * pos + 1] = n_param_per_event[2 * e + 1];
-        npe_tf1_g[2 * pos] = n_param_per_event_tf1[2 * e];
-        npe_tf1_g[2 * pos + 1] = n_param_per_event_tf1[2 * e + 1];
-      }
-      ChunkInput in_g = in;
-      in_g.npe = npe_g.data();
-      in_g.npe_tf1 = npe_tf1_g.data();
-      ChunkPlan plan_g;
-      std::string err_g;
-      if (plan_chunk(h->P, h->K, h->h_npts.data(), in_g, &plan_g, &err_g, G, short_from, short_to)) {
-        uint64_t ragged_g = 0;
-        for (const BrickHost& bh : plan_g.bricks) ragged_g += bh.n_events;
-        if (ragged_g * 2 <= ragged) {  // at least halves what goes through bricks
-          in = in_g;
-          plan = std::move(plan_g);
-          order = std::move(ord);
-        }
+    if (!enabled || ragged * 10 <= n_events) return;
+    const unsigned int *npe_in = c.in.npe, *npe_tf1_in = c.in.npe_tf1;
+    std::vector<uint32_t> ord(n_events);
+    for (uint64_t e = 0; e < n_events; ++e) ord[e] = uint32_t(e);
+    auto less = [&](uint32_t x, uint32_t y) {  // lexicographic on (spline parameters, TF1 parameters)
+      const unsigned int cx = npe_in[2 * x], sx = npe_in[2 * x + 1];
+      const unsigned int cy = npe_in[2 * y], sy = npe_in[2 * y + 1];
+      if (std::lexicographical_compare(param_no + sx, param_no + sx + cx, param_no + sy, param_no + sy + cy)) return true;
+      if (std::lexicographical_compare(param_no + sy, param_no + sy + cy, param_no + sx, param_no + sx + cx)) return false;
+      const unsigned int tx = npe_tf1_in[2 * x], ux = npe_tf1_in[2 * x + 1];
+      const unsigned int ty = npe_tf1_in[2 * y], uy = npe_tf1_in[2 * y + 1];
+      return std::lexicographical_compare(param_no_tf1 + ux, param_no_tf1 + ux + tx, param_no_tf1 + uy, param_no_tf1 + uy + ty);
+    };
+    std::stable_sort(ord.begin(), ord.end(), less);
+    Candidate g;
+    g.in = c.in;
+    g.permute(ord);
+    std::string err_g;
+    if (!plan_chunk(h->P, h->K, h->h_npts.data(), g.in, &g.plan, &err_g, G, short_from, short_to)) return;
+    uint64_t ragged_g = 0;
+    for (const BrickHost& bh : g.plan.bricks) ragged_g += bh.n_events;
+    if (ragged_g * 2 > ragged) return;  // (taken when it at least halves what goes through bricks)
+    c.npe.swap(g.npe);
+    c.npe_tf1.swap(g.npe_tf1);
+    c.in.npe = c.npe.data();
+    c.in.npe_tf1 = c.npe_tf1.data();
+    c.plan = std::move(g.plan);
+    c.group_order = std::move(ord);
+  };
+  Candidate cand;
+  cand.in = in;
+  cand.plan = std::move(plan);
+  group(cand);
+  // Order key (m3hip_monolith_order_key).  The chunk's events are STORED in the order of the caller's key (a stable sort: a chunk
+  // already in order stays as it is), then grouped as above (stable again: inside a group the key's order stays) -- unless that
+  // lay-out is more than 2 % larger than the one of the caller's order (a key that tears runs of equal parameter lists apart in
+  // a way the grouping does not mend; m3hip_info::n_key_refused counts those chunks).  From here on "event" means the physical
+  // one: the device never sees the caller's numbering, the API's per-event transfers translate (put_events / get_events).
+  std::vector<uint32_t> key_order;
+  if (!h->next_key.empty()) {
+    if (h->next_key.size() != n_events) {
+      h->next_key.clear();
+      return fail(h, M3HIP_EINVAL, "monolith_append: the order key was given for another number of events");
+    }
+    const std::vector<int32_t> key = std::move(h->next_key);
+    h->next_key.clear();
+    std::vector<uint32_t> ord(n_events);
+    for (uint64_t e = 0; e < n_events; ++e) ord[e] = uint32_t(e);
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return uint32_t(key[x]) < uint32_t(key[y]); });  // (negative keys last)
+    bool moved = false;
+    for (uint64_t pos = 0; pos < n_events && !moved; ++pos) moved = ord[pos] != pos;
+    if (moved) {
+      Candidate k;
+      k.in = in;
+      k.permute(ord);
+      std::string err_k;
+      bool ok = plan_chunk(h->P, h->K, h->h_npts.data(), k.in, &k.plan, &err_k, G, short_from, short_to);
+      if (ok) group(k);
+      if (ok && bytes_of(k.plan) <= 1.02 * bytes_of(cand.plan)) {
+        cand.npe.swap(k.npe);
+        cand.npe_tf1.swap(k.npe_tf1);
+        cand.in = k.in;
+        cand.in.npe = cand.npe.data();
+        cand.in.npe_tf1 = cand.npe_tf1.data();
+        cand.plan = std::move(k.plan);
+        cand.group_order = std::move(k.group_order);
+        key_order = std::move(ord);
+      } else {
+        h->n_key_refused++;
       }
     }
   }
+  in = cand.in;
+  plan = std::move(cand.plan);
+  std::vector<uint32_t> order = std::move(cand.group_order);
   // host staging (pinned) -> device
   struct Pinned {  // released on every way out of this function
     void* p = nullptr;
@@ -409,6 +481,10 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   if (e != hipSuccess) {
     dev_free(c.d_spl); dev_free(c.d_tf1); dev_free(c.d_words);
     return fail(h, e == hipErrorOutOfMemory ? M3HIP_ENOMEM : M3HIP_EHIP, std::string("monolith_append upload: ") + hipGetErrorString(e));
+  }
+  if (!key_order.empty()) {
+    h->n_keyed_chunks++;
+    h->keyed.emplace_back(h->E, std::move(key_order));
   }
   if (!order.empty()) {  // only now: a chunk that failed to upload leaves no trace
     h->perm_monolith = true;
@@ -546,6 +622,17 @@ int m3hip_monolith_end(m3hip_handle h) try {
   }
   h->grouped.clear();
   h->grouped.shrink_to_fit();
+  if (!h->keyed.empty()) {  // caller's event -> physical event; identity over the chunks that kept their order
+    h->h_c2p.resize(size_t(h->E));
+    for (size_t i = 0; i < h->h_c2p.size(); ++i) h->h_c2p[i] = uint32_t(i);
+    for (const auto& k : h->keyed)
+      for (size_t pos = 0; pos < k.second.size(); ++pos) h->h_c2p[size_t(k.first) + k.second[pos]] = uint32_t(k.first + pos);
+    if ((rc = dev_alloc(h, &h->d_c2p, size_t(h->E)))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_c2p, h->h_c2p.data(), sizeof(uint32_t) * h->E, hipMemcpyHostToDevice));
+  }
+  h->keyed.clear();
+  h->keyed.shrink_to_fit();
+  h->next_key.clear();
   h->mono_open = false;
   h->mono_done = true;
   return M3HIP_OK;

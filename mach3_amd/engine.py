@@ -50,6 +50,10 @@ class Engine:
         self._chk(self.lib.m3hip_monolith_begin(self.h, n_params, max_knots, _ptr(coeff_x, np.float32), _ptr(npts, np.int16)))
 
     def monolith_append(self, ch: dict):
+        key = ch.get("order_key")  # optional: the engine may store this chunk's events in the key's order (m3hip_monolith_order_key)
+        if key is not None:
+            key = np.ascontiguousarray(key, np.int32)
+            self._chk(self.lib.m3hip_monolith_order_key(self.h, _ptr(key, np.int32), int(key.size)))
         self._chk(self.lib.m3hip_monolith_append(
             self.h, ch["n_events"], _ptr(ch["coeff_many"], np.float32), ch["total_nknots"],
             _ptr(ch["nknots_arr"], np.uint32), _ptr(ch["param_no"], np.int16), ch["n_splines"],
@@ -492,9 +496,10 @@ class SampleHandlerFD:
         return seg, val
 
 
-def build_from_synth(spec, device_id=0, chunk_events=131072, event_range=None, engine=None):
+def build_from_synth(spec, device_id=0, chunk_events=131072, event_range=None, engine=None, order_by_osc=False):
     """Generate `spec` (events [e0,e1) of it) and upload it through the C ABI.
-    Returns (engine, SMonolith, SampleHandlerFD, par_vector)."""
+    Returns (engine, SMonolith, SampleHandlerFD, par_vector).  order_by_osc: every chunk goes up with its events'
+    oscillation indices as the order key (m3hip_monolith_order_key)."""
     from . import synth
 
     e0, e1 = (0, spec.n_events) if event_range is None else event_range
@@ -503,7 +508,10 @@ def build_from_synth(spec, device_id=0, chunk_events=131072, event_range=None, e
 
     def chunks():
         for a in range(e0, e1, chunk_events):
-            yield synth.monolith_chunk(spec, a, min(e1, a + chunk_events))
+            ch = synth.monolith_chunk(spec, a, min(e1, a + chunk_events))
+            if order_by_osc:
+                ch["order_key"] = synth.events_chunk(spec, a, min(e1, a + chunk_events))["osc_idx"]
+            yield ch
 
     mono = SMonolith(eng, spec.n_params, spec.n_knots, cx, npts, chunks(), expect_events=e1 - e0)
     par = synth.params(spec, 0)

@@ -231,12 +231,12 @@ def test_two_parameter_handlers_attached_to_one_engine():
         assert out[1] == 12 and out[0] <= 1e-12, (na, nb, out)
 
 
-def _run_sharded(tmp, n_ranks, exchange, events=60000, params=48, steps=150, timeout=300):
+def _run_sharded(tmp, n_ranks, exchange, events=60000, params=48, steps=150, timeout=300, order_key=0):
     exe = os.path.join(ROOT, "build", "mr2t2_sharded")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", ROOT, "examples"], check=True)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([exe, str(r), str(n_ranks), tmp, exchange, str(events), str(params), str(steps), "0"], env=env,
+    procs = [subprocess.Popen([exe, str(r), str(n_ranks), tmp, exchange, str(events), str(params), str(steps), "0", str(order_key)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n_ranks)]
     outs = []
     for p in procs:
@@ -283,6 +283,24 @@ def test_sharded_chain_through_the_facade_takes_the_same_decisions_on_every_rank
     assert 5 < int(one["accepted"]) < 145
     assert float(a["logl"]) == pytest.approx(float(one["logl"]), rel=1e-9)
     assert np.allclose(b20, b1, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_chain_over_events_the_engine_stored_in_oscillation_order():
+    """SMonolithGPU::next_event_order_key -> m3hip_monolith_order_key from the C++ side: the same seeded MR2T2 over the same
+    sample, once as the MC is numbered and once with the engine storing its events in oscillation-bin order.  Nothing else
+    changes in the caller (AddEvent in MC order): the same accept / reject sequence, likelihood to 1e-9, bins to 1e-12 (the same
+    sums in another order).  Reference: the events alias the calculator's array in MC order, Samples/SampleHandlerFD.cpp:1108-1133."""
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+        plain = _run_sharded(t1, 1, "none")[0]
+        keyed = _run_sharded(t2, 1, "none", order_key=1)[0]
+        b1, b2 = np.fromfile(os.path.join(t1, "bins_0.bin")), np.fromfile(os.path.join(t2, "bins_0.bin"))
+    assert plain["keyed_chunks"] == "0" and keyed["keyed_chunks"] == "1" and float(keyed["osc_lines"]) < 0.5 * float(plain["osc_lines"])
+    assert keyed["acc"] == plain["acc"] and len(plain["acc"]) == 150 and 5 < int(plain["accepted"]) < 145
+    assert float(keyed["logl"]) == pytest.approx(float(plain["logl"]), rel=1e-9)
+    assert np.allclose(b2, b1, rtol=1e-12, atol=0)
 
 
 @pytest.mark.gpu
