@@ -31,6 +31,7 @@ int put_events(m3hip_handle h, void* dst_base, uint64_t off, const void* src, ui
     HIPCHK(h, hipMemcpy(static_cast<char*>(dst_base) + size_t(off) * width * elem, src, bytes, hipMemcpyHostToDevice));
     return M3HIP_OK;
   }
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // the staging buffer may still feed an asynchronous copy (m3hip_eval_splines' weights)
   if (int rc = xfer_reserve(h, bytes)) return rc;
   HIPCHK(h, hipMemcpy(h->d_xfer, src, bytes, hipMemcpyHostToDevice));
   const dim3 g((unsigned)((n * width + 255) / 256)), b(256);
@@ -60,6 +61,7 @@ int get_events(m3hip_handle h, void* out, const void* src_base, uint64_t off, ui
     HIPCHK(h, hipMemcpy(out, static_cast<const char*>(src_base) + size_t(off) * elem, bytes, hipMemcpyDeviceToHost));
     return M3HIP_OK;
   }
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // (as in put_events: before the staging buffer is resized or rewritten)
   if (int rc = gather_into_xfer(h, src_base, off, n, elem)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->d_xfer, bytes, hipMemcpyDeviceToHost));

@@ -74,7 +74,15 @@ def test_random_shape_many_bins_and_samples(fresh_engine, seed):
     _run_case(fresh_engine, c, 1000 + seed)
 
 
-def _run_case(fresh_engine, c, seed):
+@pytest.mark.parametrize("seed", range(24 * SCALE))
+def test_random_shape_stored_in_the_order_of_a_key(fresh_engine, seed):
+    """the same sweep with every upload chunk handed an order key (m3hip_monolith_order_key): the events' oscillation indices, a
+    random key, or a coarse descending one -- the engine stores the events in another order (or refuses the key where it would
+    inflate the layout), every per-event array and result keeps the oracle's numbering"""
+    _run_case(fresh_engine, _case(2000 + seed), 2000 + seed, key_mode=("osc", "random", "coarse")[seed % 3])
+
+
+def _run_case(fresh_engine, c, seed, key_mode=None):
     rng, P, E = c["rng"], c["P"], c["E"]
     cx, npts, ch = make_monolith(P, 7, c["xs"], c["events"])
     nPar = P + c["n_norm"]
@@ -106,6 +114,13 @@ def _run_case(fresh_engine, c, seed):
     if E > 2048 and seed % 2:
         cut = 1024 * int(rng.integers(1, E // 1024))
         chunks = [make_monolith(P, 7, c["xs"], c["events"][:cut])[2], make_monolith(P, 7, c["xs"], c["events"][cut:])[2]]
+    if key_mode is not None:
+        key = (osc_idx if key_mode == "osc" and osc_idx is not None else
+               rng.integers(-1, 50, E).astype(np.int32) if key_mode != "coarse" else ((E - np.arange(E)) // 7).astype(np.int32))
+        a0 = 0
+        for chk in chunks:
+            chk["order_key"] = key[a0:a0 + chk["n_events"]]
+            a0 += chk["n_events"]
     # bricks of 1024, 2048 or 4096 events, by the seed (the engine reads the switch when the first chunk arrives)
     forced = os.environ.get("M3HIP_BRICK_GROUPS")
     os.environ["M3HIP_BRICK_GROUPS"] = forced or str((1, 2, 4)[seed % 3])
@@ -116,6 +131,9 @@ def _run_case(fresh_engine, c, seed):
     finally:
         if forced is None:
             del os.environ["M3HIP_BRICK_GROUPS"]
+    if key_mode is not None and E > 1:
+        info = fresh_engine.info()
+        assert info.n_keyed_chunks + info.n_key_refused >= 1 or np.all(np.diff(key.view(np.uint32).astype(np.int64)) >= 0), (seed, key_mode)
     mono.setSplinePointers(par)
     off = (np.arange(c["n_samples"] + 1) * c["nb"]).astype(np.int32)
     sh = SampleHandlerFD(fresh_engine, c["n_samples"], off, par, c["stat"], update_w2=c["update_w2"])
