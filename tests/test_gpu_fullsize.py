@@ -68,10 +68,12 @@ def test_config2_full_size_properties():
     assert np.allclose(parts[0] + parts[1], mc_whole, rtol=1e-11, atol=0)
 
 
-def _check_full_size(spec, e0, e1, windows, chunk_events=131072, laps=(1, 2), shard_check=True):
-    """properties of events [e0, e1) of `spec` on one GPU (see the module docstring); windows are relative to e0"""
+def _check_full_size(spec, e0, e1, windows, chunk_events=131072, laps=(1, 2), shard_check=True, order_key=False, move_table=False):
+    """properties of events [e0, e1) of `spec` on one GPU (see the module docstring); windows are relative to e0.
+    order_key: every chunk goes up with its events' oscillation indices as the order key (m3hip_monolith_order_key);
+    move_table: a new oscillation table before every lap (the step of a fit that moves oscillation parameters)"""
     E = e1 - e0
-    eng, mono, sh, par = build_from_synth(spec, chunk_events=chunk_events, event_range=(e0, e1))
+    eng, mono, sh, par = build_from_synth(spec, chunk_events=chunk_events, event_range=(e0, e1), order_by_osc=order_key)
     info = eng.info()
     assert info.n_events == E
     ns, nt = 0, 0
@@ -92,6 +94,11 @@ def _check_full_size(spec, e0, e1, windows, chunk_events=131072, laps=(1, 2), sh
     mc = None
     for lap in laps:
         par[:] = synth.params(spec, lap)
+        if move_table:
+            tbl = np.random.default_rng(100 + lap).random(spec.osc_n).astype(np.float32)
+            sh.SetOscillationWeights(tbl)
+            for _, osamp, *_rest in oracles:
+                osamp.keep[7][:] = tbl                    # the oracle's events alias this array
         llh = sh.Step()
         assert llh > 0
         mc = sh.GetMCArray()
@@ -155,6 +162,19 @@ def test_config5_shard_properties():
     # 16 responses per event and 12 208 groups of 1024 events: the engine lays this shard out in bricks of 4096 events (chunk by chunk)
     assert info.n_params == 1024 and info.brick_groups == 4
     assert info.n_tiles_brick == sum(-(-min(131072, per - a) // 4096) for a in range(0, per, 131072))
+
+
+def test_config5_shard_stored_in_oscillation_order_table_replaced_every_step():
+    """the same shape (another GPU's share) with the engine storing every 2^20-event chunk in oscillation-bin order
+    (m3hip_monolith_order_key) and the 204 000-entry table replaced before every step: what a fit that moves oscillation
+    parameters runs (Samples/SampleHandlerFD.cpp:323, Samples/OscillationHandler.cpp:81-100).  Windows at the start, across a
+    chunk border and at the end bit for bit in the CALLER's event numbering; conservation over all 1.25e7 events."""
+    spec = synth.CONFIGS["c5"]
+    per = spec.n_events // 8
+    info = _check_full_size(spec, 2 * per, 3 * per, [(0, 3000), ((1 << 20) - 1024, (1 << 20) + 1024), (per - 2048, per)], chunk_events=1 << 20,
+                            laps=(1, 2), shard_check=False, order_key=True, move_table=True)
+    assert info.n_keyed_chunks == -(-per // (1 << 20)) and info.n_key_refused == 0 and info.brick_groups == 4
+    assert info.osc_lines_per_kevent < 10            # (858 in the MC's own order)
 
 
 def test_more_than_1024_parameters_at_mid_size():
