@@ -631,7 +631,7 @@ def osc_moves_leg(args, local_rank, torch):
     from mach3_amd import synth
     res = {"what": "kernel = fused reweight kernel by dispatch-stamped events; frac = algorithmic bytes / kernel / 8 TB/s; table replaced before every step"}
     shapes = [("configs[4] one GPU's share of 8", synth.CONFIGS["c5"].scaled(12_500_000), "c5", False),
-              ("configs[4] share, stored by the engine in oscillation-bin order (m3hip_monolith_order_key, upload chunks of 2^20 events)",
+              ("configs[4] share, stored by the engine in oscillation-bin order (m3hip_monolith_order_key)",
                synth.CONFIGS["c5"].scaled(12_500_000), "c5", True),
               ("configs[4] share, MC in oscillation-bin order", synth.CONFIGS["c5"].scaled(12_500_000, osc_sorted=True), "c5", False),
               ("configs[2]", synth.CONFIGS["c3"], "c3", False)]
@@ -640,9 +640,7 @@ def osc_moves_leg(args, local_rank, torch):
         lines = None
         for tbl in ("resting", "device", "host"):
             a = argparse.Namespace(**vars(args))
-            a.order_key = keyed
-            if keyed:
-                a.chunk = 1 << 20  # the key orders a chunk's events: 131 072 events leave 51 table lines per 1024 events (0.696), 2^20 leave 7 (0.710)
+            a.order_key = keyed  # (the engine holds keyed chunks back until 2^20 events are together: the upload's slicing does not matter)
             a.check, a.table, a.spinup_seconds, a.warmup = False, tbl, min(args.spinup_seconds, 0.5), max(args.warmup, 8)
             m = measure(spec, 0, 1, local_rank, a, None, torch, False)
             row[tbl] = {"ms_per_step": 1e3 * m["el"] / a.steps, "avg_kernel_ms": m["k_ms"], "launches_timed": m["k_n"],

@@ -125,7 +125,10 @@ int m3hip_monolith_begin(m3hip_handle h, int n_params, int max_knots, const floa
  * Invisible through this interface: every per-event array handed over later and every per-event result keeps the CALLER's event
  * numbering (the library scatters / gathers at the boundary; set-up and diagnostics only -- a step moves no per-event data).  The
  * bin contents are the same sums in another order.  A chunk whose layout the key's order would inflate by more than 2 % (it tears
- * runs of equal parameter lists apart) keeps its order: m3hip_info::n_key_refused.  The key is consumed by the next append. */
+ * runs of equal parameter lists apart) keeps its order: m3hip_info::n_key_refused.  The key is consumed by the next append.
+ * How the caller slices its upload does not matter: keyed chunks are held back (copied into the engine's own host arrays) until
+ * 2^20 events are together and laid out as one chunk -- m3hip_info::n_keyed_chunks counts those -- so an error in a keyed chunk's
+ * arrays may be reported by a LATER append or by m3hip_monolith_end; a chunk of 2^20 events and more goes straight through. */
 int m3hip_monolith_order_key(m3hip_handle h, const int32_t* key, uint64_t n_events);
 int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many,
                           uint64_t total_nknots, const unsigned int* nknots_arr,
@@ -455,7 +458,7 @@ typedef struct {
                                  * rests (the weights are folded into the events' words), +11 % on BASELINE configs[4]'s kernel when a fit moves
                                  * oscillation parameters.  m3hip_monolith_order_key lets the engine store the events in table order itself
                                  * (the figure is then of ITS order); SampleHandlerFD::EventOrderByOscillationBin gives the order to register the MC in. */
-  uint64_t n_keyed_chunks;      /* upload chunks stored in the order of the caller's key (m3hip_monolith_order_key) */
+  uint64_t n_keyed_chunks;      /* chunks (of >= 2^20 events, merged from the caller's keyed chunks) stored in the order of the key (m3hip_monolith_order_key) */
   uint64_t n_key_refused;       /* ... that kept their order because the key's would have cost more than 2 % of layout bytes */
 } m3hip_info;
 int m3hip_get_info(m3hip_handle h, m3hip_info* out);

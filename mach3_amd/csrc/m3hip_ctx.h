@@ -109,6 +109,16 @@ struct ShortBrickPlan {
   void take(uint64_t chunk_first, uint64_t chunk_events, uint64_t* from, uint64_t* to);
 };
 
+// keyed chunks held back until enough events are together (m3hip_upload.hip, hold_back_keyed): a chunk in the reference's flat
+// layout, owned by the engine
+struct KeyedChunks {
+  uint64_t n_events = 0;
+  std::vector<float> coeff_many, coeff_tf1;
+  std::vector<unsigned int> nknots_arr, npe, npe_tf1;
+  std::vector<int16_t> param_no, param_no_tf1;
+  std::vector<int32_t> key;
+};
+
 struct m3hip_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -269,6 +279,7 @@ struct m3hip_ctx {
   // EVERYTHING on the device is in that physical order -- the kernels know nothing of it; the API translates: per-event uploads
   // are scattered and per-event results gathered through c2p (caller's event number -> physical event).  Empty: identity.
   std::vector<int32_t> next_key;  // key of the next m3hip_monolith_append (which takes it)
+  KeyedChunks keyed_acc;          // keyed chunks held back until 2^20 events are together
   std::vector<std::pair<uint64_t, std::vector<uint32_t>>> keyed;  // (first event, physical position -> caller's event, chunk-local) of every keyed chunk, until monolith_end
   std::vector<uint32_t> h_c2p;
   uint32_t* d_c2p = nullptr;

@@ -77,6 +77,7 @@ void free_monolith(m3hip_handle h) {
   h->grouped.clear();
   h->keyed.clear();
   h->next_key.clear();
+  h->keyed_acc = KeyedChunks();
   h->h_c2p.clear();
   dev_free(h->d_c2p); h->d_c2p = nullptr;
   h->n_keyed_chunks = h->n_key_refused = 0;
@@ -312,30 +313,12 @@ int m3hip_monolith_order_key(m3hip_handle h, const int32_t* key, uint64_t n_even
   return M3HIP_OK;
 } M3_API_CATCH(h)
 
-int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
-                          const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
-                          const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
-                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) try {
-  if (!h) return M3HIP_EINVAL;
-  if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_append before monolith_begin");
-  if (h->E % M3_GROUP != 0) return fail(h, M3HIP_EINVAL, "only the last chunk may hold a non-multiple of 1024 events");
-  if (h->E + n_events > 0xFFFFF000ull) return fail(h, M3HIP_EINVAL, "more than 2^32 events on one device");
-  if (n_events == 0) return M3HIP_OK;
-  if ((n_splines && (!coeff_many || !nknots_arr || !param_no)) || (n_tf1 && (!coeff_tf1 || !param_no_tf1)))
-    return fail(h, M3HIP_EINVAL, "monolith_append: NULL coefficient arrays");
+// One chunk through the re-layout and onto the device.  `key`: the order key of its events (m3hip_monolith_order_key) or null.
+static int append_chunk(m3hip_handle h, ChunkInput in, const std::vector<int32_t>* key) {
+  const uint64_t n_events = in.n_events;
+  const int16_t *param_no = in.param_no, *param_no_tf1 = in.param_no_tf1;
+  const unsigned int *n_param_per_event = in.npe, *n_param_per_event_tf1 = in.npe_tf1;  // (in the caller's event order, whatever `in` turns into below)
   HIPCHK(h, hipSetDevice(h->device));
-  ChunkInput in;
-  in.n_events = n_events;
-  in.coeff_many = coeff_many;
-  in.total_nknots = total_nknots;
-  in.nknots_arr = nknots_arr;
-  in.param_no = param_no;
-  in.n_splines = n_splines;
-  in.coeff_tf1 = coeff_tf1;
-  in.param_no_tf1 = param_no_tf1;
-  in.n_tf1 = n_tf1;
-  in.npe = n_param_per_event;
-  in.npe_tf1 = n_param_per_event_tf1;
   ChunkPlan plan;
   std::string err;
   { const char* f = getenv("M3HIP_PAD_MIN_FILL"); g_pad_min_fill = f ? atof(f) : kPadMinFillDefault; }  // experiments: > 1 disables the identity padding
@@ -419,16 +402,10 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   // a way the grouping does not mend; m3hip_info::n_key_refused counts those chunks).  From here on "event" means the physical
   // one: the device never sees the caller's numbering, the API's per-event transfers translate (put_events / get_events).
   std::vector<uint32_t> key_order;
-  if (!h->next_key.empty()) {
-    if (h->next_key.size() != n_events) {
-      h->next_key.clear();
-      return fail(h, M3HIP_EINVAL, "monolith_append: the order key was given for another number of events");
-    }
-    const std::vector<int32_t> key = std::move(h->next_key);
-    h->next_key.clear();
+  if (key) {
     std::vector<uint32_t> ord(n_events);
     for (uint64_t e = 0; e < n_events; ++e) ord[e] = uint32_t(e);
-    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return uint32_t(key[x]) < uint32_t(key[y]); });  // (negative keys last)
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return uint32_t((*key)[x]) < uint32_t((*key)[y]); });  // (negative keys last)
     bool moved = false;
     for (uint64_t pos = 0; pos < n_events && !moved; ++pos) moved = ord[pos] != pos;
     if (moved) {
@@ -578,12 +555,126 @@ int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_
   }
   h->coeff_bytes += b_spl + b_tf1;
   return M3HIP_OK;
+}
+
+// Chunks that come with an order key are held back -- re-packed into the engine's own host arrays, because the caller's are only
+// good for the duration of the call -- until 2^20 events are together, and go through append_chunk as ONE chunk: the key orders the
+// events of a chunk, and how well the neighbours of an oscillation-table line end up together depends on how many events that is
+// (one GPU's share of BASELINE configs[4]: chunks of 131 072 events leave 51 table lines per 1024 stored events, 2^20 leave 7),
+// not on how the caller happened to slice its upload.  A chunk of that size by itself goes straight through.
+constexpr uint64_t kKeyedChunkEvents = uint64_t(1) << 20;
+static int flush_keyed(m3hip_handle h) {
+  KeyedChunks& a = h->keyed_acc;
+  if (a.n_events == 0) return M3HIP_OK;
+  ChunkInput in;
+  in.n_events = a.n_events;
+  in.coeff_many = a.coeff_many.data();
+  in.total_nknots = a.coeff_many.size() / 4;
+  in.nknots_arr = a.nknots_arr.data();
+  in.param_no = a.param_no.data();
+  in.n_splines = a.param_no.size();
+  in.coeff_tf1 = a.coeff_tf1.data();
+  in.param_no_tf1 = a.param_no_tf1.data();
+  in.n_tf1 = a.param_no_tf1.size();
+  in.npe = a.npe.data();
+  in.npe_tf1 = a.npe_tf1.data();
+  const int rc = append_chunk(h, in, &a.key);
+  a = KeyedChunks();  // (whatever happened: a chunk that failed leaves no trace)
+  return rc;
+}
+// the responses of a chunk's events, copied out of the caller's arrays (which may be those of a larger sample: only what the
+// {count,start} pairs of THESE events index is taken) behind what is already held back
+static int hold_back_keyed(m3hip_handle h, const ChunkInput& in, const std::vector<int32_t>& key) {
+  KeyedChunks& a = h->keyed_acc;
+  const size_t s0 = a.param_no.size(), t0 = a.param_no_tf1.size(), k0 = a.coeff_many.size() / 4;
+  size_t s_add = 0, t_add = 0, k_add = 0;
+  for (uint64_t e = 0; e < in.n_events; ++e) {
+    const uint64_t c = in.npe[2 * e], st = in.npe[2 * e + 1], ct = in.npe_tf1[2 * e], stt = in.npe_tf1[2 * e + 1];
+    if (st + c > in.n_splines || stt + ct > in.n_tf1) return fail(h, M3HIP_EINVAL, "monolith_append: an event's {count,start} pair points past the response arrays");
+    for (uint64_t i = 0; i < c; ++i) {
+      const int p = in.param_no[st + i];
+      if (p < 0 || p >= h->P || h->h_npts[size_t(p)] < 1) return fail(h, M3HIP_EINVAL, "monolith_append: a spline names a parameter without knots");
+      if (uint64_t(in.nknots_arr[st + i]) + uint64_t(h->h_npts[size_t(p)]) > in.total_nknots) return fail(h, M3HIP_EINVAL, "monolith_append: a spline's knots lie past the coefficient array");
+      k_add += size_t(h->h_npts[size_t(p)]);
+    }
+    s_add += c;
+    t_add += ct;
+  }
+  if ((k0 + k_add) > 0xFFFFFFFFull || (s0 + s_add) > 0xFFFFFFFFull || (t0 + t_add) > 0xFFFFFFFFull)
+    return fail(h, M3HIP_EINVAL, "monolith_append: more than 2^32 coefficients in one chunk of keyed events");
+  a.param_no.reserve(s0 + s_add);
+  a.nknots_arr.reserve(s0 + s_add);
+  a.coeff_many.reserve(4 * (k0 + k_add));
+  a.param_no_tf1.reserve(t0 + t_add);
+  a.coeff_tf1.reserve(2 * (t0 + t_add));
+  a.npe.reserve(a.npe.size() + 2 * in.n_events);
+  a.npe_tf1.reserve(a.npe_tf1.size() + 2 * in.n_events);
+  for (uint64_t e = 0; e < in.n_events; ++e) {
+    const uint64_t c = in.npe[2 * e], st = in.npe[2 * e + 1], ct = in.npe_tf1[2 * e], stt = in.npe_tf1[2 * e + 1];
+    a.npe.push_back(static_cast<unsigned int>(c));
+    a.npe.push_back(static_cast<unsigned int>(a.param_no.size()));
+    for (uint64_t i = 0; i < c; ++i) {
+      const int p = in.param_no[st + i];
+      const size_t nk = size_t(h->h_npts[size_t(p)]);
+      a.param_no.push_back(int16_t(p));
+      a.nknots_arr.push_back(static_cast<unsigned int>(a.coeff_many.size() / 4));
+      const float* src = in.coeff_many + 4 * size_t(in.nknots_arr[st + i]);
+      a.coeff_many.insert(a.coeff_many.end(), src, src + 4 * nk);
+    }
+    a.npe_tf1.push_back(static_cast<unsigned int>(ct));
+    a.npe_tf1.push_back(static_cast<unsigned int>(a.param_no_tf1.size()));
+    for (uint64_t i = 0; i < ct; ++i) {
+      a.param_no_tf1.push_back(in.param_no_tf1[stt + i]);
+      a.coeff_tf1.push_back(in.coeff_tf1[2 * (stt + i)]);
+      a.coeff_tf1.push_back(in.coeff_tf1[2 * (stt + i) + 1]);
+    }
+  }
+  a.key.insert(a.key.end(), key.begin(), key.end());
+  a.n_events += in.n_events;
+  return M3HIP_OK;
+}
+
+int m3hip_monolith_append(m3hip_handle h, uint64_t n_events, const float* coeff_many, uint64_t total_nknots,
+                          const unsigned int* nknots_arr, const int16_t* param_no, uint64_t n_splines,
+                          const float* coeff_tf1, const int16_t* param_no_tf1, uint64_t n_tf1,
+                          const unsigned int* n_param_per_event, const unsigned int* n_param_per_event_tf1) try {
+  if (!h) return M3HIP_EINVAL;
+  if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_append before monolith_begin");
+  const uint64_t held = h->keyed_acc.n_events;
+  if ((h->E + held) % M3_GROUP != 0) return fail(h, M3HIP_EINVAL, "only the last chunk may hold a non-multiple of 1024 events");
+  if (h->E + held + n_events > 0xFFFFF000ull) return fail(h, M3HIP_EINVAL, "more than 2^32 events on one device");
+  if (n_events == 0) return M3HIP_OK;
+  if ((n_splines && (!coeff_many || !nknots_arr || !param_no)) || (n_tf1 && (!coeff_tf1 || !param_no_tf1)) || !n_param_per_event || !n_param_per_event_tf1)
+    return fail(h, M3HIP_EINVAL, "monolith_append: NULL coefficient arrays");
+  ChunkInput in;
+  in.n_events = n_events;
+  in.coeff_many = coeff_many;
+  in.total_nknots = total_nknots;
+  in.nknots_arr = nknots_arr;
+  in.param_no = param_no;
+  in.n_splines = n_splines;
+  in.coeff_tf1 = coeff_tf1;
+  in.param_no_tf1 = param_no_tf1;
+  in.n_tf1 = n_tf1;
+  in.npe = n_param_per_event;
+  in.npe_tf1 = n_param_per_event_tf1;
+  if (h->next_key.empty()) {  // no key: whatever is held back goes first (the events keep their places)
+    if (int rc = flush_keyed(h)) return rc;
+    return append_chunk(h, in, nullptr);
+  }
+  const std::vector<int32_t> key = std::move(h->next_key);
+  h->next_key.clear();
+  if (key.size() != n_events) return fail(h, M3HIP_EINVAL, "monolith_append: the order key was given for another number of events");
+  if (held == 0 && n_events >= kKeyedChunkEvents) return append_chunk(h, in, &key);
+  if (int rc = hold_back_keyed(h, in, key)) return rc;
+  return h->keyed_acc.n_events >= kKeyedChunkEvents ? flush_keyed(h) : M3HIP_OK;
 } M3_API_CATCH(h)
 
 int m3hip_monolith_end(m3hip_handle h) try {
   if (!h) return M3HIP_EINVAL;
   if (!h->mono_open) return fail(h, M3HIP_ESTATE, "monolith_end before monolith_begin");
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc_k = flush_keyed(h)) return rc_k;
   const uint64_t n_tiles = h->h_tiles.size();
   h->E_pad = ((h->E + M3_GROUP - 1) / M3_GROUP) * M3_GROUP;
   if (h->E_pad == 0) h->E_pad = M3_GROUP;

@@ -33,15 +33,15 @@ def test_events_stored_in_oscillation_order_results_in_the_callers(fresh_engine,
     spec = synth.CONFIGS[cfg].scaled(n_events, n_params=n_params, osc_n=40000)
     eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine, chunk_events=chunk, order_by_osc=True)
     info = eng.info()
-    assert info.n_keyed_chunks == -(-n_events // chunk) and info.n_key_refused == 0
+    assert info.n_keyed_chunks == 1 and info.n_key_refused == 0   # (keyed chunks are held back until 2^20 events are together: ONE chunk here)
     omono, osamp, opar, ch, ev = ob.build_oracle_from_synth(spec, 0, n_events)
     otbl = osamp.keep[7]
     assert info.n_splines == ch["n_splines"] and info.n_tf1 == ch["n_tf1"]
-    # the look-ups of 1024 consecutive events AS STORED: every chunk in the key's order (stable, -1 last)
+    # the look-ups of 1024 consecutive events AS STORED: in the key's order (stable, -1 last)
     def lines(osc):
         return np.mean([len(np.unique(osc[a:a + 1024][osc[a:a + 1024] >= 0] >> 5)) for a in range(0, n_events - 1023, 1024)])
-    stored = np.concatenate([ev["osc_idx"][a:a + chunk][np.argsort(ev["osc_idx"][a:a + chunk].view(np.uint32), kind="stable")] for a in range(0, n_events, chunk)])
-    assert info.osc_lines_per_kevent == pytest.approx(lines(stored), rel=1e-12) and lines(stored) < 0.5 * lines(ev["osc_idx"])
+    stored = ev["osc_idx"][np.argsort(ev["osc_idx"].view(np.uint32), kind="stable")]
+    assert info.osc_lines_per_kevent == pytest.approx(lines(stored), rel=1e-12) and lines(stored) < 0.25 * lines(ev["osc_idx"])
     assert np.array_equal(sh.GetEventBins(0, n_events), ev["bin_idx"])          # uploaded in the caller's order, read back in it
     assert np.array_equal(sh.GetEventBins(1000, 777), ev["bin_idx"][1000:1777])  # ... any range
     sh.RecordEventWeights(True)
@@ -88,6 +88,51 @@ def test_events_stored_in_oscillation_order_results_in_the_callers(fresh_engine,
     assert np.array_equal(sh.GetEventBins(0, n_events), ev2["bin_idx"])
     osamp.close()
     omono.close()
+
+
+def test_keyed_chunks_are_held_back_until_2e20_events_are_together(fresh_engine):
+    """2.5e6 light events (configs[4]'s shape) uploaded in chunks of 131 072 with their oscillation indices as the key: the engine
+    lays them out as chunks of 2^20, 2^20 and the rest -- three sorts, not twenty -- and a chunk WITHOUT a key in between flushes
+    what is held back (the events keep their places).  Windows across the engine's own chunk borders bit for bit."""
+    n_events, chunk = 2_500_000 + 333, 131072
+    spec = synth.CONFIGS["c5"].scaled(n_events, n_params=128)
+    eng, mono, sh, par = build_from_synth(spec, engine=fresh_engine, chunk_events=chunk, order_by_osc=True)
+    info = eng.info()
+    assert info.n_keyed_chunks == 3 and info.n_key_refused == 0 and info.n_events == n_events
+    osc_all = np.concatenate([synth.events_chunk(spec, a, min(n_events, a + 500_000))["osc_idx"] for a in range(0, n_events, 500_000)])
+    stored = np.concatenate([osc_all[a:a + (1 << 20)][np.argsort(osc_all[a:a + (1 << 20)].view(np.uint32), kind="stable")] for a in range(0, n_events, 1 << 20)])
+    lines = np.mean([len(np.unique(stored[a:a + 1024][stored[a:a + 1024] >= 0] >> 5)) for a in range(0, n_events - 1023, 1024)])
+    assert info.osc_lines_per_kevent == pytest.approx(lines, rel=1e-12) and lines < 12
+    windows = [(0, 2000), ((1 << 20) - 1000, (1 << 20) + 1000), ((1 << 21) - 1000, (1 << 21) + 1000), (n_events - 1500, n_events)]
+    oracles = [ob.build_oracle_from_synth(spec, a, b) for a, b in windows]
+    sh.RecordEventWeights(True)
+    rng = np.random.default_rng(3)
+    for lap in (1, 2):
+        tbl = rng.random(spec.osc_n).astype(np.float32)
+        sh.SetOscillationWeights(tbl)
+        par[:] = synth.params(spec, lap)
+        sh.Step()
+        for (a, b), (omono, osamp, opar, ch, ev) in zip(windows, oracles):
+            osamp.keep[7][:] = tbl
+            opar[:] = par
+            osamp.reweight()
+            assert np.array_equal(sh.GetSplineWeights(a, b - a).view(np.uint32), omono.total_weights.view(np.uint32)), (lap, a)
+            assert np.array_equal(sh.GetEventWeights(a, b - a).view(np.uint32), osamp.event_weights().view(np.uint32)), (lap, a)
+            assert np.array_equal(sh.GetEventBins(a, b - a), ev["bin_idx"])
+    for omono, osamp, *_ in oracles:
+        osamp.close()
+        omono.close()
+    # keyed, keyed, plain, keyed: the plain chunk flushes the two held back; the last one is flushed by monolith_end
+    cx, npts = synth.knots(spec)
+    eng.monolith_begin(spec.n_params, spec.n_knots, cx, npts)
+    for i, a in enumerate(range(0, 4 * 4096, 4096)):
+        ch = synth.monolith_chunk(spec, a, a + 4096)
+        if i != 2:
+            ch["order_key"] = synth.events_chunk(spec, a, a + 4096)["osc_idx"]
+        eng.monolith_append(ch)
+    eng.monolith_end()
+    info = eng.info()
+    assert info.n_keyed_chunks == 2 and info.n_events == 4 * 4096
 
 
 def test_a_key_in_order_changes_nothing_and_a_key_for_the_wrong_chunk_is_refused(fresh_engine):
