@@ -698,6 +698,7 @@ def main():
     ap.add_argument("--table", choices=["resting", "host", "device"], default="resting",
                     help="the oscillation table of the HEADLINE workload: resting = pre-staged once (BASELINE's configs; the default), host / device = "
                          "replaced before every step through m3hip_set_osc_table / m3hip_set_osc_table_device (profiling the moving-table step; the workload text says so)")
+    ap.add_argument("--osc-entries", type=int, default=0, help="override the number of entries of the oscillation table (debug; the workload text says so)")
     ap.add_argument("--order-key", action="store_true", help="every upload chunk goes up with its events' oscillation indices as the order key (m3hip_monolith_order_key)")
     ap.add_argument("--osc-sorted", action="store_true", help="the MC registered in oscillation-bin order (SynthSpec.osc_sorted; the workload text says so)")
     ap.add_argument("--osc-moves", action="store_true",
@@ -748,6 +749,8 @@ def main():
     spec = base.scaled(args.events) if args.events else base
     if args.osc_sorted:
         spec = spec.scaled(spec.n_events, osc_sorted=True)
+    if args.osc_entries:
+        spec = spec.scaled(spec.n_events, osc_n=args.osc_entries, osc_sorted=spec.osc_sorted)
 
     m = measure(spec, rank, n_gpus, local_rank, args, dist, torch, args.allow_host_fallback)
     ranks_seen = 1
