@@ -94,13 +94,14 @@ def binned_row(float_t, sort_by_cell=False):
     h = BinnedSplineHandler(eng, E, bs); h.setSplinePointers(par)
     edges = np.linspace(0, 5, 201); kin = rng.gamma(3.0, 0.35, E); sid = np.zeros(E, np.int32)
     sh = SampleHandlerFD(eng, 1, np.array([0, 200], np.int32), par, capi.kBarlowBeeston)
-    sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sid, 200), rng.integers(-1, 4000, E).astype(np.int32), None, None)
-    h.SetEventSplines(0, w_off, w_idx); sh.SetOscillationWeights(rng.random(4000).astype(float_t))
+    n_osc = int(os.environ.get("BINNED_OSC_N", "4000"))  # (204000: an atmospheric table; the events' look-ups are then a line each unless the engine orders them)
+    sh.SetupEvents(0, synth.find_global_bin_uniform_1d(edges, kin, sid, 200), rng.integers(-1, n_osc, E).astype(np.int32), None, None)
+    h.SetEventSplines(0, w_off, w_idx); sh.SetOscillationWeights(rng.random(n_osc).astype(float_t))
     sh.Reweight(); sh.AddData(sh.GetMCArray())
     def step():
         par[:P] = rng.uniform(-2, 2, P); return sh.Step()
     eng.timing_enable(True); us = timeit(step); k_ms,_ = eng.timing_read(0)
-    print(f"binned float_t={np.dtype(float_t).name} sorted_by_cell={sort_by_cell}: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: "
+    print(f"binned float_t={np.dtype(float_t).name} sorted_by_cell={sort_by_cell} osc_entries={n_osc}: E={E} M={P*cells} unique={len(bs['uniquecoeffindices'])} weights/event={cnt.mean():.1f}: "
           f"step {us:.1f} us, event kernel {k_ms*1e3:.1f} us ({(w_idx.nbytes + 8*E)/k_ms/1e6:.0f} GB/s of index+bin/osc bytes)", flush=True)
     eng.close()
 
